@@ -1,0 +1,261 @@
+"""TEST INFRASTRUCTURE -- ctypes bindings for the two CPU checkers.
+
+* ``load_oracle()``      -> oracle/liboracle.so   (CPU restatement, oracle/oracle.cc)
+* ``load_ref(seeded)``   -> oracle/_ref/libref_{seeded,native}.so (the REAL reference
+  sources compiled in place; prebuilt in the build container, they travel to the
+  GPU box as binaries; returns None when absent)
+
+Both expose the same C API (prefix ``oracle_`` / ``ref_``), wrapped by ``Checker``.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+MAT_LAMBERTIAN, MAT_MIRROR, MAT_DIELECTRIC, MAT_MICROFACET, MAT_METAL, MAT_DIFFUSE_LIGHT = range(6)
+
+TRI_DTYPE = np.dtype([
+    ("v0", "f4", 3), ("v1", "f4", 3), ("v2", "f4", 3),
+    ("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3),
+    ("st", "f4", 6),  # s0 t0 s1 t1 s2 t2
+    ("material", "i4"), ("shape", "i4"),
+])
+assert TRI_DTYPE.itemsize == 104
+
+MAT_DTYPE = np.dtype([
+    ("type", "i4"), ("albedo", "f4", 3), ("roughness", "f4"), ("metallic", "f4"),
+    ("emissive", "f4", 3), ("ior", "f4"), ("transmission", "f4", 3), ("fuzziness", "f4"),
+    ("texAlbedo", "i4"), ("texNormal", "i4"), ("texRoughness", "i4"), ("texMetallic", "i4"), ("texEmissive", "i4"),
+])
+assert MAT_DTYPE.itemsize == 76
+
+HIT_DTYPE = np.dtype([
+    ("hit", "i4"), ("t", "f4"), ("p", "f4", 3), ("n", "f4", 3), ("paramU", "f4"), ("paramV", "f4"), ("material", "i4"),
+])
+assert HIT_DTYPE.itemsize == 44
+
+
+class FlatTexture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", C.POINTER(C.c_float))]
+
+
+class FlatCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lookAt", C.c_float * 3),
+                ("fovY_degrees", C.c_float), ("aspectWH", C.c_float),
+                ("aperture", C.c_float), ("focalDistance", C.c_float),
+                ("beginTime", C.c_float), ("endTime", C.c_float)]
+
+
+class FlatSettings(C.Structure):
+    _fields_ = [("viewportWidth", C.c_uint32), ("viewportHeight", C.c_uint32),
+                ("samplesPerPixel", C.c_int32), ("maxPathLength", C.c_int32),
+                ("rayTMin", C.c_float), ("renderMode", C.c_uint32)]
+
+
+class FlatSceneDesc(C.Structure):
+    _fields_ = [("triangles", C.c_void_p), ("numTriangles", C.c_int32),
+                ("materials", C.c_void_p), ("numMaterials", C.c_int32),
+                ("textures", C.POINTER(FlatTexture)), ("numTextures", C.c_int32),
+                ("numShapes", C.c_int32),
+                ("sunIlluminance", C.c_float * 3), ("sunDirection", C.c_float * 3),
+                ("skyTexture", C.c_int32)]
+
+
+class OracleCounters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("cameraSamples", C.c_uint64)]
+
+
+def make_camera(origin, look_at, fov_y, aspect, aperture=0.0, focal=1.0, t0=0.0, t1=0.0):
+    c = FlatCamera()
+    c.origin[:] = [float(x) for x in origin]
+    c.lookAt[:] = [float(x) for x in look_at]
+    c.fovY_degrees, c.aspectWH = float(fov_y), float(aspect)
+    c.aperture, c.focalDistance = float(aperture), float(focal)
+    c.beginTime, c.endTime = float(t0), float(t1)
+    return c
+
+
+def make_settings(w, h, spp, max_path=5, tmin=1e-4, mode=0):
+    return FlatSettings(int(w), int(h), int(spp), int(max_path), float(tmin), int(mode))
+
+
+class FlatScene:
+    """Host-side flat scene: numpy arrays + textures; builds a FlatSceneDesc on demand."""
+
+    def __init__(self, triangles, materials, textures=(), num_shapes=None,
+                 sun_illuminance=(0, 0, 0), sun_direction=(0.0, -1.0, -0.5), sky_texture=-1):
+        self.triangles = np.ascontiguousarray(triangles, dtype=TRI_DTYPE)
+        self.materials = np.ascontiguousarray(materials, dtype=MAT_DTYPE)
+        self.textures = [np.ascontiguousarray(t, dtype=np.float32) for t in textures]  # each (H, W, 4)
+        self.num_shapes = int(num_shapes if num_shapes is not None else (self.triangles["shape"].max() + 1 if len(self.triangles) else 1))
+        self.sun_illuminance = tuple(float(x) for x in sun_illuminance)
+        self.sun_direction = tuple(float(x) for x in sun_direction)
+        self.sky_texture = int(sky_texture)
+
+    def desc(self):
+        d = FlatSceneDesc()
+        d.triangles = self.triangles.ctypes.data
+        d.numTriangles = len(self.triangles)
+        d.materials = self.materials.ctypes.data
+        d.numMaterials = len(self.materials)
+        self._tex_structs = (FlatTexture * max(1, len(self.textures)))()
+        for i, t in enumerate(self.textures):
+            self._tex_structs[i].height, self._tex_structs[i].width = t.shape[0], t.shape[1]
+            self._tex_structs[i].rgba = t.ctypes.data_as(C.POINTER(C.c_float))
+        d.textures = self._tex_structs
+        d.numTextures = len(self.textures)
+        d.numShapes = self.num_shapes
+        d.sunIlluminance[:] = self.sun_illuminance
+        d.sunDirection[:] = self.sun_direction
+        d.skyTexture = self.sky_texture
+        return d
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Checker:
+    """Uniform wrapper over liboracle.so (prefix 'oracle_') or libref_*.so (prefix 'ref_')."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.prefix = lib, prefix
+        f = self._f
+        f("scene_create").restype = C.c_void_p
+        f("scene_create").argtypes = [C.POINTER(FlatSceneDesc), C.c_uint64]
+        f("scene_destroy").argtypes = [C.c_void_p]
+        f("render").argtypes = [C.c_void_p, C.POINTER(FlatCamera), C.POINTER(FlatSettings), C.c_uint64, C.c_int32,
+                                C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        f("closest_hit").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]
+        f("aabb_hit").argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_float, C.c_void_p]
+        f("triangle_hit").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_float, C.c_void_p]
+        f("onb").argtypes = [C.POINTER(C.c_float)] * 2 + [C.c_int32] + [C.POINTER(C.c_float)] * 2
+        f("camera_rays").argtypes = [C.POINTER(FlatCamera), C.POINTER(C.c_float), C.c_int32, C.c_uint64, C.POINTER(C.c_float)]
+        f("scatter").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_uint64, C.POINTER(C.c_float)]
+        f("texture_sample").argtypes = [C.POINTER(FlatTexture), C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]
+        f("bvh_stats").argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        if prefix == "oracle_":
+            lib.oracle_get_counters.argtypes = [C.c_void_p, C.POINTER(OracleCounters)]
+            lib.oracle_material_from_mtl.argtypes = [C.POINTER(C.c_float)] * 4 + [C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p]
+            lib.oracle_postprocess.argtypes = [C.POINTER(C.c_float), C.c_int64]
+        else:
+            lib.ref_render_native.argtypes = [C.c_void_p, C.POINTER(FlatCamera), C.POINTER(FlatSettings), C.POINTER(C.c_float)]
+            lib.ref_is_seeded.restype = C.c_int32
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    # -- scene ---------------------------------------------------------------
+    def scene_create(self, flat, build_seed=1):
+        self._keep = flat  # the scene borrows texture memory only during create, but keep anyway
+        d = flat.desc()
+        return self._f("scene_create")(C.byref(d), build_seed)
+
+    def scene_destroy(self, h):
+        self._f("scene_destroy")(h)
+
+    def render(self, scene, camera, settings, seed=1, threads=None, want_samples=False):
+        w, h = settings.viewportWidth, settings.viewportHeight
+        out = np.zeros((h, w, 4), np.float32)
+        spp = max(1, settings.samplesPerPixel)
+        samples = np.zeros((h, w, spp, 3), np.float32) if want_samples else None
+        threads = threads or (os.cpu_count() or 1)
+        self._f("render")(scene, C.byref(camera), C.byref(settings), seed, threads, _fp(out),
+                          _fp(samples) if want_samples else None)
+        return (out, samples) if want_samples else out
+
+    def render_native(self, scene, camera, settings):
+        w, h = settings.viewportWidth, settings.viewportHeight
+        out = np.zeros((h, w, 4), np.float32)
+        self.lib.ref_render_native(scene, C.byref(camera), C.byref(settings), _fp(out))
+        return out
+
+    def counters(self, scene):
+        c = OracleCounters()
+        self.lib.oracle_get_counters(scene, C.byref(c))
+        return {"rays": c.rays, "nodes_visited": c.nodesVisited, "tris_tested": c.trisTested, "camera_samples": c.cameraSamples}
+
+    # -- known-answer helpers --------------------------------------------------
+    def closest_hit(self, scene, rays, tmin=1e-4):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), HIT_DTYPE)
+        self._f("closest_hit")(scene, _fp(rays), len(rays), tmin, out.ctypes.data)
+        return out
+
+    def aabb_hit(self, boxes, rays, tmin, tmax):
+        boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), np.int32)
+        self._f("aabb_hit")(_fp(boxes), _fp(rays), len(rays), tmin, tmax, out.ctypes.data)
+        return out
+
+    def triangle_hit(self, tris, rays, tmin, tmax):
+        tris = np.ascontiguousarray(tris, TRI_DTYPE)
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), HIT_DTYPE)
+        self._f("triangle_hit")(tris.ctypes.data, _fp(rays), len(rays), tmin, tmax, out.ctypes.data)
+        return out
+
+    def onb(self, normals, vecs):
+        normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        vecs = np.ascontiguousarray(vecs, np.float32).reshape(-1, 3)
+        a = np.zeros_like(vecs)
+        b = np.zeros_like(vecs)
+        self._f("onb")(_fp(normals), _fp(vecs), len(vecs), _fp(a), _fp(b))
+        return a, b
+
+    def camera_rays(self, camera, uv, seed=1):
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((len(uv), 7), np.float32)
+        self._f("camera_rays")(C.byref(camera), _fp(uv), len(uv), seed, _fp(out))
+        return out
+
+    def scatter(self, scene, material, records, seed=1):
+        records = np.ascontiguousarray(records, np.float32).reshape(-1, 16)
+        out = np.zeros((len(records), 16), np.float32)
+        self._f("scatter")(scene, material, _fp(records), len(records), seed, _fp(out))
+        return out
+
+    def texture_sample(self, tex, srgb, uv):
+        tex = np.ascontiguousarray(tex, np.float32)
+        t = FlatTexture(tex.shape[1], tex.shape[0], _fp(tex))
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((len(uv), 4), np.float32)
+        self._f("texture_sample")(C.byref(t), int(srgb), _fp(uv), len(uv), _fp(out))
+        return out
+
+    def bvh_stats(self, scene):
+        n, d = C.c_int64(0), C.c_int32(0)
+        self._f("bvh_stats")(scene, C.byref(n), C.byref(d))
+        return n.value, d.value
+
+    # -- oracle-only -------------------------------------------------------------
+    def material_from_mtl(self, Kd, Ks, Ke, Tf, Ns, Ni, illum, Pr, Pm, has_map_kd):
+        arrs = [np.asarray(a, np.float32) for a in (Kd, Ks, Ke, Tf)]
+        out = np.zeros(1, MAT_DTYPE)
+        self.lib.oracle_material_from_mtl(*[_fp(a) for a in arrs], Ns, Ni, illum, Pr, Pm, int(has_map_kd), out.ctypes.data)
+        return out[0]
+
+    def postprocess(self, rgba):
+        rgba = np.ascontiguousarray(rgba, np.float32).copy()
+        self.lib.oracle_postprocess(_fp(rgba), rgba.size // 4)
+        return rgba
+
+
+def load_oracle():
+    path = os.path.join(HERE, "liboracle.so")
+    if not os.path.exists(path):
+        raise FileNotFoundError(path + " (run `make -C oracle` or __graft_entry__.build())")
+    return Checker(C.CDLL(path), "oracle_")
+
+
+def load_ref(seeded=True):
+    path = os.path.join(HERE, "_ref", "libref_seeded.so" if seeded else "libref_native.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return Checker(C.CDLL(path), "ref_")
+    except OSError:
+        return None

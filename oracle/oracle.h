@@ -1,0 +1,47 @@
+/*
+ * TEST INFRASTRUCTURE -- C API of the CPU oracle (oracle/oracle.cc).
+ * Same entry points as oracle/ref_glue.cc (prefix oracle_ instead of ref_) so
+ * that tests can run one set of inputs through both and compare bit for bit.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include "flat_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OracleCounters {
+	uint64_t rays;          /* closest-hit / occlusion queries (reference renderer.cc:129,194,70,79) */
+	uint64_t nodesVisited;  /* BVHNode::Hit calls whose box test ran (reference bvh.cc:82-84) */
+	uint64_t trisTested;    /* Triangle::Hit calls (reference triangle.cc:18) */
+	uint64_t cameraSamples;
+} OracleCounters;
+
+void*   oracle_scene_create(const FlatSceneDesc* desc, uint64_t buildSeed);
+void    oracle_scene_destroy(void* scene);
+void    oracle_render(void* scene, const FlatCamera* cam, const FlatSettings* st, uint64_t seed,
+                      int32_t numThreads, float* outRGBA, float* outSamples);
+void    oracle_get_counters(void* scene, OracleCounters* out);   /* counters of the last oracle_render */
+void    oracle_closest_hit(void* scene, const float* rays, int32_t n, float tMin, FlatHit* out);
+void    oracle_aabb_hit(const float* boxes, const float* rays, int32_t n, float tMin, float tMax, int32_t* out);
+void    oracle_triangle_hit(const FlatTriangle* tris, const float* rays, int32_t n, float tMin, float tMax, FlatHit* out);
+void    oracle_onb(const float* normals, const float* vecs, int32_t n, float* outLocal, float* outWorld);
+void    oracle_camera_rays(const FlatCamera* cam, const float* uv, int32_t n, uint64_t seed, float* out);
+void    oracle_scatter(void* scene, int32_t material, const float* in, int32_t n, uint64_t seed, float* out);
+void    oracle_texture_sample(const FlatTexture* t, int32_t bSRGB, const float* uv, int32_t n, float* out);
+void    oracle_bvh_stats(void* scene, int64_t* outNodes, int32_t* outDepth);
+/* MTL -> material mapping (reference loader/obj_loader.cc:354-397).  Inputs are the
+ * tinyobjloader material_t fields the reference reads. */
+void    oracle_material_from_mtl(const float Kd[3], const float Ks[3], const float Ke[3], const float Tf[3],
+                                 float Ns, float Ni, int32_t illum, float Pr, float Pm,
+                                 int32_t hasMapKd, FlatMaterial* out);
+/* Image2D::PostProcess (reference render/image.cc:44-103), in place on n RGBA pixels. */
+void    oracle_postprocess(float* rgba, int64_t numPixels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

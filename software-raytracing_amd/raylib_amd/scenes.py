@@ -1,0 +1,207 @@
+"""Deterministic synthetic OBJ+MTL scene generators.
+
+The reference's named scenes (Cornell Box, Breakfast Room, Sponza, San Miguel) are
+downloaded by its Setup.ps1:42-79 and are not available offline, so every
+BASELINE.json config runs on a synthetic stand-in of matching triangle count that
+goes through the same OBJ path (Raylib_LoadOBJModel).  Cameras / suns follow the
+reference's scenes.json and src/main.cc:64-155.
+
+All coordinates are float32 and are printed with 9 significant digits, so any
+conforming OBJ parser recovers the same float32 values.
+"""
+import math
+import os
+import numpy as np
+
+WHITE, RED, GREEN, LIGHT, MIRROR, GLASS, CUTOUT = "white", "red", "green", "light", "mirror", "glass", "cutout"
+
+CORNELL_MTL = """# synthetic Cornell box materials (Ns 10, Ks 0 => roughness sqrt(2/(10*0+2)) = 1)
+newmtl white
+Ns 10
+Ka 0 0 0
+Kd 0.725 0.71 0.68
+Ks 0 0 0
+illum 2
+
+newmtl red
+Ns 10
+Kd 0.63 0.065 0.05
+Ks 0 0 0
+illum 2
+
+newmtl green
+Ns 10
+Kd 0.14 0.45 0.091
+Ks 0 0 0
+illum 2
+
+newmtl light
+Ns 10
+Kd 0.78 0.78 0.78
+Ks 0 0 0
+Ke 17 12 4
+illum 2
+
+newmtl mirror
+Ns 10
+Kd 0.9 0.9 0.9
+Ks 0 0 0
+illum 3
+
+newmtl glass
+Ns 10
+Kd 0 0 0
+Ks 0 0 0
+Tf 0.95 0.97 0.95
+Ni 1.5
+illum 4
+"""
+
+
+def _f(x):
+    return "%.9g" % float(np.float32(x))
+
+
+def _quad(p0, p1, p2, p3):
+    return np.array([p0, p1, p2, p3], np.float32)
+
+
+def _box(center, size, yaw_deg):
+    """6 outward-facing quads of a box rotated about +y."""
+    cx, cy, cz = center
+    hx, hy, hz = size[0] / 2, size[1] / 2, size[2] / 2
+    c, s = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+
+    def P(x, y, z):
+        return (cx + c * x + s * z, cy + y, cz - s * x + c * z)
+
+    quads = [
+        _quad(P(-hx, hy, -hz), P(-hx, hy, hz), P(hx, hy, hz), P(hx, hy, -hz)),      # top
+        _quad(P(-hx, -hy, -hz), P(hx, -hy, -hz), P(hx, -hy, hz), P(-hx, -hy, hz)),  # bottom
+        _quad(P(-hx, -hy, hz), P(hx, -hy, hz), P(hx, hy, hz), P(-hx, hy, hz)),      # front (+z)
+        _quad(P(hx, -hy, -hz), P(-hx, -hy, -hz), P(-hx, hy, -hz), P(hx, hy, -hz)),  # back
+        _quad(P(hx, -hy, hz), P(hx, -hy, -hz), P(hx, hy, -hz), P(hx, hy, hz)),      # right
+        _quad(P(-hx, -hy, -hz), P(-hx, -hy, hz), P(-hx, hy, hz), P(-hx, hy, -hz)),  # left
+    ]
+    return quads
+
+
+def cornell_objects(tall_material=MIRROR, short_material=WHITE):
+    """[(shape name, material, [quads])] -- 18 quads = 36 triangles."""
+    return [
+        ("floor", WHITE, [_quad((-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1))]),
+        ("ceiling", WHITE, [_quad((-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1))]),
+        ("backwall", WHITE, [_quad((-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1))]),
+        ("leftwall", RED, [_quad((-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1))]),
+        ("rightwall", GREEN, [_quad((1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1))]),
+        ("light", LIGHT, [_quad((-0.24, 1.98, -0.22), (0.23, 1.98, -0.22), (0.23, 1.98, 0.16), (-0.24, 1.98, 0.16))]),
+        ("shortbox", short_material, _box((0.33, 0.3, 0.35), (0.6, 0.6, 0.6), -17.0)),
+        ("tallbox", tall_material, _box((-0.33, 0.6, -0.3), (0.6, 1.2, 0.6), 17.0)),
+    ]
+
+
+def _tessellate(quad, k):
+    """Split a quad into k*k cells -> list of triangles (3x3 arrays) with UVs (3x2)."""
+    p0, p1, p2, p3 = [quad[i].astype(np.float64) for i in range(4)]
+    tris = []
+
+    def P(u, v):
+        return ((1 - u) * (1 - v)) * p0 + (u * (1 - v)) * p1 + (u * v) * p2 + ((1 - u) * v) * p3
+
+    for j in range(k):
+        for i in range(k):
+            u0, u1, v0, v1 = i / k, (i + 1) / k, j / k, (j + 1) / k
+            a, b, c, d = P(u0, v0), P(u1, v0), P(u1, v1), P(u0, v1)
+            tris.append((np.array([a, b, c]), np.array([[u0, v0], [u1, v0], [u1, v1]])))
+            tris.append((np.array([a, c, d]), np.array([[u0, v0], [u1, v1], [u0, v1]])))
+    return tris
+
+
+def write_obj(path, objects, mtl_text, tess=1, with_normals=True, with_uvs=True,
+              displace_fraction=0.0, displace_seed=7, room=((-1, 1), (0, 2), (-1, 1)), extra_mtl=""):
+    """Write <path>.obj and <path>.mtl; return the .obj path and the triangle count."""
+    base = os.path.splitext(path)[0]
+    mtl_name = os.path.basename(base) + ".mtl"
+    rng = np.random.RandomState(displace_seed)
+    n_tri = 0
+    vi = 1
+    with open(base + ".obj", "w") as f:
+        f.write("# synthetic scene (raylib_amd.scenes)\nmtllib %s\n" % mtl_name)
+        for name, material, quads in objects:
+            f.write("o %s\nusemtl %s\n" % (name, material))
+            for quad in quads:
+                for tri, uv in _tessellate(quad, tess):
+                    tri = tri.astype(np.float32)
+                    if displace_fraction > 0 and rng.rand() < displace_fraction:
+                        # move this triangle to a random place inside the room (keeps its size and facing)
+                        centre = tri.mean(axis=0)
+                        target = np.array([rng.uniform(lo + 0.05, hi - 0.05) for lo, hi in room], np.float32)
+                        tri = (tri - centre + target).astype(np.float32)
+                    n = np.cross(tri[1].astype(np.float64) - tri[0], tri[2].astype(np.float64) - tri[0])
+                    n = (n / max(np.linalg.norm(n), 1e-30)).astype(np.float32)
+                    for p in tri:
+                        f.write("v %s %s %s\n" % (_f(p[0]), _f(p[1]), _f(p[2])))
+                    if with_uvs:
+                        for t in uv:
+                            f.write("vt %s %s\n" % (_f(t[0]), _f(t[1])))
+                    if with_normals:
+                        f.write("vn %s %s %s\n" % (_f(n[0]), _f(n[1]), _f(n[2])))
+                    idx = []
+                    for c in range(3):
+                        s = str(vi + c)
+                        if with_uvs or with_normals:
+                            s += "/" + (str(vi + c) if with_uvs else "")
+                        if with_normals:
+                            s += "/" + str((vi - 1) // 3 + 1)
+                        idx.append(s)
+                    f.write("f %s\n" % " ".join(idx))
+                    vi += 3
+                    n_tri += 1
+    with open(base + ".mtl", "w") as f:
+        f.write(mtl_text + extra_mtl)
+    return base + ".obj", n_tri
+
+
+# ---------------------------------------------------------------------------------
+# BASELINE.json configs
+
+def cornell(path, tess=1, displace_fraction=0.0, tall_material=MIRROR, short_material=WHITE, **kw):
+    """C1/C2: 36-triangle Cornell box (tess=1).  C3: tess=91 + displace 0.2 -> 298 116 triangles."""
+    return write_obj(path, cornell_objects(tall_material, short_material), CORNELL_MTL, tess=tess,
+                     displace_fraction=displace_fraction, **kw)
+
+
+def colonnade_objects(n_columns=24, segments=24):
+    """C4 'Sponza-size' stand-in: a long hall with two rows of faceted columns."""
+    objs = [
+        ("floor", WHITE, [_quad((-14, 0, 6), (14, 0, 6), (14, 0, -6), (-14, 0, -6))]),
+        ("wall_n", WHITE, [_quad((-14, 0, -6), (14, 0, -6), (14, 8, -6), (-14, 8, -6))]),
+        ("wall_s", RED, [_quad((14, 0, 6), (-14, 0, 6), (-14, 8, 6), (14, 8, 6))]),
+        ("wall_w", GREEN, [_quad((-14, 0, 6), (-14, 0, -6), (-14, 8, -6), (-14, 8, 6))]),
+        ("wall_e", WHITE, [_quad((14, 0, -6), (14, 0, 6), (14, 8, 6), (14, 8, -6))]),
+    ]
+    for ci in range(n_columns):
+        row = ci % 2
+        x = -12.0 + (ci // 2) * (24.0 / max(1, n_columns // 2 - 1))
+        z = -3.0 if row == 0 else 3.0
+        quads = []
+        r = 0.45
+        for s in range(segments):
+            a0, a1 = 2 * math.pi * s / segments, 2 * math.pi * (s + 1) / segments
+            x0, z0, x1, z1 = x + r * math.cos(a0), z + r * math.sin(a0), x + r * math.cos(a1), z + r * math.sin(a1)
+            quads.append(_quad((x1, 0, z1), (x0, 0, z0), (x0, 6, z0), (x1, 6, z1)))
+        objs.append(("column%02d" % ci, MIRROR if ci % 7 == 3 else WHITE, quads))
+    return objs
+
+
+def colonnade(path, tess=6, **kw):
+    """C4: 24 columns x 24 facets + 5 walls = 581 quads; tess=6 -> 41 832, tess=12 -> 167 328 triangles."""
+    return write_obj(path, colonnade_objects(), CORNELL_MTL, tess=tess, **kw)
+
+
+# Cameras / suns per config (reference scenes.json, src/main.cc:64-155)
+CONFIG_CAMERAS = {
+    "cornell":   dict(origin=(0.0, 1.0, 4.0), look_at=(0.0, 1.0, -1.0), fov=45.0, sun=(0.0, 0.0, 0.0), sun_dir=(0.0, -1.0, -0.5)),
+    "breakfast": dict(origin=(0.0, 1.0, 5.0), look_at=(0.0, 1.0, -1.0), fov=60.0, sun=(20.0, 20.0, 20.0), sun_dir=(-1.0, -1.0, 0.0)),
+    "sponza":    dict(origin=(10.0, 2.0, 0.0), look_at=(0.0, 3.0, 0.0), fov=60.0, sun=(20.0, 20.0, 20.0), sun_dir=(0.0, -1.0, -0.5)),
+}
