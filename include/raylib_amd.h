@@ -1,0 +1,103 @@
+/*
+ * raylib_amd.h -- ADDITIONAL exports of the MI355X raylib.  Nothing here exists in
+ * the reference; raylib.h alone is the drop-in surface.  These exist because the
+ * reference has no seed, no counters and no device boundary:
+ *   - a deterministic seed (RendererSettings has no seed field and
+ *     must not grow one, reference raylib_types.h:41-57)
+ *   - ray / node / triangle counters (the reference cannot report Mrays/s,
+ *     render/renderer.cc:114-208 has no counter)
+ *   - a render entry that leaves the pixels in HBM and can restrict the work to a
+ *     strided subset of the 8x8 cells (reference render/renderer.cc:21-22,305-319),
+ *     which is how bench.py tiles an image over N ranks (one process per GPU)
+ *   - host-logic introspection for CPU-only tests (flattened scene, BVH)
+ *
+ * Environment variables read by the library:
+ *   RAYLIB_SEED    default seed (decimal, default 1) when RaylibAMD_SetSeed was not called
+ *   RAYLIB_DEVICE  HIP device ordinal to use (default: LOCAL_RANK if set, else 0)
+ */
+#ifndef RAYLIB_AMD_H
+#define RAYLIB_AMD_H
+
+#include "raylib_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RaylibAMDStats {
+	uint64_t rays;            /* closest-hit + occlusion queries (reference renderer.cc:129,194,70,79) */
+	uint64_t nodesVisited;    /* 64-byte BVH node records fetched */
+	uint64_t trisTested;      /* 64-byte triangle intersection records fetched */
+	uint64_t shadedHits;      /* 64-byte triangle shading records fetched */
+	uint64_t texFetches;      /* 16-byte texels fetched */
+	uint64_t cameraSamples;   /* (pixel, sample) paths traced */
+	uint64_t pixels;          /* pixels written (16 bytes each) */
+	double   kernelMs;        /* HIP-event time of all kernels of the last render, on the library's stream */
+	double   traceKernelMs;   /* ... of the path-tracing megakernel launches only */
+	double   wallMs;          /* host wall clock of the last render call, incl. D2H copy when made */
+	uint32_t traceLaunches;   /* megakernel launches in the last render (one per sample batch) */
+	uint32_t numNodes;        /* BVH nodes of the scene */
+	uint32_t numTriangles;
+	uint32_t bvhDepth;
+} RaylibAMDStats;
+
+/* Seed of the per-(pixel, sample) streams of include/raylib_amd_rng.h. */
+RAYLIB_API void     RaylibAMD_SetSeed(uint64_t seed);
+RAYLIB_API uint64_t RaylibAMD_GetSeed(void);
+
+/* Stats of the last Raylib_Render / RaylibAMD_RenderDevice on this thread's library state. */
+RAYLIB_API void RaylibAMD_GetLastStats(RaylibAMDStats* outStats);
+
+/* 1 when a gfx950-capable HIP device is present and the kernels are loadable. */
+RAYLIB_API int32_t RaylibAMD_DeviceAvailable(void);
+
+/*
+ * Render the cells {cellFirst, cellFirst + cellStride, ...} (8x8-pixel cells numbered
+ * row-major over ceil(W/8) x ceil(H/8)) and leave RGBA float pixels in device memory.
+ *   outDevice: device pointer; when cellStride == 1 && cellFirst == 0 it receives the
+ *              row-major W*H*4-float image; otherwise it receives the rank's cells
+ *              back to back, 64 pixels (row-major inside the cell) * 4 floats each.
+ *              Must hold RaylibAMD_CellBufferFloats(...) floats.  May be 0: the
+ *              library then renders into its own buffer (bench timing without output).
+ * Returns 1 on success, 0 on failure (no device, bad handle).  Synchronous: the
+ * library's stream has been synchronised when it returns.
+ */
+RAYLIB_API int32_t RaylibAMD_RenderDevice(const RendererSettings* settings, SceneHandle scene,
+	CameraHandle camera, uint32_t cellFirst, uint32_t cellStride, void* outDevice);
+RAYLIB_API uint64_t RaylibAMD_CellBufferFloats(uint32_t width, uint32_t height, uint32_t cellFirst, uint32_t cellStride);
+RAYLIB_API uint32_t RaylibAMD_NumCells(uint32_t width, uint32_t height);
+
+/* Closest-hit queries on the flat BVH (rays: n*6 floats o,d; out: n*11 words
+ * {hit, t, p[3], n[3], paramU, paramV, material} as in oracle/flat_scene.h FlatHit). */
+RAYLIB_API int32_t RaylibAMD_ClosestHit(SceneHandle scene, const float* rays, int32_t n, float tMin, void* outHits);
+
+/* ---- host-logic introspection (no GPU needed) ---------------------------------- */
+/* Flattened scene as the kernels see it.  Triangle record = 26 words, material record =
+ * 19 words, both laid out as oracle/flat_scene.h FlatTriangle / FlatMaterial. */
+RAYLIB_API int32_t RaylibAMD_SceneNumTriangles(SceneHandle scene);
+RAYLIB_API int32_t RaylibAMD_SceneNumMaterials(SceneHandle scene);
+RAYLIB_API int32_t RaylibAMD_SceneNumTextures(SceneHandle scene);
+RAYLIB_API void    RaylibAMD_SceneExportTriangles(SceneHandle scene, void* outTriangles);
+RAYLIB_API void    RaylibAMD_SceneExportMaterials(SceneHandle scene, void* outMaterials);
+RAYLIB_API void    RaylibAMD_SceneTextureSize(SceneHandle scene, int32_t index, int32_t* outW, int32_t* outH);
+RAYLIB_API void    RaylibAMD_SceneExportTexture(SceneHandle scene, int32_t index, float* outRGBA);
+RAYLIB_API void    RaylibAMD_SceneGetSun(SceneHandle scene, float outIlluminance[3], float outDirection[3]);
+/* BVH shape: nodes (64 B each), depth, and a host-side validity check (every triangle
+ * inside its leaf's box, every child box inside its parent's).  Returns 1 if valid. */
+RAYLIB_API int32_t RaylibAMD_SceneBVHInfo(SceneHandle scene, uint32_t* outNodes, uint32_t* outDepth, float* outSahCost);
+/* Camera derived state: 19 floats origin(3) lensRadius top_left(3) horizontal(3) vertical(3) u(3) v(3)
+ * (reference render/camera.h:55-78). */
+RAYLIB_API void    RaylibAMD_CameraExport(CameraHandle camera, float out[19]);
+/* Create an image from caller memory (RGBA float, row 0 = top): lets tests use textures
+ * and sky panoramas without an image codec. */
+RAYLIB_API ImageHandle RaylibAMD_CreateImageFromData(uint32_t width, uint32_t height, const float* rgba);
+/* Copy RGBA (4 floats per pixel) of an image to caller memory. */
+RAYLIB_API void    RaylibAMD_DumpImageRGBA(ImageHandle image, float* outRGBA);
+/* Replace a material's texture by an image handle (slot: 0 albedo, 1 normal, 2 roughness,
+ * 3 metallic, 4 emissive) -- the OBJ loader does the same from map_* statements. */
+RAYLIB_API int32_t RaylibAMD_OBJModelSetTexture(OBJModelHandle obj, const char* materialName, int32_t slot, ImageHandle image);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYLIB_AMD_H */

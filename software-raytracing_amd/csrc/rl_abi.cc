@@ -1,0 +1,390 @@
+// The C-ABI of the MI355X raylib: the 33 entry points of include/raylib.h (one per
+// reference function, reference raylib/raylib.cc:25-331) plus the additional exports
+// of include/raylib_amd.h.  Handles are raw pointers kept in mutex-guarded registries,
+// as in the reference (raylib.cc:18-21, core/concurrent_vector.h:8-49).
+#include "raylib.h"
+#include "raylib_amd.h"
+#include "rl_host.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+
+using namespace rl;
+
+namespace {
+
+template <typename T>
+struct Registry {
+	std::mutex mu;
+	std::vector<T*> items;
+	void add(T* p) { std::lock_guard<std::mutex> lk(mu); items.push_back(p); }
+	bool eraseFirst(T* p) {
+		std::lock_guard<std::mutex> lk(mu);
+		auto it = std::find(items.begin(), items.end(), p);
+		if (it == items.end()) return false;
+		items.erase(it);
+		return true;
+	}
+	bool contains(T* p) { std::lock_guard<std::mutex> lk(mu); return std::find(items.begin(), items.end(), p) != items.end(); }
+};
+Registry<OBJModel> g_objModels;
+Registry<Camera>   g_cameras;
+Registry<Image>    g_images;
+Registry<Scene>    g_scenes;
+
+std::mutex g_stateMu;
+uint64_t g_seed = 1;
+bool g_seedSet = false;
+RaylibAMDStats g_lastStats;
+
+uint64_t CurrentSeed()
+{
+	std::lock_guard<std::mutex> lk(g_stateMu);
+	if (!g_seedSet) {
+		if (const char* e = getenv("RAYLIB_SEED")) g_seed = strtoull(e, nullptr, 10);
+		g_seedSet = true;
+	}
+	return g_seed;
+}
+
+bool RenderInternal(const RendererSettings* settings, Scene* scene, Camera* camera,
+                    uint32_t cellFirst, uint32_t cellStride, void* outDevice, float* outHost)
+{
+	if (!settings || !scene || !camera) { Log("Raylib_Render: null argument"); return false; }
+	if (!scene->finalized) { Log("Raylib_Render: scene was not finalized (Raylib_FinalizeScene)"); return false; }
+	if (settings->renderMode >= RAYLIB_RENDERMODE_MAX) { Log("Raylib_Render: invalid render mode %u", settings->renderMode); return false; }
+	RenderRequest req;
+	req.settings = *settings;
+	req.camera = camera->ToDevice();
+	req.seed = CurrentSeed();
+	req.cellFirst = cellFirst; req.cellStride = cellStride;
+	req.outDevice = outDevice; req.outHostRGBA = outHost;
+	RaylibAMDStats stats; memset(&stats, 0, sizeof(stats));
+	bool ok = DeviceRender(*scene, req, stats);
+	{ std::lock_guard<std::mutex> lk(g_stateMu); g_lastStats = stats; }
+	return ok;
+}
+
+} // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// reference raylib.cc:25-51
+int32_t Raylib_Initialize(void)
+{
+	printf("Initialize raylib\n");
+	LogStart();
+	if (!DeviceAvailable()) {
+		fprintf(stderr, "Raylib_Initialize: no usable HIP device (gfx950) -- this library has no CPU render path\n");
+		return 0;
+	}
+	Log("Initialize obj loader");
+	return 1;
+}
+
+int32_t Raylib_Terminate(void)
+{
+	printf("Terminate raylib\n");
+	Log("Destroy obj loader");
+	LogStop();
+	return 0;   // the reference returns 0 here despite its header comment (raylib.cc:50)
+}
+
+// ---------------------------------------------------------------------------
+// reference raylib.cc:56-113
+OBJModelHandle Raylib_LoadOBJModel(const char* objPath)
+{
+	OBJModel* m = new OBJModel;
+	if (LoadOBJ(objPath, *m)) { g_objModels.add(m); return (OBJModelHandle)m; }
+	delete m;
+	return 0;
+}
+
+void Raylib_TransformOBJModel(OBJModelHandle h, float tx, float ty, float tz, float yaw, float pitch, float roll, float sx, float sy, float sz)
+{
+	if (!h) return;
+	TransformOBJ(*(OBJModel*)h, tx, ty, tz, yaw, pitch, roll, sx, sy, sz);
+}
+
+void Raylib_FinalizeOBJModel(OBJModelHandle h)
+{
+	if (!h) return;
+	((OBJModel*)h)->finalized = true;   // locks geometry (reference geom/static_mesh.cc:80-95); the BVH is built per scene
+}
+
+int32_t Raylib_UnloadOBJModel(OBJModelHandle h)
+{
+	OBJModel* m = (OBJModel*)h;
+	if (g_objModels.eraseFirst(m)) { delete m; return 1; }
+	return 0;
+}
+
+ImageHandle Raylib_LoadImage(const char* filepath)
+{
+	Image* img = LoadImageFile(filepath);
+	if (!img) return 0;   // the reference registers a null image here (raylib.cc:108-113); returning NULL as its header documents
+	g_images.add(img);
+	return (ImageHandle)img;
+}
+
+// ---------------------------------------------------------------------------
+// reference raylib.cc:118-179
+CameraHandle Raylib_CreateCamera(void)
+{
+	Camera* c = new Camera;   // the reference leaves a default camera uninitialised (camera.h:14-21); this one is valid
+	c->UpdateInternal();
+	g_cameras.add(c);
+	return (CameraHandle)c;
+}
+void Raylib_CameraSetPosition(CameraHandle h, float x, float y, float z) { Camera* c = (Camera*)h; if (!c) return; c->origin = F3(x, y, z); c->UpdateInternal(); }
+void Raylib_CameraSetLookAt(CameraHandle h, float x, float y, float z) { Camera* c = (Camera*)h; if (!c) return; c->lookAt = F3(x, y, z); c->UpdateInternal(); }
+void Raylib_CameraSetPerspective(CameraHandle h, float fovY, float aspect) { Camera* c = (Camera*)h; if (!c) return; c->fovY_degrees = fovY; c->aspectWH = aspect; c->UpdateInternal(); }
+void Raylib_CameraSetLens(CameraHandle h, float aperture, float focal) { Camera* c = (Camera*)h; if (!c) return; c->aperture = aperture; c->focalDistance = focal; c->UpdateInternal(); }
+void Raylib_CameraSetMotion(CameraHandle h, float t0, float t1) { Camera* c = (Camera*)h; if (!c) return; c->beginTime = t0; c->endTime = t1; c->UpdateInternal(); }
+void Raylib_CameraCopy(CameraHandle src, CameraHandle dst) { if (!src || !dst) return; *(Camera*)dst = *(Camera*)src; }
+int32_t Raylib_DestroyCamera(CameraHandle h)
+{
+	Camera* c = (Camera*)h;
+	if (g_cameras.eraseFirst(c)) { delete c; return 1; }
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// reference raylib.cc:181-203
+ImageHandle Raylib_CreateImage(uint32_t width, uint32_t height)
+{
+	Image* img = new Image;
+	img->Reallocate(width, height, 0.0f, 0.0f, 0.0f, 0.0f);   // Image2D(w, h, 0x0): ARGB 0 -> all channels 0
+	g_images.add(img);
+	return (ImageHandle)img;
+}
+
+void Raylib_DumpImageData(ImageHandle h, float* outDest)
+{
+	Image* img = (Image*)h;
+	if (!img || !outDest) return;
+	const size_t n = (size_t)img->width * img->height;
+	for (size_t k = 0; k < n; ++k) {   // reference render/image.cc:121-135: packed RGB, row-major
+		outDest[3 * k + 0] = img->rgba[4 * k + 0];
+		outDest[3 * k + 1] = img->rgba[4 * k + 1];
+		outDest[3 * k + 2] = img->rgba[4 * k + 2];
+	}
+}
+
+int32_t Raylib_DestroyImage(ImageHandle h)
+{
+	Image* img = (Image*)h;
+	if (g_images.eraseFirst(img)) { delete img; return 1; }
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// reference raylib.cc:205-283
+SceneHandle Raylib_CreateScene(void)
+{
+	Scene* s = new Scene;
+	g_scenes.add(s);
+	return (SceneHandle)s;
+}
+
+void Raylib_AddSceneElement(SceneHandle, SceneElementHandle)
+{
+	// The reference casts the handle to its C++ `Hitable*` (raylib.cc:258-262): that is a
+	// C++-ABI contract (vtables, class layouts), not a C one.  See INTEGRATION.md.
+	Log("Raylib_AddSceneElement: foreign C++ Hitable objects are not supported by this library; use OBJ models");
+}
+
+void Raylib_AddOBJModelToScene(SceneHandle sh, OBJModelHandle oh)
+{
+	Scene* s = (Scene*)sh; OBJModel* m = (OBJModel*)oh;
+	if (!s || !m) return;
+	if (!s->finalized) s->models.push_back(m);   // reference geom/scene.cc:15-21: ignored after Finalize
+}
+
+void Raylib_SetSkyPanorama(SceneHandle sh, ImageHandle ih)
+{
+	Scene* s = (Scene*)sh;
+	if (!s) return;
+	s->sky = (Image*)ih;
+	if (s->finalized) {   // the reference reads the handle at render time; keep that late-binding behaviour
+		if (s->device) { DeviceReleaseScene(s->device); s->device = nullptr; }
+		s->finalized = false; s->Finalize();
+	}
+}
+void Raylib_SetSunIlluminance(SceneHandle sh, float r, float g, float b)
+{
+	Scene* s = (Scene*)sh;
+	if (!s) return;
+	s->sunIlluminance = F3(r, g, b);
+	if (s->device) { DeviceReleaseScene(s->device); s->device = nullptr; }
+}
+void Raylib_SetSunDirection(SceneHandle sh, float x, float y, float z)
+{
+	Scene* s = (Scene*)sh;
+	if (!s) return;
+	s->sunDirection = normalize(F3(x, y, z));   // reference geom/scene.h:20
+	if (s->device) { DeviceReleaseScene(s->device); s->device = nullptr; }
+}
+void Raylib_FinalizeScene(SceneHandle sh)
+{
+	Scene* s = (Scene*)sh;
+	if (!s) return;
+	s->Finalize();
+}
+int32_t Raylib_DestroyScene(SceneHandle sh)
+{
+	Scene* s = (Scene*)sh;
+	if (g_scenes.eraseFirst(s)) { delete s; return 1; }
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// reference raylib.cc:231-239 -> render/renderer.cc:273-356
+void Raylib_Render(const RendererSettings* settings, SceneHandle scene, CameraHandle camera, ImageHandle outMainImage)
+{
+	Image* img = (Image*)outMainImage;
+	if (!settings || !img) { Log("Raylib_Render: null argument"); return; }
+	if (settings->viewportWidth != img->width || settings->viewportHeight != img->height)
+		img->Reallocate(settings->viewportWidth, settings->viewportHeight, 0.0f, 0.0f, 0.0f, 1.0f);   // renderer.cc:292-296
+	if ((size_t)img->width * img->height == 0) return;
+	if (!RenderInternal(settings, (Scene*)scene, (Camera*)camera, 0, 1, nullptr, img->rgba.data()))
+		fprintf(stderr, "Raylib_Render: FAILED (no HIP device or invalid arguments); the image was not written\n");
+}
+
+int32_t Raylib_Denoise(ImageHandle, int32_t, ImageHandle, ImageHandle, ImageHandle)
+{
+	return 0;   // reference render/renderer.cc:358-370 returns false when OIDN is not integrated (every non-Windows build)
+}
+
+void Raylib_PostProcess(ImageHandle h)
+{
+	Image* img = (Image*)h;
+	if (!img) return;
+	PostProcessHost(*img);
+}
+
+int32_t Raylib_IsDenoiserSupported(void) { return 0; }
+
+// ---------------------------------------------------------------------------
+// reference raylib.cc:298-331
+const char* Raylib_GetRenderModeString(uint32_t auxMode)
+{
+	static const char* names[] = { "Default", "Albedo", "SurfaceNormal", "MicrosurfaceNormal", "Texcoord", "Emission", "Reflectance" };
+	return auxMode < RAYLIB_RENDERMODE_MAX ? names[auxMode] : nullptr;
+}
+
+int32_t Raylib_WriteImageToDisk(ImageHandle h, const char* filepath, uint32_t fileType)
+{
+	if (h == 0 || filepath == nullptr || fileType >= RAYLIB_IMAGEFILETYPE_MAX) return 0;
+	return WriteImageFile(*(Image*)h, filepath, fileType) ? 1 : 0;
+}
+
+void Raylib_FlushLogThread(void) { LogFlush(); }
+
+// ===========================================================================
+// include/raylib_amd.h
+// ===========================================================================
+void RaylibAMD_SetSeed(uint64_t seed) { std::lock_guard<std::mutex> lk(g_stateMu); g_seed = seed; g_seedSet = true; }
+uint64_t RaylibAMD_GetSeed(void) { return CurrentSeed(); }
+void RaylibAMD_GetLastStats(RaylibAMDStats* out) { if (!out) return; std::lock_guard<std::mutex> lk(g_stateMu); *out = g_lastStats; }
+int32_t RaylibAMD_DeviceAvailable(void) { return DeviceAvailable() ? 1 : 0; }
+
+uint32_t RaylibAMD_NumCells(uint32_t w, uint32_t h) { return ((w + 7) / 8) * ((h + 7) / 8); }
+uint64_t RaylibAMD_CellBufferFloats(uint32_t w, uint32_t h, uint32_t cellFirst, uint32_t cellStride)
+{
+	if (cellStride <= 1 && cellFirst == 0) return (uint64_t)w * h * 4;
+	const uint32_t n = RaylibAMD_NumCells(w, h);
+	const uint32_t local = cellFirst < n ? (n - cellFirst + cellStride - 1) / cellStride : 0;
+	return (uint64_t)local * 64 * 4;
+}
+
+int32_t RaylibAMD_RenderDevice(const RendererSettings* settings, SceneHandle scene, CameraHandle camera,
+                               uint32_t cellFirst, uint32_t cellStride, void* outDevice)
+{
+	if (!settings || settings->viewportWidth == 0 || settings->viewportHeight == 0) return 0;
+	return RenderInternal(settings, (Scene*)scene, (Camera*)camera, cellFirst, cellStride ? cellStride : 1, outDevice, nullptr) ? 1 : 0;
+}
+
+int32_t RaylibAMD_ClosestHit(SceneHandle sh, const float* rays, int32_t n, float tMin, void* outHits)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized || !rays || !outHits) return 0;
+	return DeviceClosestHit(*s, rays, n, tMin, outHits) ? 1 : 0;
+}
+
+int32_t RaylibAMD_SceneNumTriangles(SceneHandle sh) { Scene* s = (Scene*)sh; return s ? (int32_t)s->triangles.size() : 0; }
+int32_t RaylibAMD_SceneNumMaterials(SceneHandle sh) { Scene* s = (Scene*)sh; return s ? (int32_t)s->materials.size() : 0; }
+int32_t RaylibAMD_SceneNumTextures(SceneHandle sh) { Scene* s = (Scene*)sh; return s ? (int32_t)s->textures.size() : 0; }
+void RaylibAMD_SceneExportTriangles(SceneHandle sh, void* out) { Scene* s = (Scene*)sh; if (s && out && !s->triangles.empty()) memcpy(out, s->triangles.data(), s->triangles.size() * sizeof(HostTriangle)); }
+void RaylibAMD_SceneExportMaterials(SceneHandle sh, void* out) { Scene* s = (Scene*)sh; if (s && out && !s->materials.empty()) memcpy(out, s->materials.data(), s->materials.size() * sizeof(HostMaterial)); }
+void RaylibAMD_SceneTextureSize(SceneHandle sh, int32_t i, int32_t* w, int32_t* h)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || i < 0 || i >= (int32_t)s->textures.size()) { if (w) *w = 0; if (h) *h = 0; return; }
+	if (w) *w = (int32_t)s->textures[i]->width;
+	if (h) *h = (int32_t)s->textures[i]->height;
+}
+void RaylibAMD_SceneExportTexture(SceneHandle sh, int32_t i, float* out)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !out || i < 0 || i >= (int32_t)s->textures.size()) return;
+	memcpy(out, s->textures[i]->rgba.data(), s->textures[i]->rgba.size() * sizeof(float));
+}
+void RaylibAMD_SceneGetSun(SceneHandle sh, float ill[3], float dir[3])
+{
+	Scene* s = (Scene*)sh;
+	if (!s) return;
+	ill[0] = s->sunIlluminance.x; ill[1] = s->sunIlluminance.y; ill[2] = s->sunIlluminance.z;
+	dir[0] = s->sunDirection.x; dir[1] = s->sunDirection.y; dir[2] = s->sunDirection.z;
+}
+int32_t RaylibAMD_SceneBVHInfo(SceneHandle sh, uint32_t* nodes, uint32_t* depth, float* sah)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized) return 0;
+	if (nodes) *nodes = (uint32_t)s->bvh.nodes.size();
+	if (depth) *depth = s->bvh.depth;
+	if (sah) *sah = s->bvh.sahCost;
+	return ValidateBVH(s->bvh, s->triangles) ? 1 : 0;
+}
+void RaylibAMD_CameraExport(CameraHandle h, float out[19])
+{
+	Camera* c = (Camera*)h;
+	if (!c || !out) return;
+	const f3* v[6] = { &c->origin, &c->top_left, &c->horizontal, &c->vertical, &c->u, &c->v };
+	int k = 0;
+	out[k++] = c->origin.x; out[k++] = c->origin.y; out[k++] = c->origin.z; out[k++] = c->lensRadius;
+	for (int i = 1; i < 6; ++i) { out[k++] = v[i]->x; out[k++] = v[i]->y; out[k++] = v[i]->z; }
+}
+ImageHandle RaylibAMD_CreateImageFromData(uint32_t w, uint32_t h, const float* rgba)
+{
+	if (!rgba) return 0;
+	Image* img = new Image;
+	img->width = w; img->height = h;
+	img->rgba.assign(rgba, rgba + (size_t)w * h * 4);
+	g_images.add(img);
+	return (ImageHandle)img;
+}
+void RaylibAMD_DumpImageRGBA(ImageHandle h, float* out)
+{
+	Image* img = (Image*)h;
+	if (!img || !out) return;
+	memcpy(out, img->rgba.data(), img->rgba.size() * sizeof(float));
+}
+int32_t RaylibAMD_OBJModelSetTexture(OBJModelHandle oh, const char* materialName, int32_t slot, ImageHandle ih)
+{
+	OBJModel* m = (OBJModel*)oh; Image* img = (Image*)ih;
+	if (!m || !materialName || slot < 0 || slot > 4 || !img || m->finalized) return 0;
+	for (size_t i = 0; i < m->materialNames.size(); ++i) {
+		if (m->materialNames[i] == materialName && m->materials[i].type == MAT_MICROFACET) {
+			m->images.push_back(std::make_shared<Image>(*img));
+			m->materials[i].tex[slot] = (int32_t)m->images.size() - 1;
+			return 1;
+		}
+	}
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,115 @@
+// Device-side data layout (HBM) shared by the host flattener and the HIP kernels.
+// Every record is a multiple of 16 bytes and 64-byte records are 64-byte aligned,
+// so one lane fetches a record with 4 x global_load_dwordx4 and never straddles a
+// 128-byte line more than once.
+#pragma once
+
+#include <stdint.h>
+
+namespace rl {
+
+// BVH2 node, 64 B: both child boxes live in the parent, so one fetch decides both
+// children (the reference keeps one box per heap node and chases a pointer per
+// child: geom/bvh.h:20-22, 48 B + vtable).
+//   child >= 0            : inner node index
+//   child <  0, != EMPTY  : leaf, ~child = (firstTri << 4) | (alphaTested << 3) | (count - 1)
+//   child == DNODE_EMPTY  : nothing (box is inverted, never hit)
+#define DNODE_EMPTY ((int32_t)0x80000000)
+struct alignas(64) DNode {
+	float lmin[3], lmax[3];
+	float rmin[3], rmax[3];
+	int32_t left, right;
+	int32_t pad0, pad1;
+};
+static_assert(sizeof(DNode) == 64, "DNode");
+
+// Triangle intersection record, 64 B.  The reference tests ray vs plane, then
+// barycentrics from dot products of edge vectors (geom/triangle.cc:18-58); all
+// ray-independent terms of that formula are precomputed here with the reference's
+// own operation order, so the per-ray arithmetic reproduces its t / barycentrics
+// bit for bit:  u = v1-v0, v = v2-v0, uv = dot(u,v), uu, vv, denom = uv*uv - uu*vv.
+struct alignas(64) DTriIsect {
+	float v0[3];
+	float n[3];      // unit geometric normal, normalize(cross(v1-v0, v2-v0)) (geom/triangle.h:34-38)
+	float u[3];
+	float v[3];
+	float uv, uu, vv, denom;
+};
+static_assert(sizeof(DTriIsect) == 64, "DTriIsect");
+
+// Triangle shading record, 64 B: fetched once per path vertex for the winning hit
+// (and for alpha-tested candidates).
+struct alignas(64) DTriShade {
+	float n0[3], n1[3], n2[3];
+	float s0, t0, s1, t1, s2, t2;
+	int32_t material;
+};
+static_assert(sizeof(DTriShade) == 64, "DTriShade");
+
+// Material record, 80 B (fields as reference render/material.h, see rl_host.h HostMaterial).
+struct alignas(16) DMaterial {
+	int32_t type;
+	float albedo[3];
+	float roughness, metallic;
+	float emissive[3];
+	float ior;
+	float transmission[3];
+	float fuzziness;
+	int32_t tex[5];
+	int32_t pad;
+};
+static_assert(sizeof(DMaterial) == 80, "DMaterial");
+
+// Texture descriptor; texels are float RGBA (16 B) in one pool, row 0 = top
+// (reference render/image.h:88-119 keeps float Pixels too).
+struct DTexture {
+	uint32_t offset;   // first texel in the pool
+	int32_t width, height;
+	int32_t pad;
+};
+
+// Camera constants (reference render/camera.h:95-101).
+struct DCamera {
+	float origin[3];     float lensRadius;
+	float top_left[3];   float beginTime;
+	float horizontal[3]; float timePeriod;
+	float vertical[3];   float pad0;
+	float u[3];          float pad1;
+	float v[3];          float pad2;
+};
+
+struct DSceneView {
+	const DNode* nodes;
+	const DTriIsect* isect;
+	const DTriShade* shade;
+	const DMaterial* materials;
+	const DTexture* textures;
+	const float* texels;       // float4 pool
+	float sunIlluminance[3];
+	float sunDirection[3];     // normalised
+	int32_t skyTexture;        // -1 = none
+	int32_t hasSun;
+	int32_t numTriangles;
+};
+
+// Counters written by the kernels (one 64-bit atomic per wave and counter at exit).
+enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SHADED, CNT_TEXELS, CNT_SAMPLES, CNT_COUNT };
+
+struct DRenderParams {
+	uint32_t width, height;
+	uint32_t spp;              // max(1, samplesPerPixel): divisor of the mean
+	uint32_t sampleBegin;      // first sample index of this batch
+	uint32_t sampleCount;      // samples in this batch
+	int32_t  maxPathLength;
+	float    rayTMin;
+	uint32_t renderMode;
+	uint64_t seed;
+	uint32_t cellsX, cellsY;
+	uint32_t cellFirst, cellStride, numLocalCells;
+	uint32_t numJobs;          // numLocalCells * sampleCount * 64
+	uint32_t stackStride;      // threads in the grid (path-stack column count)
+	uint32_t rowMajorOutput;   // 1: out[y*W+x]; 0: out[localCell*64 + p]
+	DCamera camera;
+};
+
+} // namespace rl

@@ -1,0 +1,156 @@
+// Host-side object model of the MI355X raylib (everything behind the C-ABI that is
+// not a kernel): OBJ models, images, cameras, scenes, and the flattening step
+// that turns them into the device layout of rl_device.h.
+#pragma once
+
+#include "raylib_types.h"
+#include "raylib_amd.h"
+#include "rl_device.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace rl {
+
+// ---------------------------------------------------------------------------
+// float3 with the arithmetic conventions the reference's results depend on
+// (reference core/vec3.h): normalize multiplies by 1/length, dot sums left to
+// right, cross negates the middle term.  Host code is compiled with
+// -ffp-contract=off so that these produce the same bits as the reference build.
+struct f3 { float x, y, z; };
+inline f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+inline f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline f3 operator*(f3 a, float t) { return F3(a.x * t, a.y * t, a.z * t); }
+inline f3 operator*(float t, f3 a) { return F3(a.x * t, a.y * t, a.z * t); }
+inline f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+inline float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x); }
+inline float length(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline f3 normalize(f3 a) { float k = 1.0f / length(a); return F3(a.x * k, a.y * k, a.z * k); }
+// std::min / std::max selection order (reference core/vec3.h:151-162): min(a,b) = (b < a) ? b : a
+inline f3 fmin3(f3 a, f3 b) { return F3(b.x < a.x ? b.x : a.x, b.y < a.y ? b.y : a.y, b.z < a.z ? b.z : a.z); }
+inline f3 fmax3(f3 a, f3 b) { return F3(a.x < b.x ? b.x : a.x, a.y < b.y ? b.y : a.y, a.z < b.z ? b.z : a.z); }
+
+// ---------------------------------------------------------------------------
+// 26-word triangle / 19-word material records: the host-side truth, identical in
+// layout to what RaylibAMD_SceneExport* hand out.
+struct HostTriangle {
+	f3 v0, v1, v2;
+	f3 n0, n1, n2;
+	float s0, t0, s1, t1, s2, t2;
+	int32_t material;
+	int32_t shape;
+};
+static_assert(sizeof(HostTriangle) == 104, "HostTriangle layout");
+
+enum MaterialType { MAT_LAMBERTIAN = 0, MAT_MIRROR = 1, MAT_DIELECTRIC = 2, MAT_MICROFACET = 3, MAT_METAL = 4, MAT_DIFFUSE_LIGHT = 5 };
+
+struct HostMaterial {
+	int32_t type;
+	float albedo[3];
+	float roughness, metallic;
+	float emissive[3];
+	float ior;
+	float transmission[3];
+	float fuzziness;
+	int32_t tex[5];   // albedo, normal, roughness, metallic, emissive; -1 = none
+};
+static_assert(sizeof(HostMaterial) == 76, "HostMaterial layout");
+
+struct Image {
+	uint32_t width = 0, height = 0;
+	std::vector<float> rgba;          // 4 floats per pixel, row 0 = top
+	void Reallocate(uint32_t w, uint32_t h, float r, float g, float b, float a);
+};
+
+struct OBJModel {
+	std::vector<HostTriangle> triangles;
+	std::vector<HostMaterial> materials;           // MTL order, then the fallback Lambertian(0.5)
+	std::vector<std::string> materialNames;
+	std::vector<std::shared_ptr<Image>> images;    // textures referenced by materials[].tex
+	int32_t numShapes = 0;
+	bool finalized = false;
+};
+
+struct Camera {
+	// settable state (reference render/camera.h:80-93)
+	f3 origin = F3(0, 0, 0), lookAt = F3(0, 0, -1);
+	float fovY_degrees = 60.0f, aspectWH = 16.0f / 9.0f;
+	float aperture = 0.0f, focalDistance = 1.0f;
+	float beginTime = 0.0f, endTime = 0.0f;
+	// derived (reference render/camera.h:55-78)
+	float lensRadius, timePeriod;
+	f3 top_left, horizontal, vertical, u, v, w;
+	void UpdateInternal();
+	DCamera ToDevice() const;
+};
+
+struct BVH {
+	std::vector<DNode> nodes;
+	std::vector<uint32_t> triOrder;   // leaf order -> index into the flat triangle array
+	uint32_t depth = 0;
+	float sahCost = 0.0f;
+};
+// Binned-SAH BVH2 over triangle bounds.  Leaves hold <= 4 triangles.
+void BuildBVH(const std::vector<HostTriangle>& tris, BVH& out);
+bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris);
+
+struct DeviceScene;   // rl_render.hip
+
+struct Scene {
+	std::vector<OBJModel*> models;    // borrowed (reference raylib.cc:264-268)
+	Image* sky = nullptr;             // borrowed (reference raylib.cc:270-273)
+	f3 sunIlluminance = F3(0, 0, 0);
+	f3 sunDirection;
+	bool finalized = false;
+
+	// flattened at Raylib_FinalizeScene
+	std::vector<HostTriangle> triangles;
+	std::vector<HostMaterial> materials;
+	std::vector<std::shared_ptr<Image>> textures;
+	std::shared_ptr<Image> skyCopy;
+	int32_t skyTexture = -1;
+	BVH bvh;
+	DeviceScene* device = nullptr;    // uploaded lazily at first render
+
+	Scene();
+	~Scene();
+	void Finalize();
+};
+
+// loaders (rl_obj_loader.cc, rl_image_io.cc)
+bool LoadOBJ(const char* path, OBJModel& out);
+void TransformOBJ(OBJModel& m, float tx, float ty, float tz, float yaw, float pitch, float roll, float sx, float sy, float sz);
+Image* LoadImageFile(const char* path);
+bool WriteImageFile(const Image& img, const char* path, uint32_t fileType);
+void PostProcessHost(Image& img);   // see rl_abi.cc: used only when the image never lived on a device
+
+// logging (rl_log.cc)
+void Log(const char* fmt, ...);
+void LogStart();
+void LogFlush();
+void LogStop();
+
+// device side (rl_render.hip)
+struct RenderRequest {
+	RendererSettings settings;
+	DCamera camera;
+	uint64_t seed;
+	uint32_t cellFirst, cellStride;
+	void* outDevice;        // may be null
+	float* outHostRGBA;     // may be null; W*H*4 floats (only for full-image renders)
+};
+bool DeviceAvailable();
+bool DeviceRender(Scene& scene, const RenderRequest& req, RaylibAMDStats& stats);
+bool DeviceClosestHit(Scene& scene, const float* rays, int32_t n, float tMin, void* outHits);
+bool DevicePostProcess(Image& img);
+void DeviceReleaseScene(DeviceScene* dev);
+void DeviceShutdown();
+
+} // namespace rl

@@ -1,0 +1,1204 @@
+// HIP kernels + device runtime of the MI355X raylib (gfx950, wave64).
+//
+// Replaces, on the device, the reference's per-pixel render loop and everything it
+// calls (reference render/renderer.cc:62-271, geom/bvh.cc:82-107, geom/aabb.h:14-55,
+// geom/triangle.cc:18-58, geom/hit.cc:6-30, render/material.cc, render/brdf.h,
+// render/camera.h:44-53, render/texture.cc:30-53, core/random.cc:3-50):
+//
+//   k_trace    persistent "megakernel": every lane owns one camera sample (a path)
+//              at a time and runs one bounce per loop trip; lanes whose path ended
+//              are refilled at the top of the loop from a global job counter using a
+//              wave64 __ballot + prefix rank (one atomic per wave and trip), so waves
+//              stay full while path lengths differ.  Traversal is iterative on ONE
+//              flat BVH2 with an LDS stack ([entry][lane], conflict free), ordered
+//              near-first with t-shrinking -- it returns the reference's closest hit
+//              (min t over all triangles) without the reference's both-children walk.
+//   k_resolve  sums a pixel's samples IN SAMPLE ORDER (float addition is not
+//              associative; the reference adds s = 0..SPP-1 sequentially,
+//              renderer.cc:232-246) and applies the reciprocal-multiply mean.
+//   k_aov      the debug render modes (renderer.cc:62-111).
+//   k_closest_hit  rays in -> hit records out (tests).
+//
+// Radiance is folded exactly as the reference's recursion evaluates it
+// (renderer.cc:139-151): per bounce the lane stores (reflectance, scatteringPdf,
+// pdf, emitted) in a global path stack and, when the path ends, folds from the last
+// vertex back to the camera, so every rounding step is the reference's.
+#include <hip/hip_runtime.h>
+
+#include "rl_host.h"
+#include "rl_math.h"
+#include "raylib_amd_rng.h"
+
+#include <chrono>
+#include <float.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace rl {
+
+#define RL_BLOCK 256
+
+// ---------------------------------------------------------------------------
+// device float3 (reference core/vec3.h conventions; see rl_host.h f3)
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 v3s(float s) { return v3(s, s, s); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float t) { return v3(a.x * t, a.y * t, a.z * t); }
+__device__ __forceinline__ V3 operator*(float t, V3 a) { return v3(a.x * t, a.y * t, a.z * t); }
+__device__ __forceinline__ V3 operator/(V3 a, float t) { return v3(a.x / t, a.y / t, a.z / t); }
+__device__ __forceinline__ V3 operator-(V3 a, float t) { return v3(a.x - t, a.y - t, a.z - t); }
+__device__ __forceinline__ V3 operator-(float t, V3 a) { return v3(t - a.x, t - a.y, t - a.z); }
+__device__ __forceinline__ V3 operator+(V3 a, float t) { return v3(a.x + t, a.y + t, a.z + t); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float absDot(V3 a, V3 b) { return fabsf(a.x * b.x + a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 normalize(V3 a) { float k = 1.0f / length(a); return v3(a.x * k, a.y * k, a.z * k); }
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; }
+__device__ __forceinline__ V3 mix(V3 a, V3 b, float t) { return (1.0f - t) * a + t * b; }
+__device__ __forceinline__ V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ bool isZero(V3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+
+#define RL_PI 3.14159265359f   /* BRDF::PI, reference render/brdf.h:8 */
+
+struct Counters { uint32_t rays, nodes, tris, shaded, texels, samples; };
+
+// ---------------------------------------------------------------------------
+// RNG (include/raylib_amd_rng.h); draws in the reference's program order.
+struct Rng { RaylibRngStream s; };
+__device__ __forceinline__ float Next(Rng& g) { return raylib_rng_next_float(&g.s); }
+
+// reference core/random.cc:3-23
+__device__ __forceinline__ V3 RandomInUnitSphere(Rng& g)
+{
+	float u1 = Next(g);
+	float u2 = Next(g);
+	float z = 1.0f - 2.0f * u1;
+	float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+	float phi = 2.0f * 3.141592f * u2;
+	return v3(r * rtm::cos_(phi), r * rtm::sin_(phi), z);
+}
+// reference core/random.cc:42-50
+__device__ __forceinline__ V3 RandomInUnitDisk(Rng& g)
+{
+	float u1 = Next(g);
+	float u2 = Next(g);
+	float r = sqrtf(u1);
+	float theta = 2.0f * 3.14159265358979323846f * u2;
+	return v3(r * rtm::cos_(theta), r * rtm::sin_(theta), 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Texture2D::Sample (reference render/texture.cc:30-53, render/image.h:79-83)
+__device__ __forceinline__ float4 TexSample(const DSceneView& S, int tex, bool srgb, float u, float v, Counters& c)
+{
+	const DTexture T = S.textures[tex];
+	u = rtm::fmod1_(u); if (u < 0.0f) u += 1.0f;
+	v = rtm::fmod1_(v); if (v < 0.0f) v += 1.0f; v = 1.0f - v;
+	if (isnan(u) || isinf(u)) u = 0.0f;
+	if (isnan(v) || isinf(v)) v = 0.0f;
+	int x = (int)((float)(uint32_t)(T.width - 1) * u);
+	int y = (int)((float)(uint32_t)(T.height - 1) * v);
+	float4 px = ((const float4*)S.texels)[T.offset + (uint32_t)(y * T.width + x)];
+	c.texels++;
+	if (srgb) { px.x = rtm::pow_(px.x, 2.2f); px.y = rtm::pow_(px.y, 2.2f); px.z = rtm::pow_(px.z, 2.2f); px.w = rtm::pow_(px.w, 2.2f); }
+	return px;
+}
+
+struct Mat {   // DMaterial in registers
+	int type;
+	V3 albedo; float roughness, metallic; V3 emissive; float ior; V3 transmission; float fuzz;
+	int tex0, tex1, tex2, tex3, tex4;
+};
+__device__ __forceinline__ Mat LoadMat(const DSceneView& S, int i)
+{
+	const float4* p = (const float4*)(S.materials + i);
+	float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+	Mat m;
+	m.type = __float_as_int(a.x); m.albedo = v3(a.y, a.z, a.w);
+	m.roughness = b.x; m.metallic = b.y; m.emissive = v3(b.z, b.w, c.x);
+	m.ior = c.y; m.transmission = v3(c.z, c.w, d.x); m.fuzz = d.y;
+	m.tex0 = __float_as_int(d.z); m.tex1 = __float_as_int(d.w);
+	m.tex2 = __float_as_int(e.x); m.tex3 = __float_as_int(e.y); m.tex4 = __float_as_int(e.z);
+	return m;
+}
+
+// ---------------------------------------------------------------------------
+// Closest hit on the flat BVH2.
+struct HitRec { float t, a, b; int tri; };
+
+struct Tri { V3 v0, n, u, v; float uv, uu, vv, denom; };
+__device__ __forceinline__ Tri LoadTri(const DSceneView& S, int i)
+{
+	const float4* p = (const float4*)(S.isect + i);
+	float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+	Tri t;
+	t.v0 = v3(q0.x, q0.y, q0.z); t.n = v3(q0.w, q1.x, q1.y);
+	t.u = v3(q1.z, q1.w, q2.x); t.v = v3(q2.y, q2.z, q2.w);
+	t.uv = q3.x; t.uu = q3.y; t.vv = q3.z; t.denom = q3.w;
+	return t;
+}
+
+struct Shade { V3 n0, n1, n2; float s0, t0, s1, t1, s2, t2; int material; };
+__device__ __forceinline__ Shade LoadShade(const DSceneView& S, int i)
+{
+	const float4* p = (const float4*)(S.shade + i);
+	float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+	Shade s;
+	s.n0 = v3(q0.x, q0.y, q0.z); s.n1 = v3(q0.w, q1.x, q1.y); s.n2 = v3(q1.z, q1.w, q2.x);
+	s.s0 = q2.y; s.t0 = q2.z; s.s1 = q2.w; s.t1 = q3.x; s.s2 = q3.y; s.t2 = q3.z;
+	s.material = __float_as_int(q3.w);
+	return s;
+}
+
+// MicrofacetMaterial::AlphaTest for a candidate (reference render/material.cc:397-404 via geom/triangle.cc:48-54)
+__device__ __noinline__ bool AlphaTestCandidate(const DSceneView& S, int tri, float a, float b, Counters& c)
+{
+	Shade sh = LoadShade(S, tri);
+	c.shaded++;
+	const DMaterial* M = S.materials + sh.material;
+	if (M->type != MAT_MICROFACET || M->tex[0] < 0) return true;
+	float U = (1 - a - b) * sh.s0 + a * sh.s1 + b * sh.s2;
+	float V = (1 - a - b) * sh.t0 + a * sh.t1 + b * sh.t2;
+	float4 px = TexSample(S, M->tex[0], true, U, V, c);
+	return px.w >= 0.5f;
+}
+
+// Slab test of one child box against [tMin, tMax] (reference geom/aabb.h:39-54:
+// same products (bound - o) * invD, same "swap if invD < 0", NaN keeps the old
+// bound).  tMax is widened by 2 ulp so the test stays conservative.
+__device__ __forceinline__ bool Slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                     V3 o, V3 inv, bool nx, bool ny, bool nz, float tMin, float tMax, float& tNear)
+{
+	float tn = tMin, tf = tMax;
+	float a0 = ((nx ? mxx : mnx) - o.x) * inv.x, a1 = ((nx ? mnx : mxx) - o.x) * inv.x;
+	tn = fmaxf(tn, a0); tf = fminf(tf, a1);
+	float b0 = ((ny ? mxy : mny) - o.y) * inv.y, b1 = ((ny ? mny : mxy) - o.y) * inv.y;
+	tn = fmaxf(tn, b0); tf = fminf(tf, b1);
+	float c0 = ((nz ? mxz : mnz) - o.z) * inv.z, c1 = ((nz ? mnz : mxz) - o.z) * inv.z;
+	tn = fmaxf(tn, c0); tf = fminf(tf, c1);
+	tNear = tn;
+	return !(tf * 1.0000004f < tn);
+}
+
+// stk: this lane's column of the LDS stack; entry k at stk[k * RL_BLOCK].
+template <int STACK, bool ANYHIT>
+__device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float tMin, HitRec& best, int* stk, Counters& c)
+{
+	c.rays++;
+	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+	best.t = INFINITY; best.tri = -1; best.a = 0.0f; best.b = 0.0f;
+	int sp = 0;
+	int cur = 0;   // root is an inner node
+	for (;;) {
+		if (cur >= 0) {
+			const float4* np = (const float4*)(S.nodes + cur);
+			const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+			const int4 k = ((const int4*)np)[3];
+			c.nodes++;
+			float tl, tr;
+			const float tmx = fminf(best.t, FLT_MAX);
+			bool hl = Slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, nx, ny, nz, tMin, tmx, tl);
+			bool hr = Slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, nx, ny, nz, tMin, tmx, tr);
+			hl = hl && (k.x != DNODE_EMPTY);
+			hr = hr && (k.y != DNODE_EMPTY);
+			if (hl && hr) {
+				const bool leftFirst = tl <= tr;
+				const int nearC = leftFirst ? k.x : k.y, farC = leftFirst ? k.y : k.x;
+				if (sp < STACK) { stk[sp * RL_BLOCK] = farC; ++sp; }
+				cur = nearC;
+				continue;
+			} else if (hl) { cur = k.x; continue; }
+			else if (hr) { cur = k.y; continue; }
+		} else {
+			const uint32_t code = (uint32_t)~cur;
+			const int first = (int)(code >> 4);
+			const int count = (int)(code & 7u) + 1;
+			const bool alpha = (code & 8u) != 0;
+			for (int i = 0; i < count; ++i) {
+				const Tri T = LoadTri(S, first + i);
+				c.tris++;
+				// reference geom/triangle.cc:22-27
+				const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
+				if (!(t >= tMin && t <= FLT_MAX && t < best.t)) continue;
+				const V3 p = o + t * d;
+				const V3 w = p - T.v0;
+				const float wv = dot(w, T.v), wu = dot(w, T.u);
+				const float pa = (T.uv * wv - T.vv * wu) / T.denom;
+				const float pb = (T.uv * wu - T.uu * wv) / T.denom;
+				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
+					if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
+					best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
+					if (ANYHIT) return true;
+				}
+			}
+		}
+		if (sp == 0) break;
+		--sp;
+		cur = stk[sp * RL_BLOCK];
+	}
+	return best.tri >= 0;
+}
+
+// ---------------------------------------------------------------------------
+// Surface interaction (reference geom/hit.h:16-36)
+struct Surf { float t; V3 p, n; float U, V; V3 tangent, bitangent; };
+
+// reference geom/triangle.cc:43-47 + geom/hit.cc:6-18
+__device__ __forceinline__ void BuildSurface(const Shade& sh, V3 o, V3 d, const HitRec& h, Surf& s, bool basis)
+{
+	s.t = h.t;
+	s.p = o + h.t * d;
+	const float a = h.a, b = h.b;
+	s.n = normalize((1 - a - b) * sh.n0 + a * sh.n1 + b * sh.n2);
+	s.U = (1 - a - b) * sh.s0 + a * sh.s1 + b * sh.s2;
+	s.V = (1 - a - b) * sh.t0 + a * sh.t1 + b * sh.t2;
+	if (basis) {
+		V3 T = (fabsf(s.n.x) > 0.9f) ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+		V3 B = normalize(cross(T, s.n));
+		T = normalize(cross(s.n, B));
+		s.tangent = T; s.bitangent = B;
+	}
+}
+__device__ __forceinline__ V3 LocalToWorld(const Surf& s, V3 v)
+{
+	float wx = dot(v3(s.tangent.x, s.bitangent.x, s.n.x), v);
+	float wy = dot(v3(s.tangent.y, s.bitangent.y, s.n.y), v);
+	float wz = dot(v3(s.tangent.z, s.bitangent.z, s.n.z), v);
+	return v3(wx, wy, wz);
+}
+__device__ __forceinline__ V3 WorldToLocal(const Surf& s, V3 v) { return v3(dot(v, s.tangent), dot(v, s.bitangent), dot(v, s.n)); }
+
+// ---- microfacet BRDF pieces (reference render/brdf.h, render/material.cc:16-190) ----
+__device__ __forceinline__ float Clampf(float val, float lo, float hi) { return fmaxf(lo, fminf(hi, val)); }
+
+__device__ float ErfInv(float x)
+{
+	float w, p;
+	x = Clampf(x, -.99999f, .99999f);
+	w = -rtm::log_((1 - x) * (1 + x));
+	if (w < 5) {
+		w = w - 2.5f;
+		p = 2.81022636e-08f;
+		p = 3.43273939e-07f + p * w;
+		p = -3.5233877e-06f + p * w;
+		p = -4.39150654e-06f + p * w;
+		p = 0.00021858087f + p * w;
+		p = -0.00125372503f + p * w;
+		p = -0.00417768164f + p * w;
+		p = 0.246640727f + p * w;
+		p = 1.50140941f + p * w;
+	} else {
+		w = sqrtf(w) - 3;
+		p = -0.000200214257f;
+		p = 0.000100950558f + p * w;
+		p = 0.00134934322f + p * w;
+		p = -0.00367342844f + p * w;
+		p = 0.00573950773f + p * w;
+		p = -0.0076224613f + p * w;
+		p = 0.00943887047f + p * w;
+		p = 1.00167406f + p * w;
+		p = 2.83297682f + p * w;
+	}
+	return p * x;
+}
+__device__ float Erf(float x)
+{
+	const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f;
+	const float p = 0.3275911f;
+	int sign = 1;
+	if (x < 0) sign = -1;
+	x = fabsf(x);
+	float t = 1 / (1 + p * x);
+	float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * rtm::exp_(-x * x);
+	return sign * y;
+}
+__device__ __forceinline__ float SinThetaL(V3 w) { return sqrtf(fmaxf(0.0f, 1.0f - w.z * w.z)); }
+__device__ __forceinline__ float CosPhi(V3 w) { float s = SinThetaL(w); return (s == 0) ? 1 : Clampf(w.x / s, -1, 1); }
+__device__ __forceinline__ float SinPhi(V3 w) { float s = SinThetaL(w); return (s == 0) ? 0 : Clampf(w.y / s, -1, 1); }
+
+// reference render/material.cc:83-165
+__device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y)
+{
+	const float Pi = RL_PI;
+	if ((double)cosThetaI > .9999) {
+		float r = sqrtf(-rtm::log_(1.0f - U1));
+		float sinPhi = rtm::sin_(2 * Pi * U2);
+		float cosPhi = rtm::cos_(2 * Pi * U2);
+		*slope_x = r * cosPhi;
+		*slope_y = r * sinPhi;
+		return;
+	}
+	float sinThetaI = sqrtf(fmaxf((float)0, (float)1 - cosThetaI * cosThetaI));
+	float tanThetaI = sinThetaI / cosThetaI;
+	float cotThetaI = 1 / tanThetaI;
+
+	float a = -1, c = Erf(cotThetaI);
+	float sample_x = fmaxf(U1, (float)1e-6f);
+
+	float thetaI = rtm::acos_(cosThetaI);
+	float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+	float b = c - (1 + c) * rtm::pow_(1 - sample_x, fit);
+
+	const float SQRT_PI_INV = 1.f / sqrtf(Pi);
+	float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * rtm::exp_(-cotThetaI * cotThetaI));
+
+	int it = 0;
+	while (++it < 10) {
+		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+		float invErf = ErfInv(b);
+		float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * rtm::exp_(-invErf * invErf)) - sample_x;
+		float derivative = normalization * (1 - invErf * tanThetaI);
+		if (fabsf(value) < 1e-5f) break;
+		if (value > 0) c = b; else a = b;
+		b -= value / derivative;
+	}
+	*slope_x = ErfInv(b);
+	*slope_y = ErfInv(2.0f * fmaxf(U2, (float)1e-6f) - 1.0f);
+}
+// reference render/material.cc:166-190
+__device__ V3 BeckmannSample(V3 wi, float alpha_x, float alpha_y, float U1, float U2)
+{
+	V3 wiStretched = normalize(v3(alpha_x * wi.x, alpha_y * wi.y, wi.z));
+	float slope_x, slope_y;
+	BeckmannSample11(wiStretched.z, U1, U2, &slope_x, &slope_y);
+	float tmp = CosPhi(wiStretched) * slope_x - SinPhi(wiStretched) * slope_y;
+	slope_y = SinPhi(wiStretched) * slope_x + CosPhi(wiStretched) * slope_y;
+	slope_x = tmp;
+	slope_x = alpha_x * slope_x;
+	slope_y = alpha_y * slope_y;
+	return normalize(v3(-slope_x, -slope_y, 1.f));
+}
+// reference render/brdf.h:39-58
+__device__ __forceinline__ float DistributionBeckmann(V3 N, V3 H, float roughness)
+{
+	float cosH = dot(N, H);
+	if (roughness == 0.0f) return 1.0f;
+	if (H.z < 0.0f) cosH = -cosH;
+	float cosH2 = cosH * cosH;
+	float rr = roughness * roughness;
+	float exp_x = (1.0f - cosH2) / (rr * cosH);
+	float num = (cosH > 0.0f ? 1.0f : 0.0f) * rtm::exp_(-exp_x);
+	float denom = RL_PI * rr * cosH2 * cosH2;
+	return num / denom;
+}
+// reference render/brdf.h:74-93
+__device__ __forceinline__ float GeometryBeckmann(V3 N, V3 H, V3 V, float roughness)
+{
+	float thetaV = rtm::acos_(dot(N, V));
+	float tanThetaV = rtm::tan_(thetaV);
+	float a = 1.0f / (roughness * tanThetaV);
+	float aa = a * a;
+	if (dot(V, H) / dot(V, N) <= 0.0f) return 0.0f;
+	if (a < 1.6f) {
+		float num = 3.535f * a + 2.181f * aa;
+		float denom = 1.0f + 2.276f * a + 2.577f * aa;
+		return num / denom;
+	}
+	return 1.0f;
+}
+
+// material texture lookups (reference render/material.cc:297-303,378-395,406-415)
+__device__ __forceinline__ V3 GetAlbedo(const DSceneView& S, const Mat& m, float U, float V, Counters& c)
+{
+	if (m.type == MAT_LAMBERTIAN || m.type == MAT_METAL) return m.albedo;
+	if (m.type == MAT_MICROFACET) {
+		V3 albedo = m.albedo;
+		if (m.tex0 >= 0) { float4 px = TexSample(S, m.tex0, true, U, V, c); albedo = v3(px.x, px.y, px.z) * px.w; }
+		return albedo;
+	}
+	return v3s(0.0f);
+}
+__device__ __forceinline__ float GetRoughness(const DSceneView& S, const Mat& m, float U, float V, Counters& c)
+{
+	float roughness = m.roughness;
+	if (m.tex2 >= 0) roughness = TexSample(S, m.tex2, false, U, V, c).x;
+	return roughness;
+}
+__device__ __forceinline__ V3 GetMicrosurfaceNormal(const DSceneView& S, const Mat& m, const Surf& s, Counters& c)
+{
+	if (m.type == MAT_MICROFACET && m.tex1 >= 0) {
+		float4 px = TexSample(S, m.tex1, false, s.U, s.V, c);
+		V3 N = v3(px.x, px.y, px.z);
+		N = normalize(2.0f * N - 1.0f);
+		return N;
+	}
+	return v3(0.0f, 0.0f, 1.0f);
+}
+__device__ __forceinline__ bool IsMirrorLike(const DSceneView& S, const Mat& m, float U, float V, Counters& c)
+{
+	if (m.type == MAT_DIELECTRIC || m.type == MAT_MIRROR) return true;
+	if (m.type == MAT_MICROFACET) return GetRoughness(S, m, U, V, c) < 0.1f;
+	return false;
+}
+// reference render/material.cc:342-350, material.h:67-69
+__device__ __forceinline__ V3 Emitted(const DSceneView& S, const Mat& m, const Surf& s, Counters& c)
+{
+	if (m.type == MAT_DIFFUSE_LIGHT) return m.albedo;
+	if (m.type == MAT_MICROFACET) {
+		V3 emit = m.emissive;
+		if (m.tex4 >= 0) { float4 px = TexSample(S, m.tex4, false, s.U, s.U, c); emit = v3s(px.z); }  // (U,U) and vec3(b): reference bugs kept
+		return emit;
+	}
+	return v3s(0.0f);
+}
+
+// One scattering event.  Returns false when the material does not scatter.
+// Outputs reflectance, new direction, pdf and ScatteringPdf (the value the
+// reference recomputes at renderer.cc:144).
+__device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 inD, const Surf& s, Rng& g, Counters& c,
+                                        V3& refl, V3& outD, float& pdf, float& sp)
+{
+	switch (m.type) {
+		case MAT_DIFFUSE_LIGHT: return false;
+		case MAT_LAMBERTIAN: {   // material.cc:195-219
+			V3 N = s.n;
+			V3 r = RandomInUnitSphere(g);
+			if ((double)dot(r, N) < 0.0) r = -r;
+			V3 Wi = normalize(r);
+			outD = Wi;
+			refl = m.albedo;
+			pdf = absDot(N, Wi) / RL_PI;
+			sp = fmaxf(0.0f, dot(s.n, Wi)) / RL_PI;
+			return true;
+		}
+		case MAT_METAL: {        // material.cc:225-239
+			V3 ud = normalize(inD);
+			V3 reflected = reflect(ud, s.n);
+			outD = reflected + m.fuzz * RandomInUnitSphere(g);
+			refl = m.albedo;
+			pdf = 1.0f;
+			sp = 1.0f / RL_PI;
+			return dot(outD, s.n) > 0.0f;
+		}
+		case MAT_MIRROR: {       // material.h:149-162
+			refl = m.albedo;
+			outD = reflect(inD, s.n);
+			pdf = 1.0f;
+			sp = 1.0f;
+			return true;
+		}
+		case MAT_DIELECTRIC: {   // material.cc:244-285
+			V3 outward_normal;
+			V3 reflected = reflect(inD, s.n);
+			float ni_over_nt;
+			refl = m.transmission;
+			V3 refracted = v3s(0.0f);
+			float reflect_prob, cosine;
+			if (dot(inD, s.n) > 0.0f) {
+				outward_normal = -s.n;
+				ni_over_nt = m.ior;
+				cosine = m.ior * dot(inD, s.n) / length(inD);
+			} else {
+				outward_normal = s.n;
+				ni_over_nt = 1.0f / m.ior;
+				cosine = -dot(inD, s.n) / length(inD);
+			}
+			bool bRefract;
+			{   // vec3.h:136-145
+				V3 uv = normalize(inD);
+				float dt = dot(uv, outward_normal);
+				float D = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+				bRefract = D > 0.0f;
+				if (bRefract) refracted = ni_over_nt * (uv - outward_normal * dt) - outward_normal * sqrtf(D);
+			}
+			if (bRefract) {
+				float r0 = (1.0f - m.ior) / (1.0f + m.ior);
+				r0 = r0 * r0;
+				reflect_prob = r0 + (1.0f - r0) * rtm::pow_((1.0f - cosine), 5.0f);
+			} else {
+				reflect_prob = 1.0f;
+			}
+			outD = (Next(g) < reflect_prob) ? reflected : refracted;
+			pdf = 1.0f;
+			sp = 1.0f / RL_PI;
+			return true;
+		}
+		default: {               // MicrofacetMaterial, material.cc:290-340,352-376,417-431
+			V3 baseColor = GetAlbedo(S, m, s.U, s.V, c);
+			float roughness = GetRoughness(S, m, s.U, s.V, c);
+			float metallic = m.metallic;
+			if (m.tex3 >= 0) metallic = TexSample(S, m.tex3, false, s.U, s.V, c).x;
+
+			V3 N = GetMicrosurfaceNormal(S, m, s, c);
+			V3 Wo = WorldToLocal(s, -inD);
+			float u0 = Next(g);
+			float u1 = Next(g);
+			bool bFlip = Wo.z < 0.0f;
+			V3 Wh = BeckmannSample(bFlip ? -Wo : Wo, roughness, roughness, u0, u1);
+			if (bFlip) Wh = -Wh;
+			V3 Wi = reflect(-Wo, Wh);
+			float NdotWi = absDot(N, Wi);
+
+			V3 F0 = v3s(0.04f);
+			F0 = mix(F0, baseColor, metallic);
+			V3 F = F0 + (1.0f - F0) * rtm::pow_(1.0f - absDot(Wh, Wo), 5.0f);
+			float ggx2 = GeometryBeckmann(N, Wh, Wo, roughness);
+			float ggx1 = GeometryBeckmann(N, Wh, Wi, roughness);
+			float G = 1.0f / (1.0f + ggx1 * ggx2);
+			float NDF = DistributionBeckmann(N, Wh, roughness);
+
+			V3 kS = F;
+			V3 kD = 1.0f - kS;
+			V3 diffuse = baseColor * (1.0f - metallic);
+			V3 specular = (F * G * NDF) / (4.0f * NdotWi * absDot(N, Wo) + 0.001f);
+
+			V3 WiW = LocalToWorld(s, Wi);
+			outD = WiW;
+			refl = (kD * diffuse + kS * specular) * NdotWi;
+
+			// ScatteringPdf(hit, -inD, WiW), material.cc:352-376
+			V3 wo = WorldToLocal(s, -inD);
+			V3 wi = WorldToLocal(s, WiW);
+			V3 wh = normalize(wo + wi);
+			if (wh.z < 0.0f) wh.z = -wh.z;
+			float D = DistributionBeckmann(N, wh, roughness);
+			sp = D * absDot(wh, N);
+			pdf = sp / (4.0f * dot(Wo, Wh));
+			return true;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Camera::GetCameraRay (reference render/camera.h:44-53)
+__device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rng& g, V3& o, V3& d)
+{
+	V3 rd = k.lensRadius * RandomInUnitDisk(g);
+	V3 cu = ld3(k.u), cv = ld3(k.v);
+	V3 offset = (cu * rd.x) + (cv * rd.y);
+	float captureTime = k.beginTime + k.timePeriod * Next(g);
+	(void)captureTime;   // ray.t is only consumed by the moving Cube primitive, which triangle scenes do not contain
+	V3 origin = ld3(k.origin);
+	o = origin + offset;
+	d = normalize(ld3(k.top_left) + s * ld3(k.horizontal) + (1.0f - t) * ld3(k.vertical) - origin - offset);
+}
+
+struct SkyRot { float m0[3], m1[3], m2[3]; };   // Rotator(yaw 90).rotate rows, computed on the host (renderer.cc:166-168)
+
+// Miss shader: sky panorama + sun (reference render/renderer.cc:155-199)
+template <int STACK>
+__device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTMin, int* stk, Counters& c)
+{
+	V3 missResult = v3s(0.0f);
+	if (S.skyTexture >= 0) {
+		V3 dir = normalize(d);
+		V3 D = v3(dot(ld3(R.m0), dir), dot(ld3(R.m1), dir), dot(ld3(R.m2), dir));
+		float u = rtm::atan2_(D.z, D.x), v = rtm::asin_(D.y);
+		u *= 0.1591f; v *= 0.3183f;
+		u += 0.5f; v += 0.5f;
+		const DTexture T = S.textures[S.skyTexture];
+		int x = (int)(u * (float)(uint32_t)(T.width - 1));
+		int y = (int)(v * (float)(uint32_t)(T.height - 1));
+		float4 px = ((const float4*)S.texels)[T.offset + (uint32_t)(y * T.width + x)];
+		c.texels++;
+		missResult = missResult + v3(px.x, px.y, px.z);
+	}
+	if (S.hasSun) {
+		HitRec tmp;
+		if (!Traverse<STACK, true>(S, o, -ld3(S.sunDirection), rayTMin, tmp, stk, c)) missResult = missResult + ld3(S.sunIlluminance);
+	}
+	return missResult;
+}
+
+// job -> (local cell, sample, pixel in cell) -> image coordinates
+struct JobPixel { uint32_t x, y, slot, sample; bool valid; };
+__device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t job)
+{
+	JobPixel j;
+	const uint32_t p = job & 63u;
+	const uint32_t rest = job >> 6;
+	const uint32_t sLocal = rest % P.sampleCount;
+	const uint32_t cellLocal = rest / P.sampleCount;
+	const uint32_t cell = P.cellFirst + cellLocal * P.cellStride;
+	const uint32_t cx = cell % P.cellsX, cy = cell / P.cellsX;
+	j.x = cx * 8u + (p & 7u); j.y = cy * 8u + (p >> 3);
+	j.slot = cellLocal * 64u + p;
+	j.sample = sLocal;
+	j.valid = (j.x < P.width) && (j.y < P.height);
+	return j;
+}
+
+// ---------------------------------------------------------------------------
+// The megakernel.  samples: [sampleCount][numLocalCells*64] float4.
+// pathStack: [maxPathLength][8][stackStride] floats (refl.xyz, sp, pdf, E.xyz).
+template <int STACK>
+__global__ void __launch_bounds__(RL_BLOCK)
+k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
+        float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
+{
+	__shared__ int s_stack[STACK * RL_BLOCK];
+	int* stk = s_stack + threadIdx.x;
+	const uint32_t gtid = blockIdx.x * RL_BLOCK + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t numSlots = P.numLocalCells * 64u;
+
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = 0;
+	Rng g; g.s.state = 0;
+	V3 o = v3s(0.0f), d = v3s(0.0f);
+	int depth = 0;
+	uint32_t outIndex = 0;
+	bool active = false;
+	bool exhausted = false;
+
+	for (;;) {
+		// ---- refill idle lanes: wave64 ballot + prefix rank, one atomic per wave ----
+		const bool need = !active && !exhausted;
+		const unsigned long long mask = __ballot(need);
+		if (mask != 0ull) {
+			const uint32_t n = (uint32_t)__popcll(mask);
+			const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+			uint32_t base = 0;
+			if (lane == leader) base = atomicAdd(jobCounter, n);
+			base = __shfl(base, (int)leader);
+			if (need) {
+				const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+				const uint32_t job = base + rank;
+				if (job >= P.numJobs) {
+					exhausted = true;
+				} else {
+					const JobPixel j = DecodeJob(P, job);
+					if (j.valid) {
+						// GenerateCell body, reference render/renderer.cc:232-239
+						const uint32_t s = P.sampleBegin + j.sample;
+						g.s = raylib_rng_begin(P.seed, j.y * P.width + j.x, s);
+						const float imageWidth = (float)P.width, imageHeight = (float)P.height;
+						float u = (float)j.x / imageWidth;
+						float v = (float)j.y / imageHeight;
+						if (s != 0) {
+							u += (Next(g) - 0.5f) * 2.0f / imageWidth;
+							v += (Next(g) - 0.5f) * 2.0f / imageHeight;
+						}
+						CameraRay(P.camera, u, v, g, o, d);
+						depth = 0;
+						outIndex = j.sample * numSlots + j.slot;
+						active = true;
+						c.samples++;
+					}
+				}
+			}
+		}
+		if (__ballot(active) == 0ull) {
+			if (__ballot(!exhausted) == 0ull) break;
+			continue;
+		}
+
+		// ---- one bounce for every active lane (TraceScene, reference render/renderer.cc:114-208) ----
+		if (active) {
+			bool done = false;
+			V3 L = v3s(0.0f);
+			if (depth >= P.maxPathLength) {
+				done = true;                                   // renderer.cc:120-123
+			} else {
+				HitRec h;
+				if (Traverse<STACK, false>(S, o, d, P.rayTMin, h, stk, c)) {
+					const Shade sh = LoadShade(S, h.tri);
+					c.shaded++;
+					Surf s;
+					BuildSurface(sh, o, d, h, s, true);
+					const Mat m = LoadMat(S, sh.material);
+					V3 refl = v3s(0.0f), outD = v3s(0.0f);
+					float pdf = 0.0f, sp = 0.0f;
+					const bool scattered = Scatter(S, m, d, s, g, c, refl, outD, pdf, sp);
+					const V3 E = Emitted(S, m, s, c);
+					if (scattered && pdf > 0.0f) {
+						float* st = pathStack + (size_t)depth * 8u * P.stackStride + gtid;
+						st[0] = refl.x; st[P.stackStride] = refl.y; st[2 * (size_t)P.stackStride] = refl.z;
+						st[3 * (size_t)P.stackStride] = sp; st[4 * (size_t)P.stackStride] = pdf;
+						st[5 * (size_t)P.stackStride] = E.x; st[6 * (size_t)P.stackStride] = E.y; st[7 * (size_t)P.stackStride] = E.z;
+						o = s.p; d = outD;
+						depth++;
+					} else {
+						L = v3s(0.0f) + E;                        // radiance(0) += Emitted, renderer.cc:137,151
+						done = true;
+					}
+				} else {
+					L = MissShader<STACK>(S, R, o, d, P.rayTMin, stk, c);
+					done = true;
+				}
+			}
+			if (done) {
+				// fold back to the camera: radiance = (0 + refl*Li*sp/pdf) + E at every vertex
+				for (int k = depth - 1; k >= 0; --k) {
+					const float* st = pathStack + (size_t)k * 8u * P.stackStride + gtid;
+					const V3 refl = v3(st[0], st[P.stackStride], st[2 * (size_t)P.stackStride]);
+					const float sp = st[3 * (size_t)P.stackStride], pdf = st[4 * (size_t)P.stackStride];
+					const V3 E = v3(st[5 * (size_t)P.stackStride], st[6 * (size_t)P.stackStride], st[7 * (size_t)P.stackStride]);
+					V3 radiance = v3s(0.0f);
+					radiance = radiance + refl * L * sp / pdf;
+					radiance = radiance + E;
+					L = radiance;
+				}
+				samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+				active = false;
+			}
+		}
+	}
+
+	// ---- counters: wave reduction, one atomic per wave and counter ----
+	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples };
+	for (int k = 0; k < CNT_COUNT; ++k) {
+		unsigned long long v = vals[k];
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+		if (lane == 0 && v) atomicAdd(&counters[k], v);
+	}
+}
+
+// Sequential per-pixel sum of this batch's samples, then (last batch) the mean.
+// reference render/renderer.cc:244-248 + core/vec3.h:214-220 (operator/= multiplies by 1/SPP)
+__global__ void __launch_bounds__(RL_BLOCK)
+k_resolve(const DRenderParams P, const float4* __restrict__ samples, float4* __restrict__ accum, float4* __restrict__ out, int firstBatch, int lastBatch)
+{
+	const uint32_t numSlots = P.numLocalCells * 64u;
+	const uint32_t slot = blockIdx.x * RL_BLOCK + threadIdx.x;
+	if (slot >= numSlots) return;
+	const uint32_t p = slot & 63u, cellLocal = slot >> 6;
+	const uint32_t cell = P.cellFirst + cellLocal * P.cellStride;
+	const uint32_t x = (cell % P.cellsX) * 8u + (p & 7u), y = (cell / P.cellsX) * 8u + (p >> 3);
+	const bool valid = x < P.width && y < P.height;
+	float4 a = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+	if (valid) {
+		if (!firstBatch) a = accum[slot];
+		for (uint32_t s = 0; s < P.sampleCount; ++s) {
+			const float4 v = samples[(size_t)s * numSlots + slot];
+			a.x += v.x; a.y += v.y; a.z += v.z;
+		}
+		if (lastBatch) {
+			const float k = 1.0f / (float)P.spp;
+			a.x *= k; a.y *= k; a.z *= k; a.w = 1.0f;
+		} else {
+			accum[slot] = a;
+		}
+	}
+	if (lastBatch) {
+		if (P.rowMajorOutput) { if (valid) out[(size_t)y * P.width + x] = a; }
+		else out[slot] = valid ? a : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
+}
+
+// Debug render modes (reference render/renderer.cc:62-111, :258-268): one unjittered sample.
+// Modes 3 and 6 read an uninitialised tangent frame in the reference; here it is built.
+template <int STACK>
+__global__ void __launch_bounds__(RL_BLOCK)
+k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsigned long long* __restrict__ counters)
+{
+	__shared__ int s_stack[STACK * RL_BLOCK];
+	int* stk = s_stack + threadIdx.x;
+	const uint32_t numSlots = P.numLocalCells * 64u;
+	const uint32_t slot = blockIdx.x * RL_BLOCK + threadIdx.x;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = 0;
+	bool valid = false;
+	uint32_t x = 0, y = 0;
+	if (slot < numSlots) {
+		const uint32_t p = slot & 63u, cellLocal = slot >> 6;
+		const uint32_t cell = P.cellFirst + cellLocal * P.cellStride;
+		x = (cell % P.cellsX) * 8u + (p & 7u); y = (cell / P.cellsX) * 8u + (p >> 3);
+		valid = x < P.width && y < P.height;
+	}
+	V3 debugValue = v3s(0.0f);
+	if (valid) {
+		Rng g; g.s = raylib_rng_begin(P.seed, y * P.width + x, 0);
+		V3 o, d;
+		CameraRay(P.camera, (float)x / (float)P.width, (float)y / (float)P.height, g, o, d);
+		c.samples++;
+		HitRec h;
+		if (Traverse<STACK, false>(S, o, d, P.rayTMin, h, stk, c)) {
+			const Shade sh = LoadShade(S, h.tri);
+			c.shaded++;
+			Surf s;
+			BuildSurface(sh, o, d, h, s, true);
+			const Mat m = LoadMat(S, sh.material);
+			const uint32_t mode = P.renderMode;
+			if (mode == RAYLIB_RENDERMODE_Albedo) {
+				debugValue = GetAlbedo(S, m, s.U, s.V, c);
+				if (IsMirrorLike(S, m, s.U, s.V, c)) {
+					HitRec h2;
+					const V3 d2 = reflect(d, s.n);
+					if (Traverse<STACK, false>(S, s.p, d2, P.rayTMin, h2, stk, c)) {
+						const Shade sh2 = LoadShade(S, h2.tri);
+						c.shaded++;
+						Surf s2;
+						BuildSurface(sh2, s.p, d2, h2, s2, false);
+						const Mat m2 = LoadMat(S, sh2.material);
+						debugValue = GetAlbedo(S, m2, s2.U, s2.V, c);
+					}
+				}
+			} else if (mode == RAYLIB_RENDERMODE_SurfaceNormal) {
+				debugValue = v3s(0.5f) + 0.5f * s.n;
+			} else if (mode == RAYLIB_RENDERMODE_MicrosurfaceNormal) {
+				V3 N = GetMicrosurfaceNormal(S, m, s, c);
+				N = LocalToWorld(s, N);
+				debugValue = 0.5f * N + 0.5f;
+			} else if (mode == RAYLIB_RENDERMODE_Texcoord) {
+				debugValue = v3(s.U, s.V, 0.0f);
+			} else if (mode == RAYLIB_RENDERMODE_Emission) {
+				debugValue = Emitted(S, m, s, c);
+			} else if (mode == RAYLIB_RENDERMODE_Reflectance) {
+				V3 refl = v3(1.0f, 0.75f, 0.8f), outD; float pdf, sp;
+				Scatter(S, m, d, s, g, c, refl, outD, pdf, sp);
+				debugValue = refl;
+			}
+		}
+	}
+	if (slot < numSlots) {
+		const float4 px = make_float4(debugValue.x, debugValue.y, debugValue.z, 1.0f);
+		if (P.rowMajorOutput) { if (valid) out[(size_t)y * P.width + x] = px; }
+		else out[slot] = valid ? px : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples };
+	for (int k = 0; k < CNT_COUNT; ++k) {
+		unsigned long long v = vals[k];
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+		if (lane == 0 && v) atomicAdd(&counters[k], v);
+	}
+}
+
+struct DHitOut { int32_t hit; float t; float p[3]; float n[3]; float paramU, paramV; int32_t material; };
+
+template <int STACK>
+__global__ void __launch_bounds__(RL_BLOCK)
+k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float tMin, DHitOut* __restrict__ out)
+{
+	__shared__ int s_stack[STACK * RL_BLOCK];
+	int* stk = s_stack + threadIdx.x;
+	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = 0;
+	const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
+	HitRec h;
+	DHitOut r; memset(&r, 0, sizeof(r)); r.material = -1;
+	if (Traverse<STACK, false>(S, o, d, tMin, h, stk, c)) {
+		const Shade sh = LoadShade(S, h.tri);
+		Surf s;
+		BuildSurface(sh, o, d, h, s, false);
+		r.hit = 1; r.t = s.t;
+		r.p[0] = s.p.x; r.p[1] = s.p.y; r.p[2] = s.p.z;
+		r.n[0] = s.n.x; r.n[1] = s.n.y; r.n[2] = s.n.z;
+		r.paramU = s.U; r.paramV = s.V; r.material = sh.material;
+	}
+	out[i] = r;
+}
+
+// ===========================================================================
+// Host runtime
+// ===========================================================================
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	Log("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__, __LINE__, #expr); return false; } } while (0)
+
+struct DeviceScene {
+	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
+	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
+	DSceneView view;
+	SkyRot skyRot;
+	uint32_t bvhDepth = 0;
+};
+
+namespace {
+
+struct Runtime {
+	bool probed = false, ok = false;
+	int device = 0;
+	int numCUs = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+	// reusable work buffers
+	float4* samples = nullptr; size_t samplesBytes = 0;
+	float4* accum = nullptr; size_t accumBytes = 0;
+	float4* image = nullptr; size_t imageBytes = 0;
+	float* pathStack = nullptr; size_t pathStackBytes = 0;
+	unsigned long long* counters = nullptr;
+	unsigned int* jobCounter = nullptr;
+	std::mutex lock;
+};
+Runtime g_rt;
+
+bool EnsureRuntime()
+{
+	Runtime& R = g_rt;
+	if (R.probed) return R.ok;
+	R.probed = true;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+		Log("raylib(MI355X): no HIP device visible -- Raylib_Render cannot run (there is no CPU fallback)");
+		return false;
+	}
+	int dev = 0;
+	if (const char* e = getenv("RAYLIB_DEVICE")) dev = atoi(e);
+	else if (const char* l = getenv("LOCAL_RANK")) dev = atoi(l);
+	if (dev < 0 || dev >= count) dev = dev % count;
+	HIP_OK(hipSetDevice(dev));
+	hipDeviceProp_t prop;
+	HIP_OK(hipGetDeviceProperties(&prop, dev));
+	R.device = dev;
+	R.numCUs = prop.multiProcessorCount;
+	HIP_OK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+	for (int i = 0; i < 4; ++i) HIP_OK(hipEventCreate(&R.ev[i]));
+	HIP_OK(hipMalloc(&R.counters, CNT_COUNT * sizeof(unsigned long long)));
+	HIP_OK(hipMalloc(&R.jobCounter, sizeof(unsigned int)));
+	Log("raylib(MI355X): device %d %s (%s), %d CUs", dev, prop.name, prop.gcnArchName, R.numCUs);
+	R.ok = true;
+	return true;
+}
+
+template <typename T>
+bool Grow(T*& ptr, size_t& have, size_t need)
+{
+	if (need <= have && ptr) return true;
+	if (ptr) { (void)hipFree(ptr); ptr = nullptr; have = 0; }
+	HIP_OK(hipMalloc(&ptr, need));
+	have = need;
+	return true;
+}
+
+template <typename T>
+bool Upload(T*& dst, const T* src, size_t count)
+{
+	size_t bytes = (count ? count : 1) * sizeof(T);
+	HIP_OK(hipMalloc(&dst, bytes));
+	if (count) HIP_OK(hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+	return true;
+}
+
+// Flatten the host scene into device records (leaf order) and upload.
+bool UploadScene(Scene& sc)
+{
+	if (sc.device) return true;
+	DeviceScene* D = new DeviceScene;
+	const size_t n = sc.triangles.size();
+	std::vector<DTriIsect> isect(n);
+	std::vector<DTriShade> shade(n);
+	for (size_t k = 0; k < n; ++k) {
+		const HostTriangle& t = sc.triangles[sc.bvh.triOrder[k]];
+		DTriIsect& I = isect[k];
+		const f3 nrm = normalize(cross(t.v1 - t.v0, t.v2 - t.v0));   // geom/triangle.h:34-38
+		const f3 u = t.v1 - t.v0, v = t.v2 - t.v0;                   // geom/triangle.cc:30-31
+		const float uv = dot(u, v), uu = dot(u, u), vv = dot(v, v);  // :34-38
+		const float uvuv = uv * uv, uuvv = uu * vv;                  // :39-40
+		I.v0[0] = t.v0.x; I.v0[1] = t.v0.y; I.v0[2] = t.v0.z;
+		I.n[0] = nrm.x; I.n[1] = nrm.y; I.n[2] = nrm.z;
+		I.u[0] = u.x; I.u[1] = u.y; I.u[2] = u.z;
+		I.v[0] = v.x; I.v[1] = v.y; I.v[2] = v.z;
+		I.uv = uv; I.uu = uu; I.vv = vv; I.denom = uvuv - uuvv;
+		DTriShade& Sh = shade[k];
+		Sh.n0[0] = t.n0.x; Sh.n0[1] = t.n0.y; Sh.n0[2] = t.n0.z;
+		Sh.n1[0] = t.n1.x; Sh.n1[1] = t.n1.y; Sh.n1[2] = t.n1.z;
+		Sh.n2[0] = t.n2.x; Sh.n2[1] = t.n2.y; Sh.n2[2] = t.n2.z;
+		Sh.s0 = t.s0; Sh.t0 = t.t0; Sh.s1 = t.s1; Sh.t1 = t.t1; Sh.s2 = t.s2; Sh.t2 = t.t2;
+		Sh.material = t.material;
+	}
+	std::vector<DMaterial> mats(sc.materials.size());
+	for (size_t i = 0; i < mats.size(); ++i) {
+		const HostMaterial& h = sc.materials[i];
+		DMaterial& m = mats[i]; memset(&m, 0, sizeof(m));
+		m.type = h.type;
+		memcpy(m.albedo, h.albedo, 12); m.roughness = h.roughness; m.metallic = h.metallic;
+		memcpy(m.emissive, h.emissive, 12); m.ior = h.ior; memcpy(m.transmission, h.transmission, 12);
+		m.fuzziness = h.fuzziness; memcpy(m.tex, h.tex, 20);
+	}
+	std::vector<DTexture> texs(sc.textures.size());
+	std::vector<float> pool;
+	for (size_t i = 0; i < texs.size(); ++i) {
+		const Image& im = *sc.textures[i];
+		texs[i].offset = (uint32_t)(pool.size() / 4); texs[i].width = (int32_t)im.width; texs[i].height = (int32_t)im.height; texs[i].pad = 0;
+		pool.insert(pool.end(), im.rgba.begin(), im.rgba.end());
+	}
+	if (!Upload(D->nodes, sc.bvh.nodes.data(), sc.bvh.nodes.size())) return false;
+	if (!Upload(D->isect, isect.data(), n)) return false;
+	if (!Upload(D->shade, shade.data(), n)) return false;
+	if (!Upload(D->materials, mats.data(), mats.size())) return false;
+	if (!Upload(D->textures, texs.data(), texs.size())) return false;
+	if (!Upload(D->texels, pool.data(), pool.size())) return false;
+	DSceneView& V = D->view;
+	V.nodes = D->nodes; V.isect = D->isect; V.shade = D->shade; V.materials = D->materials;
+	V.textures = D->textures; V.texels = D->texels;
+	V.sunIlluminance[0] = sc.sunIlluminance.x; V.sunIlluminance[1] = sc.sunIlluminance.y; V.sunIlluminance[2] = sc.sunIlluminance.z;
+	V.sunDirection[0] = sc.sunDirection.x; V.sunDirection[1] = sc.sunDirection.y; V.sunDirection[2] = sc.sunDirection.z;
+	V.skyTexture = sc.skyTexture;
+	V.hasSun = !(sc.sunIlluminance.x == 0.0f && sc.sunIlluminance.y == 0.0f && sc.sunIlluminance.z == 0.0f);   // renderer.cc:192
+	V.numTriangles = (int32_t)n;
+	{   // Rotator(yaw = 90).rotate rows, reference geom/transform.cc:47-65 (host libm, as the reference)
+		const float pi_f = (float)3.1415926535897932385;
+		const float ry = 90.0f * pi_f / 180.0f, rp = 0.0f * pi_f / 180.0f, rr = 0.0f * pi_f / 180.0f;
+		const float ch = cosf(ry), sh = sinf(ry), cp = cosf(rp), sp = sinf(rp), cb = cosf(rr), sb = sinf(rr);
+		D->skyRot.m0[0] = ch * cb + sh * sp * sb; D->skyRot.m0[1] = sb * cp; D->skyRot.m0[2] = -sh * cb + ch * sp * sb;
+		D->skyRot.m1[0] = -ch * sb + sh * sp * cb; D->skyRot.m1[1] = cb * cp; D->skyRot.m1[2] = sb * sh + ch * sp * cb;
+		D->skyRot.m2[0] = sh * cp; D->skyRot.m2[1] = -sp; D->skyRot.m2[2] = ch * cp;
+	}
+	D->bvhDepth = sc.bvh.depth;
+	sc.device = D;
+	return true;
+}
+
+template <int STACK>
+bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
+{
+	Runtime& R = g_rt;
+	DeviceScene* D = sc.device;
+	const RendererSettings& st = req.settings;
+	const uint32_t W = st.viewportWidth, H = st.viewportHeight;
+	const uint32_t cellsX = (W + 7) / 8, cellsY = (H + 7) / 8, numCells = cellsX * cellsY;
+	const uint32_t stride = req.cellStride ? req.cellStride : 1;
+	const uint32_t numLocalCells = req.cellFirst < numCells ? (numCells - req.cellFirst + stride - 1) / stride : 0;
+	const uint32_t numSlots = numLocalCells * 64u;
+	const bool rowMajor = (stride == 1 && req.cellFirst == 0);
+	const uint32_t SPP = (uint32_t)(st.samplesPerPixel > 1 ? st.samplesPerPixel : 1);
+	const bool pathTrace = (st.renderMode == RAYLIB_RENDERMODE_Default);
+
+	DRenderParams P; memset(&P, 0, sizeof(P));
+	P.width = W; P.height = H; P.spp = SPP; P.maxPathLength = st.maxPathLength; P.rayTMin = st.rayTMin;
+	P.renderMode = st.renderMode; P.seed = req.seed; P.cellsX = cellsX; P.cellsY = cellsY;
+	P.cellFirst = req.cellFirst; P.cellStride = stride; P.numLocalCells = numLocalCells;
+	P.rowMajorOutput = rowMajor ? 1u : 0u; P.camera = req.camera;
+
+	const size_t outBytes = rowMajor ? (size_t)W * H * sizeof(float4) : (size_t)numSlots * sizeof(float4);
+	float4* out = (float4*)req.outDevice;
+	if (!out) { if (!Grow(R.image, R.imageBytes, outBytes ? outBytes : 16)) return false; out = R.image; }
+
+	HIP_OK(hipMemsetAsync(R.counters, 0, CNT_COUNT * sizeof(unsigned long long), R.stream));
+	float traceMs = 0.0f;
+	uint32_t launches = 0;
+	HIP_OK(hipEventRecord(R.ev[0], R.stream));
+	if (numSlots == 0) {
+		// nothing to do for this rank
+	} else if (!pathTrace) {
+		const uint32_t blocks = (numSlots + RL_BLOCK - 1) / RL_BLOCK;
+		hipLaunchKernelGGL(k_aov<STACK>, dim3(blocks), dim3(RL_BLOCK), 0, R.stream, P, D->view, out, R.counters);
+		HIP_OK(hipGetLastError());
+	} else {
+		// sample batches: bound the sample buffer to ~2 GiB
+		const size_t perSample = (size_t)numSlots * sizeof(float4);
+		uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(SPP, ((size_t)2 << 30) / perSample));
+		if (!Grow(R.samples, R.samplesBytes, perSample * batch)) return false;
+		if (batch < SPP && !Grow(R.accum, R.accumBytes, perSample)) return false;
+		int blocksPerCU = 0;
+		HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, k_trace<STACK>, RL_BLOCK, 0));
+		if (blocksPerCU < 1) blocksPerCU = 1;
+		if (const char* e = getenv("RAYLIB_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) blocksPerCU = v; }
+		const int depthSlots = st.maxPathLength > 1 ? st.maxPathLength : 1;
+		for (uint32_t s0 = 0; s0 < SPP; s0 += batch) {
+			const uint32_t cnt = std::min(batch, SPP - s0);
+			P.sampleBegin = s0; P.sampleCount = cnt;
+			const uint64_t jobs64 = (uint64_t)numLocalCells * cnt * 64u;
+			if (jobs64 > 0xFFFFFF00ull) { Log("Raylib_Render: job count overflow"); return false; }
+			P.numJobs = (uint32_t)jobs64;
+			uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)R.numCUs * blocksPerCU, (jobs64 + RL_BLOCK - 1) / RL_BLOCK);
+			if (blocks < 1) blocks = 1;
+			P.stackStride = blocks * RL_BLOCK;
+			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
+			HIP_OK(hipMemsetAsync(R.jobCounter, 0, sizeof(unsigned int), R.stream));
+			HIP_OK(hipEventRecord(R.ev[2], R.stream));
+			hipLaunchKernelGGL(k_trace<STACK>, dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
+			                   P, D->view, D->skyRot, R.samples, R.pathStack, R.counters, R.jobCounter);
+			HIP_OK(hipGetLastError());
+			HIP_OK(hipEventRecord(R.ev[3], R.stream));
+			const uint32_t rblocks = (numSlots + RL_BLOCK - 1) / RL_BLOCK;
+			hipLaunchKernelGGL(k_resolve, dim3(rblocks), dim3(RL_BLOCK), 0, R.stream,
+			                   P, R.samples, R.accum, out, (int)(s0 == 0), (int)(s0 + cnt >= SPP));
+			HIP_OK(hipGetLastError());
+			HIP_OK(hipEventSynchronize(R.ev[3]));
+			float ms = 0.0f;
+			HIP_OK(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]));
+			traceMs += ms;
+			++launches;
+		}
+	}
+	HIP_OK(hipEventRecord(R.ev[1], R.stream));
+	HIP_OK(hipEventSynchronize(R.ev[1]));
+	float totalMs = 0.0f;
+	HIP_OK(hipEventElapsedTime(&totalMs, R.ev[0], R.ev[1]));
+
+	unsigned long long cnt[CNT_COUNT];
+	HIP_OK(hipMemcpyAsync(cnt, R.counters, sizeof(cnt), hipMemcpyDeviceToHost, R.stream));
+	if (req.outHostRGBA && rowMajor) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, outBytes, hipMemcpyDeviceToHost, R.stream));
+	HIP_OK(hipStreamSynchronize(R.stream));
+
+	stats.rays = cnt[CNT_RAYS]; stats.nodesVisited = cnt[CNT_NODES]; stats.trisTested = cnt[CNT_TRIS];
+	stats.shadedHits = cnt[CNT_SHADED]; stats.texFetches = cnt[CNT_TEXELS]; stats.cameraSamples = cnt[CNT_SAMPLES];
+	uint64_t px = 0;
+	for (uint32_t k = 0; k < numLocalCells; ++k) {
+		const uint32_t cell = req.cellFirst + k * stride, cx = cell % cellsX, cy = cell / cellsX;
+		px += (uint64_t)std::min(8u, W - cx * 8) * std::min(8u, H - cy * 8);
+	}
+	stats.pixels = px;
+	stats.kernelMs = totalMs; stats.traceKernelMs = pathTrace ? traceMs : totalMs; stats.traceLaunches = pathTrace ? launches : 1;
+	stats.numNodes = (uint32_t)sc.bvh.nodes.size(); stats.numTriangles = (uint32_t)sc.triangles.size(); stats.bvhDepth = sc.bvh.depth;
+	return true;
+}
+
+} // namespace
+
+bool DeviceAvailable()
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	return EnsureRuntime();
+}
+
+bool DeviceRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	const auto t0 = std::chrono::steady_clock::now();
+	if (!EnsureRuntime()) return false;
+	HIP_OK(hipSetDevice(g_rt.device));
+	if (!UploadScene(sc)) return false;
+	bool ok;
+	if (sc.bvh.depth <= 32) ok = LaunchRender<32>(sc, req, stats);
+	else if (sc.bvh.depth <= 64) ok = LaunchRender<64>(sc, req, stats);
+	else { Log("Raylib_Render: BVH depth %u exceeds the traversal stack (64)", sc.bvh.depth); ok = false; }
+	stats.wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	return ok;
+}
+
+bool DeviceClosestHit(Scene& sc, const float* rays, int32_t n, float tMin, void* outHits)
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	if (!EnsureRuntime()) return false;
+	HIP_OK(hipSetDevice(g_rt.device));
+	if (!UploadScene(sc)) return false;
+	if (n <= 0) return true;
+	float* dRays = nullptr; DHitOut* dOut = nullptr;
+	HIP_OK(hipMalloc(&dRays, (size_t)n * 6 * sizeof(float)));
+	HIP_OK(hipMalloc(&dOut, (size_t)n * sizeof(DHitOut)));
+	HIP_OK(hipMemcpy(dRays, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
+	const uint32_t blocks = ((uint32_t)n + RL_BLOCK - 1) / RL_BLOCK;
+	if (sc.bvh.depth <= 32) hipLaunchKernelGGL(k_closest_hit<32>, dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, sc.device->view, dRays, n, tMin, dOut);
+	else hipLaunchKernelGGL(k_closest_hit<64>, dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, sc.device->view, dRays, n, tMin, dOut);
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipStreamSynchronize(g_rt.stream));
+	HIP_OK(hipMemcpy(outHits, dOut, (size_t)n * sizeof(DHitOut), hipMemcpyDeviceToHost));
+	(void)hipFree(dRays); (void)hipFree(dOut);
+	return true;
+}
+
+bool DevicePostProcess(Image&) { return false; }
+
+void DeviceReleaseScene(DeviceScene* D)
+{
+	if (!D) return;
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	(void)hipFree(D->nodes); (void)hipFree(D->isect); (void)hipFree(D->shade);
+	(void)hipFree(D->materials); (void)hipFree(D->textures); (void)hipFree(D->texels);
+	delete D;
+}
+
+void DeviceShutdown()
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	Runtime& R = g_rt;
+	if (!R.ok) return;
+	(void)hipFree(R.samples); (void)hipFree(R.accum); (void)hipFree(R.image); (void)hipFree(R.pathStack);
+	(void)hipFree(R.counters); (void)hipFree(R.jobCounter);
+	R.samples = R.accum = R.image = nullptr; R.pathStack = nullptr; R.counters = nullptr; R.jobCounter = nullptr;
+	R.samplesBytes = R.accumBytes = R.imageBytes = R.pathStackBytes = 0;
+	for (int i = 0; i < 4; ++i) if (R.ev[i]) (void)hipEventDestroy(R.ev[i]);
+	if (R.stream) (void)hipStreamDestroy(R.stream);
+	R.stream = nullptr; R.ok = false; R.probed = false;
+}
+
+} // namespace rl

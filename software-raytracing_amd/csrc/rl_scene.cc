@@ -1,0 +1,133 @@
+// Scene / camera host logic: what the reference does in geom/scene.cc,
+// render/camera.h and raylib.cc between Raylib_CreateScene and Raylib_FinalizeScene,
+// re-stated for a flat device scene.
+#include "rl_host.h"
+
+#include <string.h>
+
+namespace rl {
+
+// reference render/camera.h:55-78
+void Camera::UpdateInternal()
+{
+	lensRadius = aperture * 0.5f;
+	timePeriod = endTime - beginTime;
+	w = normalize(origin - lookAt);
+	f3 up = F3(0.0f, 1.0f, 0.0f);
+	if (dot(w, up) >= 0.9f) up = F3(1.0f, 0.0f, 0.0f);
+	u = normalize(cross(up, w));
+	v = cross(w, u);
+	const float pi_f = (float)3.1415926535897932385;
+	float theta = fovY_degrees * pi_f / 180.0f;
+	float hh = tanf(theta / 2.0f);
+	float hw = aspectWH * hh;
+	top_left = origin - (hw * focalDistance * u) - (hh * focalDistance * v) - (focalDistance * w);
+	horizontal = 2.0f * hw * focalDistance * u;
+	vertical = 2.0f * hh * focalDistance * v;
+}
+
+DCamera Camera::ToDevice() const
+{
+	DCamera d; memset(&d, 0, sizeof(d));
+	d.origin[0] = origin.x; d.origin[1] = origin.y; d.origin[2] = origin.z; d.lensRadius = lensRadius;
+	d.top_left[0] = top_left.x; d.top_left[1] = top_left.y; d.top_left[2] = top_left.z; d.beginTime = beginTime;
+	d.horizontal[0] = horizontal.x; d.horizontal[1] = horizontal.y; d.horizontal[2] = horizontal.z; d.timePeriod = timePeriod;
+	d.vertical[0] = vertical.x; d.vertical[1] = vertical.y; d.vertical[2] = vertical.z;
+	d.u[0] = u.x; d.u[1] = u.y; d.u[2] = u.z;
+	d.v[0] = v.x; d.v[1] = v.y; d.v[2] = v.z;
+	return d;
+}
+
+// reference geom/scene.cc:6-10
+Scene::Scene()
+{
+	sunIlluminance = F3(0.0f, 0.0f, 0.0f);
+	sunDirection = normalize(F3(0.0f, -1.0f, -0.5f));
+}
+
+Scene::~Scene()
+{
+	if (device) DeviceReleaseScene(device);
+}
+
+// reference geom/scene.cc:23-31 builds the top BVH over the elements added so far and
+// ignores later additions.  Here: concatenate the borrowed models' triangles, offset
+// their material / texture indices, build the flat BVH, mark alpha-tested leaves.
+void Scene::Finalize()
+{
+	if (finalized) return;
+	finalized = true;
+	triangles.clear(); materials.clear(); textures.clear();
+	int32_t shapeBase = 0;
+	for (OBJModel* m : models) {
+		const int32_t matBase = (int32_t)materials.size();
+		const int32_t texBase = (int32_t)textures.size();
+		for (const std::shared_ptr<Image>& im : m->images) textures.push_back(im);
+		for (HostMaterial hm : m->materials) {
+			for (int k = 0; k < 5; ++k) if (hm.tex[k] >= 0) hm.tex[k] += texBase;
+			materials.push_back(hm);
+		}
+		for (HostTriangle t : m->triangles) {
+			t.material += matBase;
+			t.shape += shapeBase;
+			triangles.push_back(t);
+		}
+		shapeBase += m->numShapes;
+	}
+	skyTexture = -1;
+	if (sky) {
+		skyCopy = std::make_shared<Image>(*sky);
+		skyTexture = (int32_t)textures.size();
+		textures.push_back(skyCopy);
+	}
+	BuildBVH(triangles, bvh);
+	// leaves that contain a triangle whose material has an albedo texture run the
+	// cut-out test inside traversal (reference geom/triangle.cc:54, material.cc:397-404)
+	std::vector<uint8_t> alpha(triangles.size(), 0);
+	bool any = false;
+	for (size_t i = 0; i < triangles.size(); ++i) {
+		const HostMaterial& hm = materials[triangles[i].material];
+		if (hm.type == MAT_MICROFACET && hm.tex[0] >= 0) { alpha[i] = 1; any = true; }
+	}
+	if (any) {
+		auto patch = [&](int32_t& ref) {
+			if (ref >= 0 || ref == DNODE_EMPTY) return;
+			uint32_t code = (uint32_t)~ref, first = code >> 4, count = (code & 7u) + 1;
+			for (uint32_t k = 0; k < count; ++k) if (alpha[bvh.triOrder[first + k]]) { code |= 8u; break; }
+			ref = ~(int32_t)code;
+		};
+		for (DNode& n : bvh.nodes) { patch(n.left); patch(n.right); }
+	}
+	Log("Scene finalized: %u triangles, %u BVH nodes, depth %u, SAH cost %.2f",
+	    (unsigned)triangles.size(), (unsigned)bvh.nodes.size(), bvh.depth, bvh.sahCost);
+}
+
+// Image2D::PostProcess on the host (reference render/image.cc:44-103): max-luminance
+// scan, extended Reinhard on luminance, clamp to white, gamma 1/2.2.
+void PostProcessHost(Image& img)
+{
+	const size_t len = (size_t)img.width * img.height;
+	float maxWhiteLuminance = 1.0f;
+	for (size_t i = 0; i < len; ++i) {
+		const float* p = &img.rgba[4 * i];
+		float L = dot(F3(p[0], p[1], p[2]), F3(0.2126f, 0.7152f, 0.0722f));
+		if (maxWhiteLuminance < L) maxWhiteLuminance = L;
+	}
+	Log("Max white luminance: %f", maxWhiteLuminance);
+	for (size_t i = 0; i < len; ++i) {
+		float* p = &img.rgba[4 * i];
+		f3 rgb = F3(p[0], p[1], p[2]);
+		float luminanceOld = dot(rgb, F3(0.2126f, 0.7152f, 0.0722f));
+		if (luminanceOld <= 0.0001f) rgb = F3(0.0f, 0.0f, 0.0f);
+		else {
+			float numerator = luminanceOld * (1.0f + (luminanceOld / (maxWhiteLuminance * maxWhiteLuminance)));
+			float luminanceNew = numerator / (1.0f + luminanceOld);
+			rgb = rgb * (luminanceNew / luminanceOld);
+		}
+		rgb = fmin3(F3(1.0f, 1.0f, 1.0f), rgb);
+		const float K = 1.0f / 2.2f;
+		p[0] = powf(rgb.x, K); p[1] = powf(rgb.y, K); p[2] = powf(rgb.z, K);
+	}
+}
+
+} // namespace rl

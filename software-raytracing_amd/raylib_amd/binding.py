@@ -1,0 +1,197 @@
+"""ctypes binding of libraylib.so -- the Python mirror of the reference's own FFI
+wrapper (gui-app/gui-app/RaylibWrapper.cs:43-145 binds the same 33 functions with
+P/Invoke).  Function names, argument order and return conventions are the C-ABI's.
+
+There is no fallback: if the shared library is missing this module raises, and if
+no HIP device is present Raylib_Initialize returns 0 and Raylib_Render fails loudly.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(HERE), "libraylib.so")
+
+RENDERMODE_DEFAULT, RENDERMODE_ALBEDO, RENDERMODE_SURFACE_NORMAL, RENDERMODE_MICROSURFACE_NORMAL, \
+    RENDERMODE_TEXCOORD, RENDERMODE_EMISSION, RENDERMODE_REFLECTANCE = range(7)
+
+
+class RendererSettings(C.Structure):
+    """reference raylib_types.h:41-57 / RaylibWrapper.cs:27-38 (24 bytes)."""
+    _fields_ = [("viewportWidth", C.c_uint32), ("viewportHeight", C.c_uint32),
+                ("samplesPerPixel", C.c_int32), ("maxPathLength", C.c_int32),
+                ("rayTMin", C.c_float), ("renderMode", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64),
+                ("shadedHits", C.c_uint64), ("texFetches", C.c_uint64), ("cameraSamples", C.c_uint64),
+                ("pixels", C.c_uint64), ("kernelMs", C.c_double), ("traceKernelMs", C.c_double), ("wallMs", C.c_double),
+                ("traceLaunches", C.c_uint32), ("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("bvhDepth", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# Per-ray / per-unit algorithmic byte constants of the flat layout (csrc/rl_device.h)
+NODE_B, TRI_B, SHADE_B, TEXEL_B, PIXEL_B = 64, 64, 64, 16, 16
+
+
+def algorithmic_bytes(stats):
+    """nodes*NODE_B + tris*TRI_B + shaded*SHADE_B + texels*TEXEL_B + pixels*16."""
+    return (stats.nodesVisited * NODE_B + stats.trisTested * TRI_B + stats.shadedHits * SHADE_B +
+            stats.texFetches * TEXEL_B + stats.pixels * PIXEL_B)
+
+
+_EXPORTS = {
+    # name: (restype, argtypes)   -- include/raylib.h
+    "Raylib_Initialize": (C.c_int32, []),
+    "Raylib_Terminate": (C.c_int32, []),
+    "Raylib_LoadOBJModel": (C.c_void_p, [C.c_char_p]),
+    "Raylib_TransformOBJModel": (None, [C.c_void_p] + [C.c_float] * 9),
+    "Raylib_FinalizeOBJModel": (None, [C.c_void_p]),
+    "Raylib_UnloadOBJModel": (C.c_int32, [C.c_void_p]),
+    "Raylib_LoadImage": (C.c_void_p, [C.c_char_p]),
+    "Raylib_CreateScene": (C.c_void_p, []),
+    "Raylib_AddSceneElement": (None, [C.c_void_p, C.c_void_p]),
+    "Raylib_AddOBJModelToScene": (None, [C.c_void_p, C.c_void_p]),
+    "Raylib_SetSkyPanorama": (None, [C.c_void_p, C.c_void_p]),
+    "Raylib_SetSunIlluminance": (None, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "Raylib_SetSunDirection": (None, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "Raylib_FinalizeScene": (None, [C.c_void_p]),
+    "Raylib_DestroyScene": (C.c_int32, [C.c_void_p]),
+    "Raylib_CreateCamera": (C.c_void_p, []),
+    "Raylib_CameraSetPosition": (None, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "Raylib_CameraSetLookAt": (None, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "Raylib_CameraSetPerspective": (None, [C.c_void_p, C.c_float, C.c_float]),
+    "Raylib_CameraSetLens": (None, [C.c_void_p, C.c_float, C.c_float]),
+    "Raylib_CameraSetMotion": (None, [C.c_void_p, C.c_float, C.c_float]),
+    "Raylib_CameraCopy": (None, [C.c_void_p, C.c_void_p]),
+    "Raylib_DestroyCamera": (C.c_int32, [C.c_void_p]),
+    "Raylib_CreateImage": (C.c_void_p, [C.c_uint32, C.c_uint32]),
+    "Raylib_DumpImageData": (None, [C.c_void_p, C.POINTER(C.c_float)]),
+    "Raylib_DestroyImage": (C.c_int32, [C.c_void_p]),
+    "Raylib_Render": (None, [C.POINTER(RendererSettings), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "Raylib_Denoise": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "Raylib_PostProcess": (None, [C.c_void_p]),
+    "Raylib_IsDenoiserSupported": (C.c_int32, []),
+    "Raylib_GetRenderModeString": (C.c_char_p, [C.c_uint32]),
+    "Raylib_WriteImageToDisk": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint32]),
+    "Raylib_FlushLogThread": (None, []),
+    # include/raylib_amd.h
+    "RaylibAMD_SetSeed": (None, [C.c_uint64]),
+    "RaylibAMD_GetSeed": (C.c_uint64, []),
+    "RaylibAMD_GetLastStats": (None, [C.POINTER(Stats)]),
+    "RaylibAMD_DeviceAvailable": (C.c_int32, []),
+    "RaylibAMD_RenderDevice": (C.c_int32, [C.POINTER(RendererSettings), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "RaylibAMD_CellBufferFloats": (C.c_uint64, [C.c_uint32] * 4),
+    "RaylibAMD_NumCells": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+    "RaylibAMD_ClosestHit": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]),
+    "RaylibAMD_SceneNumTriangles": (C.c_int32, [C.c_void_p]),
+    "RaylibAMD_SceneNumMaterials": (C.c_int32, [C.c_void_p]),
+    "RaylibAMD_SceneNumTextures": (C.c_int32, [C.c_void_p]),
+    "RaylibAMD_SceneExportTriangles": (None, [C.c_void_p, C.c_void_p]),
+    "RaylibAMD_SceneExportMaterials": (None, [C.c_void_p, C.c_void_p]),
+    "RaylibAMD_SceneTextureSize": (None, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "RaylibAMD_SceneExportTexture": (None, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
+    "RaylibAMD_SceneGetSun": (None, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "RaylibAMD_SceneBVHInfo": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
+    "RaylibAMD_CameraExport": (None, [C.c_void_p, C.POINTER(C.c_float)]),
+    "RaylibAMD_CreateImageFromData": (C.c_void_p, [C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
+    "RaylibAMD_DumpImageRGBA": (None, [C.c_void_p, C.POINTER(C.c_float)]),
+    "RaylibAMD_OBJModelSetTexture": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p]),
+}
+RAYLIB_H_EXPORTS = [k for k in _EXPORTS if k.startswith("Raylib_")]
+RAYLIB_AMD_H_EXPORTS = [k for k in _EXPORTS if k.startswith("RaylibAMD_")]
+
+
+def load(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise FileNotFoundError(path + " -- build it with `make -C software-raytracing_amd` (or __graft_entry__.build())")
+    lib = C.CDLL(path)
+    for name, (res, args) in _EXPORTS.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class SceneSession:
+    """The GUI's call sequence (reference gui-app/gui-app/MainForm.cs:121-256) as an object:
+    LoadOBJ -> FinalizeOBJ -> CreateScene/Camera -> AddOBJ -> Sun -> FinalizeScene -> camera setters."""
+
+    def __init__(self, lib, obj_path, origin, look_at, fov, aspect, sun=(0, 0, 0), sun_dir=(0.0, -1.0, -0.5),
+                 aperture=0.0, focal=1.0, shutter=(0.0, 0.0), sky_image=None, textures=()):
+        self.lib = lib
+        self.obj = lib.Raylib_LoadOBJModel(obj_path.encode())
+        if not self.obj:
+            raise RuntimeError("Raylib_LoadOBJModel failed: " + obj_path)
+        self._images = []
+        for mat_name, slot, rgba in textures:
+            rgba = np.ascontiguousarray(rgba, np.float32)
+            ih = lib.RaylibAMD_CreateImageFromData(rgba.shape[1], rgba.shape[0], _fp(rgba))
+            self._images.append(ih)
+            if not lib.RaylibAMD_OBJModelSetTexture(self.obj, mat_name.encode(), slot, ih):
+                raise RuntimeError("RaylibAMD_OBJModelSetTexture failed for " + mat_name)
+        lib.Raylib_FinalizeOBJModel(self.obj)
+        self.scene = lib.Raylib_CreateScene()
+        self.camera = lib.Raylib_CreateCamera()
+        lib.Raylib_AddOBJModelToScene(self.scene, self.obj)
+        lib.Raylib_SetSunIlluminance(self.scene, *[float(x) for x in sun])
+        lib.Raylib_SetSunDirection(self.scene, *[float(x) for x in sun_dir])
+        if sky_image is not None:
+            sky = np.ascontiguousarray(sky_image, np.float32)
+            ih = lib.RaylibAMD_CreateImageFromData(sky.shape[1], sky.shape[0], _fp(sky))
+            self._images.append(ih)
+            lib.Raylib_SetSkyPanorama(self.scene, ih)
+        lib.Raylib_FinalizeScene(self.scene)
+        lib.Raylib_CameraSetPosition(self.camera, *[float(x) for x in origin])
+        lib.Raylib_CameraSetLookAt(self.camera, *[float(x) for x in look_at])
+        lib.Raylib_CameraSetPerspective(self.camera, float(fov), float(aspect))
+        lib.Raylib_CameraSetLens(self.camera, float(aperture), float(focal))
+        lib.Raylib_CameraSetMotion(self.camera, float(shutter[0]), float(shutter[1]))
+
+    def settings(self, w, h, spp, max_path=5, tmin=1e-4, mode=RENDERMODE_DEFAULT):
+        return RendererSettings(int(w), int(h), int(spp), int(max_path), float(tmin), int(mode))
+
+    def render(self, w, h, spp, max_path=5, tmin=1e-4, mode=RENDERMODE_DEFAULT):
+        """Raylib_Render into a fresh image; returns (H, W, 4) float32 RGBA."""
+        lib = self.lib
+        st = self.settings(w, h, spp, max_path, tmin, mode)
+        img = lib.Raylib_CreateImage(w, h)
+        lib.Raylib_Render(C.byref(st), self.scene, self.camera, img)
+        out = np.zeros((h, w, 4), np.float32)
+        lib.RaylibAMD_DumpImageRGBA(img, _fp(out))
+        lib.Raylib_DestroyImage(img)
+        return out
+
+    def stats(self):
+        s = Stats()
+        self.lib.RaylibAMD_GetLastStats(C.byref(s))
+        return s
+
+    def export_flat(self):
+        """(triangles, materials) as numpy arrays with the oracle's record layouts."""
+        from_tri = np.dtype([("v0", "f4", 3), ("v1", "f4", 3), ("v2", "f4", 3), ("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3),
+                             ("st", "f4", 6), ("material", "i4"), ("shape", "i4")])
+        from_mat = np.dtype([("type", "i4"), ("albedo", "f4", 3), ("roughness", "f4"), ("metallic", "f4"), ("emissive", "f4", 3),
+                             ("ior", "f4"), ("transmission", "f4", 3), ("fuzziness", "f4"),
+                             ("texAlbedo", "i4"), ("texNormal", "i4"), ("texRoughness", "i4"), ("texMetallic", "i4"), ("texEmissive", "i4")])
+        lib = self.lib
+        tris = np.zeros(lib.RaylibAMD_SceneNumTriangles(self.scene), from_tri)
+        mats = np.zeros(lib.RaylibAMD_SceneNumMaterials(self.scene), from_mat)
+        lib.RaylibAMD_SceneExportTriangles(self.scene, tris.ctypes.data)
+        lib.RaylibAMD_SceneExportMaterials(self.scene, mats.ctypes.data)
+        return tris, mats
+
+    def close(self):
+        lib = self.lib
+        # reference order: model, scene, camera, images (MainForm.cs:253-256)
+        lib.Raylib_UnloadOBJModel(self.obj)
+        lib.Raylib_DestroyScene(self.scene)
+        lib.Raylib_DestroyCamera(self.camera)
+        for ih in self._images:
+            lib.Raylib_DestroyImage(ih)
