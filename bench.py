@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the hot path (Raylib_Render's megakernel) on N MI355X GPUs.
+
+A "step" is one full frame of BASELINE.json's configs[1]: synthetic Cornell box
+(36 triangles), 1920x1080, 64 spp, maxPathLength 5, fixed RNG seed, scene resident
+in HBM.  With N ranks (one process per GPU) the 8x8-pixel cells of the frame are
+dealt round-robin to the ranks, each rank renders its cells into device memory, and
+one RCCL gather per frame brings them to rank 0 (strong scaling: total work fixed).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
+os.environ.setdefault("RAYLIB_QUIET", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cornell_1080p_64spp": dict(scene="cornell", kw={}, w=1920, h=1080, spp=64, max_path=5, camera="cornell"),
+    # configs[2]-sized stress (parity-test size by default; selectable for profiling)
+    "breakfast_300k_1080p_128spp": dict(scene="cornell", kw=dict(tess=91, displace_fraction=0.2), w=1920, h=1080, spp=128, max_path=5, camera="breakfast"),
+}
+
+
+def cpu_baseline(workload, cam, gpu_rays_per_sample):
+    """The reference's own CPU path (Renderer::RenderScene + its ThreadPool, built in place into
+    oracle/_ref/libref_native.so) timed on this host's cores on a bounded sample of the same
+    workload.  Falls back to the oracle restatement (kind "port") when the prebuilt binary is absent."""
+    sys.path.insert(0, ROOT)
+    from oracle import ffi, objflat           # checker only: never on the product path
+    from raylib_amd import scenes
+    orc = ffi.load_oracle()
+    tmp = tempfile.mkdtemp()
+    obj, _ = getattr(scenes, workload["scene"])(os.path.join(tmp, "cpu.obj"), **workload["kw"])
+    flat = objflat.load_obj(obj, orc, sun_illuminance=cam["sun"], sun_direction=cam["sun_dir"])
+    w, h = workload["w"], workload["h"]
+    spp = max(1, min(workload["spp"], 8 if flat.triangles.shape[0] < 1000 else 1))
+    camera = ffi.make_camera(cam["origin"], cam["look_at"], cam["fov"], w / h)
+    st = ffi.make_settings(w, h, spp, max_path=workload["max_path"])
+    cores = os.cpu_count() or 1
+    ref = ffi.load_ref(seeded=False)
+    if ref is not None:
+        scene = ref.scene_create(flat, 1)
+        t0 = time.time(); ref.render_native(scene, camera, st); dt = time.time() - t0
+        kind = "reference"
+    else:
+        scene = orc.scene_create(flat, 1)
+        t0 = time.time(); orc.render(scene, camera, st, seed=1, threads=cores); dt = time.time() - t0
+        kind = "port"
+    samples = w * h * spp
+    return {"value": samples * gpu_rays_per_sample / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
+            "seconds": dt, "camera_samples_per_s": samples / dt,
+            "sample": "%dx%d at %d spp of the same scene/camera (%.1f%% of the step's camera samples), all %d host threads; "
+                      "rays = camera samples x the GPU run's measured rays per camera sample (%.4f), since the reference has no ray counter"
+                      % (w, h, spp, 100.0 * spp / workload["spp"], cores, gpu_rays_per_sample)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell_1080p_64spp", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ["RAYLIB_DEVICE"] = str(local_rank)
+
+    import torch
+    import torch.distributed as dist
+    from raylib_amd import binding, scenes, tiling
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    lib = binding.load()
+    if lib.Raylib_Initialize() != 1:
+        raise SystemExit("Raylib_Initialize failed")
+    lib.RaylibAMD_SetSeed(1)
+
+    wl = WORKLOADS[args.workload]
+    cam = scenes.CONFIG_CAMERAS[wl["camera"]]
+    w, h = wl["w"], wl["h"]
+    tmp = tempfile.mkdtemp()
+    obj, ntris = getattr(scenes, wl["scene"])(os.path.join(tmp, "bench_r%d.obj" % rank), **wl["kw"])
+    ses = binding.SceneSession(lib, obj, cam["origin"], cam["look_at"], cam["fov"], w / h, sun=cam["sun"], sun_dir=cam["sun_dir"])
+    st = ses.settings(w, h, wl["spp"], max_path=wl["max_path"])
+
+    # device buffers: this rank's cells (padded to equal size for the gather) and, on rank 0, the frame
+    if world > 1:
+        pad_floats = tiling.padded_cells(w, h, world) * 64 * 4
+        mine = torch.zeros(pad_floats, dtype=torch.float32, device=dev)
+        gathered = [torch.zeros(pad_floats, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+        frame = torch.zeros(h * w, 4, dtype=torch.float32, device=dev) if rank == 0 else None
+        plan = tiling.torch_scatter_plan(w, h, world, dev) if rank == 0 else None
+    else:
+        mine = torch.zeros(w * h * 4, dtype=torch.float32, device=dev)
+
+    stats = binding.Stats()
+    acc = dict(rays=0, trace_ms=0.0, launches=0, bytes=0, nodes=0, tris=0, shaded=0, texels=0, samples=0, kernel_ms=0.0)
+
+    def step(record):
+        ok = lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank if world > 1 else 0, world, C.c_void_p(mine.data_ptr()))
+        if ok != 1:
+            raise SystemExit("RaylibAMD_RenderDevice failed")
+        if world > 1:
+            dist.gather(mine, gathered, dst=0)               # one RCCL gather per frame
+            if rank == 0:
+                frame[plan[1]] = torch.stack(gathered).reshape(-1, 4)[plan[0]]
+        if record:
+            lib.RaylibAMD_GetLastStats(C.byref(stats))
+            acc["rays"] += stats.rays; acc["trace_ms"] += stats.traceKernelMs; acc["launches"] += stats.traceLaunches
+            acc["kernel_ms"] += stats.kernelMs
+            acc["bytes"] += binding.algorithmic_bytes(stats)
+            acc["nodes"] += stats.nodesVisited; acc["tris"] += stats.trisTested; acc["shaded"] += stats.shadedHits
+            acc["texels"] += stats.texFetches; acc["samples"] += stats.cameraSamples
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(acc["rays"]), float(acc["samples"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
+    else:
+        total_rays, total_samples = float(acc["rays"]), float(acc["samples"])
+
+    if rank == 0:
+        launches = max(1, acc["launches"])
+        avg_launch_ms = acc["trace_ms"] / launches
+        bytes_per_launch = acc["bytes"] / launches
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc)).get(args.workload)
+                if rec and world == 1:
+                    traffic = rec["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/sec (primary+secondary) + frame time, Cornell Box 1080p 64spp",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "scene_triangles": ntris, "width": w, "height": h, "spp": wl["spp"],
+                       "max_path_length": wl["max_path"], "seed": 1, "tiling": "8x8 cells round-robin over %d rank(s)" % world,
+                       "rays_per_step": total_rays / args.steps, "camera_samples_per_step": total_samples / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_trace", "avg_launch_ms": avg_launch_ms, "launches": acc["launches"],
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "rank 0's launches; algorithmic bytes = 64 B x (BVH nodes + triangle records + shading records) + 16 B x (texels + pixels)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, cam, total_rays / max(1.0, total_samples))
+        print(json.dumps(out))
+        sys.stdout.flush()
+
+    ses.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,6 +128,8 @@ class Checker:
         f("scene_destroy").argtypes = [C.c_void_p]
         f("render").argtypes = [C.c_void_p, C.POINTER(FlatCamera), C.POINTER(FlatSettings), C.c_uint64, C.c_int32,
                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        f("render_region").argtypes = [C.c_void_p, C.POINTER(FlatCamera), C.POINTER(FlatSettings), C.c_uint64, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         f("closest_hit").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]
         f("aabb_hit").argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_float, C.c_void_p]
         f("triangle_hit").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_float, C.c_void_p]
@@ -165,6 +167,13 @@ class Checker:
         self._f("render")(scene, C.byref(camera), C.byref(settings), seed, threads, _fp(out),
                           _fp(samples) if want_samples else None)
         return (out, samples) if want_samples else out
+
+    def render_region(self, scene, camera, settings, x0, y0, rw, rh, seed=1, threads=None):
+        """Pixels [x0, x0+rw) x [y0, y0+rh) of the full-size image (same pixel keys as a full render)."""
+        out = np.zeros((rh, rw, 4), np.float32)
+        threads = threads or (os.cpu_count() or 1)
+        self._f("render_region")(scene, C.byref(camera), C.byref(settings), seed, threads, x0, y0, rw, rh, _fp(out), None)
+        return out
 
     def render_native(self, scene, camera, settings):
         w, h = settings.viewportWidth, settings.viewportHeight

@@ -24,6 +24,9 @@ void*   oracle_scene_create(const FlatSceneDesc* desc, uint64_t buildSeed);
 void    oracle_scene_destroy(void* scene);
 void    oracle_render(void* scene, const FlatCamera* cam, const FlatSettings* st, uint64_t seed,
                       int32_t numThreads, float* outRGBA, float* outSamples);
+void    oracle_render_region(void* scene, const FlatCamera* cam, const FlatSettings* st, uint64_t seed,
+                             int32_t numThreads, int32_t x0, int32_t y0, int32_t rw, int32_t rh,
+                             float* outRGBA, float* outSamples);
 void    oracle_get_counters(void* scene, OracleCounters* out);   /* counters of the last oracle_render */
 void    oracle_closest_hit(void* scene, const float* rays, int32_t n, float tMin, FlatHit* out);
 void    oracle_aabb_hit(const float* boxes, const float* rays, int32_t n, float tMin, float tMax, int32_t* out);

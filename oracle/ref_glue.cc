@@ -209,8 +209,12 @@ void ref_scene_destroy(void* h)
 // the body of GenerateCell (reference renderer.cc:229-248 default mode,
 // :258-268 debug modes) around the reference's Camera::GetCameraRay and TraceScene.
 // outRGBA: H*W*4 floats (alpha 1, as Pixel(r,g,b) does). outSamples (optional): H*W*SPP*3.
-void ref_render(void* h, const FlatCamera* fc, const FlatSettings* st, uint64_t seed,
-                int32_t numThreads, float* outRGBA, float* outSamples)
+// Region form: only pixels [x0, x0+rw) x [y0, y0+rh) of the W x H image are computed;
+// outRGBA is rw*rh*4 floats, outSamples (optional) rw*rh*SPP*3.  Pixel keys stay those
+// of the full image, so a window of a large render can be checked without rendering it all.
+void ref_render_region(void* h, const FlatCamera* fc, const FlatSettings* st, uint64_t seed,
+                       int32_t numThreads, int32_t x0, int32_t y0, int32_t rw, int32_t rh,
+                       float* outRGBA, float* outSamples)
 {
 	RefScene* rs = (RefScene*)h;
 	const Camera camera = MakeCamera(fc);
@@ -221,13 +225,14 @@ void ref_render(void* h, const FlatCamera* fc, const FlatSettings* st, uint64_t 
 	const bool bDefault = (st->renderMode == RAYLIB_RENDERMODE_Default);
 	if (numThreads < 1) numThreads = 1;
 
-	std::atomic<int32_t> nextRow(0);
+	std::atomic<int32_t> nextRow(y0);
 	auto worker = [&]() {
 		for (;;) {
 			int32_t y = nextRow.fetch_add(1);
-			if (y >= H) break;
-			for (int32_t x = 0; x < W; ++x) {
+			if (y >= y0 + rh || y >= H) break;
+			for (int32_t x = x0; x < x0 + rw && x < W; ++x) {
 				const uint32_t pixelIndex = (uint32_t)(y * W + x);
+				const size_t outIndex = (size_t)(y - y0) * rw + (x - x0);
 				vec3 result;
 				if (bDefault) {
 					static thread_local RNG randomsAA(4096 * 8);
@@ -244,7 +249,7 @@ void ref_render(void* h, const FlatCamera* fc, const FlatSettings* st, uint64_t 
 						vec3 Li = TraceScene(cameraRay, &rs->scene, 0, rt);
 						accum += Li;
 						if (outSamples) {
-							float* o = outSamples + 3 * ((size_t)pixelIndex * SPP + s);
+							float* o = outSamples + 3 * (outIndex * SPP + s);
 							o[0] = Li.x; o[1] = Li.y; o[2] = Li.z;
 						}
 					}
@@ -257,7 +262,7 @@ void ref_render(void* h, const FlatCamera* fc, const FlatSettings* st, uint64_t 
 					ray cameraRay = camera.GetCameraRay(u, v);
 					result = TraceSceneDebugMode(cameraRay, &rs->scene, rt, (ERenderMode)st->renderMode);
 				}
-				float* o = outRGBA + 4 * (size_t)pixelIndex;
+				float* o = outRGBA + 4 * outIndex;
 				o[0] = result.x; o[1] = result.y; o[2] = result.z; o[3] = 1.0f;
 			}
 		}
@@ -266,6 +271,12 @@ void ref_render(void* h, const FlatCamera* fc, const FlatSettings* st, uint64_t 
 	for (int32_t i = 1; i < numThreads; ++i) threads.emplace_back(worker);
 	worker();
 	for (auto& t : threads) t.join();
+}
+
+void ref_render(void* h, const FlatCamera* fc, const FlatSettings* st, uint64_t seed,
+                int32_t numThreads, float* outRGBA, float* outSamples)
+{
+	ref_render_region(h, fc, st, seed, numThreads, 0, 0, (int32_t)st->viewportWidth, (int32_t)st->viewportHeight, outRGBA, outSamples);
 }
 
 // The reference's own entry point, untouched: Renderer::RenderScene with its

@@ -29,6 +29,7 @@
 #include "rl_math.h"
 #include "raylib_amd_rng.h"
 
+#include <algorithm>
 #include <chrono>
 #include <float.h>
 #include <stdio.h>
@@ -1075,6 +1076,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		// sample batches: bound the sample buffer to ~2 GiB
 		const size_t perSample = (size_t)numSlots * sizeof(float4);
 		uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(SPP, ((size_t)2 << 30) / perSample));
+		if (const char* e = getenv("RAYLIB_SAMPLE_BATCH")) { int v = atoi(e); if (v > 0) batch = std::min<uint32_t>((uint32_t)v, SPP); }
 		if (!Grow(R.samples, R.samplesBytes, perSample * batch)) return false;
 		if (batch < SPP && !Grow(R.accum, R.accumBytes, perSample)) return false;
 		int blocksPerCU = 0;

@@ -205,3 +205,83 @@ CONFIG_CAMERAS = {
     "breakfast": dict(origin=(0.0, 1.0, 5.0), look_at=(0.0, 1.0, -1.0), fov=60.0, sun=(20.0, 20.0, 20.0), sun_dir=(-1.0, -1.0, 0.0)),
     "sponza":    dict(origin=(10.0, 2.0, 0.0), look_at=(0.0, 3.0, 0.0), fov=60.0, sun=(20.0, 20.0, 20.0), sun_dir=(0.0, -1.0, -0.5)),
 }
+
+
+# ---------------------------------------------------------------------------------
+# Textured / cut-out test scene (exercises map_Kd, sRGB decode, alpha test inside
+# traversal, the emissive-texture path and the sky panorama)
+
+CUTOUT_MTL = """
+newmtl cutout
+Ns 10
+Kd 0.8 0.8 0.8
+Ks 0 0 0
+map_Kd leaf.png
+illum 2
+"""
+
+
+def leaf_texture(size=16):
+    """RGBA8 checkerboard: opaque green / transparent cells plus a gradient, (H, W, 4) uint8."""
+    img = np.zeros((size, size, 4), np.uint8)
+    for y in range(size):
+        for x in range(size):
+            on = ((x // 2) + (y // 2)) % 2 == 0
+            img[y, x] = (40 + 10 * x, 120 + 8 * y, 30 + 3 * (x + y), 255 if on else 0)
+    return img
+
+
+def write_png_rgba(path, img):
+    """Minimal PNG writer (zlib), so fixtures do not depend on PIL."""
+    import struct
+    import zlib
+    h, w, _ = img.shape
+    raw = b"".join(b"\x00" + img[y].astype(np.uint8).tobytes() for y in range(h))
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def texture_as_float(img_u8):
+    """byte/255 in float32, as reference render/image.h:37-43."""
+    return (img_u8.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+
+
+def cutout(path, tess=1):
+    """Cornell room with a cut-out card (alpha-tested map_Kd) in front of the boxes."""
+    objs = cornell_objects()
+    objs.append(("card", CUTOUT, [_quad((-0.6, 0.2, 0.7), (0.6, 0.2, 0.7), (0.6, 1.4, 0.7), (-0.6, 1.4, 0.7))]))
+    obj, n = write_obj(path, objs, CORNELL_MTL, tess=tess, extra_mtl=CUTOUT_MTL)
+    write_png_rgba(os.path.join(os.path.dirname(os.path.abspath(path)), "leaf.png"), leaf_texture())
+    return obj, n
+
+
+def soup(path, n_tris=10000, seed=3, extent=4.0, size=0.35):
+    """Random triangle soup (no normals, no UVs) for closest-hit / BVH-vs-brute-force tests."""
+    rng = np.random.RandomState(seed)
+    base = os.path.splitext(path)[0]
+    with open(base + ".obj", "w") as f:
+        f.write("o soup\n")
+        for i in range(n_tris):
+            c = rng.uniform(-extent, extent, 3)
+            p = (c + rng.uniform(-size, size, (3, 3))).astype(np.float32)
+            for q in p:
+                f.write("v %s %s %s\n" % (_f(q[0]), _f(q[1]), _f(q[2])))
+            f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    return base + ".obj", n_tris
+
+
+def sky_panorama(w=64, h=32):
+    """Float RGBA equirectangular test panorama (smooth gradient + a bright spot)."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.zeros((h, w, 4), np.float32)
+    img[..., 0] = 0.2 + 0.6 * xx / w
+    img[..., 1] = 0.3 + 0.5 * yy / h
+    img[..., 2] = 0.9 - 0.4 * xx / w
+    img[..., 3] = 1.0
+    img[h // 4, w // 3, :3] = (8.0, 7.0, 5.0)
+    return img

@@ -1,0 +1,116 @@
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref/libref_seeded.so).
+
+Run in the build container only (needs /root/reference to have been compiled into
+oracle/_ref by `make -C oracle ref`):   python tests/golden/gen_golden.py
+The fixtures are data -- inputs and the reference's outputs -- and travel to the
+GPU box, where /root/reference does not exist.
+"""
+import os
+import sys
+import tempfile
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import helpers  # noqa: E402
+from helpers import ffi, scenes, objflat  # noqa: E402
+
+SEED, BUILD_SEED = 1, 1
+
+
+def main():
+    ref = ffi.load_ref(True)
+    assert ref is not None and ref.lib.ref_is_seeded() == 1, "build oracle/_ref first (make -C oracle ref)"
+    orc = ffi.load_oracle()   # only for the MTL rule inside objflat (not reference-pinned; see objflat.py)
+    tmp = tempfile.mkdtemp()
+
+    # ---- image-level goldens ------------------------------------------------------
+    for name in helpers.CASES:
+        obj, c, flat = helpers.flat_for_case(name, tmp, orc)
+        scene = ref.scene_create(flat, BUILD_SEED)
+        cam = helpers.camera_for_case(c)
+        out = {"triangles": flat.triangles, "materials": flat.materials}
+        for spp in (1, 4, 16):
+            img, smp = ref.render(scene, cam, ffi.make_settings(64, 64, spp), seed=SEED, want_samples=True)
+            out["mode0_spp%d" % spp] = img
+            if spp == 4:
+                out["mode0_spp4_samples"] = smp
+        for mode in (1, 2, 4, 5):
+            out["mode%d" % mode] = ref.render(scene, cam, ffi.make_settings(64, 64, 1, mode=mode), seed=SEED)
+        # non-square, not a multiple of 8, deeper paths
+        out["mode0_40x28_spp3_len8"] = ref.render(scene, ffi.make_camera(c["origin"], c["look_at"], c["fov"], 40 / 28, c["aperture"], c["focal"], *c["shutter"]),
+                                                  ffi.make_settings(40, 28, 3, max_path=8), seed=7)
+        rays = helpers.random_rays(2048, 11, extent=1.5)
+        rays[:, 1] += 1.0
+        out["hit_rays"] = rays
+        out["hits"] = ref.closest_hit(scene, rays, 1e-4)
+        # per-material scatter records on this scene's materials
+        rng = np.random.RandomState(5)
+        rec = np.zeros((128, 16), np.float32)
+        d = rng.normal(size=(128, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        n = rng.normal(size=(128, 3)); n /= np.linalg.norm(n, axis=1, keepdims=True)
+        n[np.sum(n * d, axis=1) > 0] *= -1     # face the ray
+        rec[:, 0:3] = rng.uniform(-1, 1, (128, 3)); rec[:, 3:6] = d; rec[:, 6] = 0.0
+        rec[:, 7] = 1.0; rec[:, 8:11] = rng.uniform(-1, 1, (128, 3)); rec[:, 11:14] = n
+        rec[:, 14:16] = rng.uniform(-0.5, 1.5, (128, 2))
+        out["scatter_in"] = rec
+        for mi in range(len(flat.materials)):
+            out["scatter_mat%d" % mi] = ref.scatter(scene, mi, rec, seed=SEED)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "done", {k: v.shape for k, v in out.items() if k.startswith("mode0_spp")})
+
+    # ---- function-level known answers ------------------------------------------------
+    rng = np.random.RandomState(17)
+    kat = {}
+    n = 2000
+    boxes = np.sort(rng.uniform(-2, 2, (n, 2, 3)).astype(np.float32), axis=1).reshape(n, 6)
+    boxes[::7, 4] = boxes[::7, 1]                        # flat boxes (tMax == tMin must pass)
+    rays = helpers.random_rays(n, 18, extent=3.0)
+    rays[::5, 3] = 0.0; rays[::11, 4] = 0.0              # axis-parallel directions (inf / NaN slabs)
+    rays[::13, 1] = boxes[::13, 1]                       # origin on a slab plane
+    kat["aabb_boxes"], kat["aabb_rays"] = boxes, rays
+    kat["aabb_out"] = ref.aabb_hit(boxes, rays, 1e-4, 3.4028234663852886e38)
+    tris = np.zeros(n, ffi.TRI_DTYPE)
+    P = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32)
+    tris["v0"], tris["v1"], tris["v2"] = P[:, 0], P[:, 1], P[:, 2]
+    N = rng.normal(size=(n, 3, 3)).astype(np.float32)
+    tris["n0"], tris["n1"], tris["n2"] = N[:, 0], N[:, 1], N[:, 2]
+    tris["st"] = rng.uniform(-2, 2, (n, 6)).astype(np.float32)
+    trays = helpers.random_rays(n, 19, extent=1.0)
+    target = (P.mean(axis=1) + rng.normal(scale=0.3, size=(n, 3))).astype(np.float32)
+    dd = target - trays[:, :3]; dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    trays[:, 3:] = dd.astype(np.float32)
+    kat["tri_tris"], kat["tri_rays"] = tris, trays
+    kat["tri_out"] = ref.triangle_hit(tris, trays, 1e-4, 3.4028234663852886e38)
+    nn = rng.normal(size=(512, 3)).astype(np.float32); nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    nn[:8] = np.eye(3, dtype=np.float32)[[0, 1, 2, 0, 1, 2, 0, 1]] * np.array([1, 1, 1, -1, -1, -1, 1, 1], np.float32)[:, None]
+    vv = rng.normal(size=(512, 3)).astype(np.float32)
+    kat["onb_n"], kat["onb_v"] = nn, vv
+    kat["onb_local"], kat["onb_world"] = ref.onb(nn, vv)
+    cam = ffi.make_camera((0.3, 1.2, 4), (0, 0.9, -1), 50.0, 1.5, 0.1, 3.0, 0.0, 2.0)
+    uv = rng.uniform(0, 1, (512, 2)).astype(np.float32)
+    kat["cam_uv"] = uv
+    kat["cam_rays"] = ref.camera_rays(cam, uv, seed=3)
+    cam2 = ffi.make_camera((0, 5, 0), (0, 0, 0), 60.0, 1.0)     # looking straight down: the up-vector switch (camera.h:62-66)
+    kat["cam2_rays"] = ref.camera_rays(cam2, uv, seed=3)
+    tex = scenes.texture_as_float(scenes.leaf_texture())
+    tuv = rng.uniform(-3, 3, (1024, 2)).astype(np.float32)
+    tuv[:16] = [[0, 0], [1, 1], [0.999999, 0.5], [-0.0, 0.25], [1.0, 0.0], [0.5, 1.0], [2.0, -1.0], [-1e-8, 1e-8]] * 2
+    kat["tex_uv"] = tuv
+    kat["tex_linear"] = ref.texture_sample(tex, 0, tuv)
+    kat["tex_srgb"] = ref.texture_sample(tex, 1, tuv)
+    np.savez_compressed(os.path.join(HERE, "kat.npz"), **kat)
+
+    # ---- closest hit on a 10k-triangle soup ------------------------------------------
+    obj, _ = scenes.soup(os.path.join(tmp, "soup.obj"), 10000)
+    flat = objflat.load_obj(obj, orc)
+    scene = ref.scene_create(flat, BUILD_SEED)
+    rays = helpers.random_rays(4096, 23, extent=4.5)
+    hits = ref.closest_hit(scene, rays, 1e-4)
+    nodes, depth = ref.bvh_stats(scene)
+    np.savez_compressed(os.path.join(HERE, "soup.npz"), rays=rays, hits=hits, bvh=np.array([nodes, depth]))
+    print("soup: %d / %d rays hit; reference BVH nodes %d depth %d" % (hits["hit"].sum(), len(hits), nodes, depth))
+
+
+if __name__ == "__main__":
+    main()

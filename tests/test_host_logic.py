@@ -1,0 +1,224 @@
+"""Host-side logic of libraylib.so that needs no GPU: the C-ABI surface, OBJ/MTL
+ingestion, scene flattening, the BVH builder, image codecs, registries."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+import helpers
+from helpers import ffi, scenes
+
+INCLUDE = os.path.join(helpers.ROOT, "include")
+
+
+def declared_symbols(header):
+    txt = open(os.path.join(INCLUDE, header)).read()
+    return re.findall(r"RAYLIB_API\s+[\w\s\*]+?\b(Raylib(?:AMD)?_\w+)\s*\(", txt)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from raylib_amd import binding
+    raylib = declared_symbols("raylib.h")
+    amd = declared_symbols("raylib_amd.h")
+    assert len(raylib) == 33, raylib                       # the reference's 33 entry points (raylib/raylib.h:17-151)
+    assert sorted(raylib) == sorted(binding.RAYLIB_H_EXPORTS)
+    assert sorted(amd) == sorted(binding.RAYLIB_AMD_H_EXPORTS)
+    for name in raylib + amd:
+        assert getattr(lib, name) is not None
+
+
+def test_settings_struct_layout():
+    from raylib_amd import binding
+    assert C.sizeof(binding.RendererSettings) == 24        # reference raylib_types.h:41-57 / RaylibWrapper.cs:27-38
+    assert binding.RendererSettings.renderMode.offset == 20
+
+
+def test_render_mode_strings_and_misc(lib):
+    names = [lib.Raylib_GetRenderModeString(i) for i in range(7)]
+    assert names == [b"Default", b"Albedo", b"SurfaceNormal", b"MicrosurfaceNormal", b"Texcoord", b"Emission", b"Reflectance"]
+    assert lib.Raylib_GetRenderModeString(7) is None
+    assert lib.Raylib_IsDenoiserSupported() == 0
+    assert lib.Raylib_Denoise(None, 1, None, None, None) == 0
+    assert lib.Raylib_LoadOBJModel(b"/nonexistent/file.obj") is None
+    assert lib.Raylib_LoadImage(b"/nonexistent/file.png") is None
+
+
+def test_handle_registries(lib):
+    cam = lib.Raylib_CreateCamera()
+    assert lib.Raylib_DestroyCamera(cam) == 1 and lib.Raylib_DestroyCamera(cam) == 0
+    img = lib.Raylib_CreateImage(5, 3)
+    out = np.ones(5 * 3 * 3, np.float32)
+    lib.Raylib_DumpImageData(img, out.ctypes.data_as(C.POINTER(C.c_float)))
+    assert (out == 0).all()                                 # cleared to RGBA 0 (raylib.cc:181-186)
+    assert lib.Raylib_DestroyImage(img) == 1 and lib.Raylib_DestroyImage(img) == 0
+    sc = lib.Raylib_CreateScene()
+    lib.Raylib_FinalizeScene(sc)
+    lib.Raylib_FinalizeScene(sc)                            # idempotent
+    assert lib.Raylib_DestroyScene(sc) == 1 and lib.Raylib_DestroyScene(sc) == 0
+
+
+@pytest.mark.parametrize("name", list(helpers.CASES))
+def test_obj_ingestion_matches_oracle_side_parser(name, lib, oracle, workdir):
+    """Product OBJ/MTL loader + MTL->material rules vs the independent Python parser + oracle rule."""
+    obj, c, flat = helpers.flat_for_case(name, workdir, oracle)
+    ses = helpers.session_for_case(lib, name, workdir)
+    tris, mats = ses.export_flat()
+    assert tris.tobytes() == flat.triangles.tobytes()
+    assert mats.tobytes() == flat.materials.tobytes()
+    assert lib.RaylibAMD_SceneNumTextures(ses.scene) == len(flat.textures)
+    for i, t in enumerate(flat.textures):
+        w, h = C.c_int32(), C.c_int32()
+        lib.RaylibAMD_SceneTextureSize(ses.scene, i, C.byref(w), C.byref(h))
+        assert (h.value, w.value) == t.shape[:2]
+        got = np.zeros_like(t)
+        lib.RaylibAMD_SceneExportTexture(ses.scene, i, got.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(got, t)                       # PNG decode == byte/255 of the generator's pixels
+    ill, d = (C.c_float * 3)(), (C.c_float * 3)()
+    lib.RaylibAMD_SceneGetSun(ses.scene, ill, d)
+    sd = np.asarray(c["sun_dir"], np.float32)
+    k = np.float32(1.0) / np.sqrt(np.float32(sd[0] * sd[0] + sd[1] * sd[1]) + np.float32(sd[2] * sd[2]))
+    assert np.allclose(np.asarray(d[:]), sd * k, rtol=0, atol=1e-7)
+    ses.close()
+
+
+def test_golden_scene_matches_product_loader(lib, workdir):
+    """The flat scene stored in the fixtures (what the reference rendered) is what the product loads."""
+    for name in helpers.CASES:
+        g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
+        ses = helpers.session_for_case(lib, name, workdir)
+        tris, mats = ses.export_flat()
+        assert tris.tobytes() == g["triangles"].tobytes() and mats.tobytes() == g["materials"].tobytes()
+        ses.close()
+
+
+def test_camera_derived_state_matches_oracle(lib, oracle):
+    cam_h = lib.Raylib_CreateCamera()
+    lib.Raylib_CameraSetPosition(cam_h, 0.3, 1.2, 4.0)
+    lib.Raylib_CameraSetLookAt(cam_h, 0.0, 0.9, -1.0)
+    lib.Raylib_CameraSetPerspective(cam_h, 50.0, 1.5)
+    lib.Raylib_CameraSetLens(cam_h, 0.0, 3.0)
+    lib.Raylib_CameraSetMotion(cam_h, 0.0, 0.0)
+    out = (C.c_float * 19)()
+    lib.RaylibAMD_CameraExport(cam_h, out)
+    o = np.asarray(out[:], np.float32)
+    origin, top_left, horiz, vert = o[0:3], o[4:7], o[7:10], o[10:13]
+    cam = ffi.make_camera((0.3, 1.2, 4.0), (0.0, 0.9, -1.0), 50.0, 1.5, 0.0, 3.0)
+    uv = np.array([[0, 0], [1, 0], [0, 1], [0.25, 0.75]], np.float32)
+    rays = oracle.camera_rays(cam, uv, seed=1)
+    f = np.float32
+    for (s, t), r in zip(uv, rays):
+        d = ((top_left + f(s) * horiz).astype(np.float32) + (f(1.0) - f(t)) * vert).astype(np.float32) - origin
+        d = (d - np.zeros(3, np.float32)).astype(np.float32)
+        d = d * (f(1.0) / np.sqrt(f(f(d[0] * d[0]) + f(d[1] * d[1])) + f(d[2] * d[2])))
+        assert np.array_equal(np.asarray(d, np.float32), r[3:6])
+    # copy keeps everything
+    c2 = lib.Raylib_CreateCamera()
+    lib.Raylib_CameraCopy(cam_h, c2)
+    out2 = (C.c_float * 19)()
+    lib.RaylibAMD_CameraExport(c2, out2)
+    assert out[:] == out2[:]
+    lib.Raylib_DestroyCamera(cam_h); lib.Raylib_DestroyCamera(c2)
+
+
+def test_bvh_builder(lib, workdir):
+    from raylib_amd import binding
+    for make, kw, expect in ((scenes.cornell, dict(tess=6, displace_fraction=0.2), 36 * 36), (scenes.soup, dict(n_tris=5000), 5000)):
+        obj, n = make(os.path.join(str(workdir), "bvh_%s.obj" % make.__name__), **kw)
+        assert n == expect
+        ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+        nodes, depth, sah = C.c_uint32(), C.c_uint32(), C.c_float()
+        assert lib.RaylibAMD_SceneBVHInfo(ses.scene, C.byref(nodes), C.byref(depth), C.byref(sah)) == 1
+        assert lib.RaylibAMD_SceneNumTriangles(ses.scene) == n
+        assert n / 4 <= nodes.value <= n and depth.value <= 64
+        ses.close()
+    # empty and single-triangle scenes
+    sc = lib.Raylib_CreateScene(); lib.Raylib_FinalizeScene(sc)
+    assert lib.RaylibAMD_SceneNumTriangles(sc) == 0
+    lib.Raylib_DestroyScene(sc)
+
+
+def test_transform_rules(lib, workdir):
+    """rotate -> scale -> translate on positions, rotation only on normals; ignored after finalize
+    (reference raylib.cc:71-90, static_mesh.cc:54-78)."""
+    obj, _ = scenes.cornell(os.path.join(str(workdir), "xf.obj"))
+    h = lib.Raylib_LoadOBJModel(obj.encode())
+    lib.Raylib_TransformOBJModel(h, 1.0, 2.0, 3.0, 90.0, 0.0, 0.0, 2.0, 2.0, 2.0)
+    sc = lib.Raylib_CreateScene(); lib.Raylib_AddOBJModelToScene(sc, h); lib.Raylib_FinalizeOBJModel(h)
+    lib.Raylib_TransformOBJModel(h, 100.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0)   # ignored: locked
+    lib.Raylib_FinalizeScene(sc)
+    from raylib_amd import binding
+    tris = np.zeros(36, ffi.TRI_DTYPE)
+    lib.RaylibAMD_SceneExportTriangles(sc, tris.ctypes.data)
+    base = helpers.objflat.load_obj(obj, ffi.load_oracle()).triangles
+    # yaw 90: (x, y, z) -> (-z*?, y, x*?) with the reference matrix: x' = ch*x - sh*z, z' = sh*x + ch*z (ch ~ 0, sh = 1)
+    v = base["v0"]
+    want = np.stack([-v[:, 2], v[:, 1], v[:, 0]], axis=1) * 2.0 + np.array([1.0, 2.0, 3.0])
+    assert np.allclose(tris["v0"], want, atol=1e-5)
+    n = base["n0"]
+    assert np.allclose(tris["n0"], np.stack([-n[:, 2], n[:, 1], n[:, 0]], axis=1), atol=1e-6)
+    lib.Raylib_DestroyScene(sc); lib.Raylib_UnloadOBJModel(h)
+
+
+def test_image_codecs_roundtrip(lib, workdir):
+    rgba = np.zeros((6, 7, 4), np.float32)
+    rng = np.random.RandomState(2)
+    rgba[..., :3] = rng.randint(0, 256, (6, 7, 3)) / np.float32(255.0)
+    rgba[..., 3] = 1.0
+    ih = lib.RaylibAMD_CreateImageFromData(7, 6, rgba.ctypes.data_as(C.POINTER(C.c_float)))
+    for ftype, ext in ((0, "bmp"), (2, "png")):
+        path = os.path.join(str(workdir), "rt." + ext).encode()
+        assert lib.Raylib_WriteImageToDisk(ih, path, ftype) == 1
+        back = lib.Raylib_LoadImage(path)
+        assert back
+        got = np.zeros((6, 7, 4), np.float32)
+        lib.RaylibAMD_DumpImageRGBA(back, got.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(got, rgba)                    # row 0 stays the top row through both codecs
+        lib.Raylib_DestroyImage(back)
+    assert lib.Raylib_WriteImageToDisk(ih, b"/tmp/x.jpg", 1) == 0      # no JPEG encoder
+    assert lib.Raylib_WriteImageToDisk(ih, b"/tmp/x.png", 3) == 0      # invalid type (raylib.cc:316)
+    assert lib.Raylib_WriteImageToDisk(None, b"/tmp/x.png", 2) == 0
+    lib.Raylib_DestroyImage(ih)
+
+
+def test_postprocess_matches_oracle(lib, oracle):
+    rng = np.random.RandomState(4)
+    rgba = np.zeros((9, 11, 4), np.float32)
+    rgba[..., :3] = rng.gamma(1.0, 0.8, (9, 11, 3)).astype(np.float32)
+    rgba[0, 0, :3] = 0.0; rgba[1, 1, :3] = (9.0, 12.0, 3.0)
+    rgba[..., 3] = 1.0
+    ih = lib.RaylibAMD_CreateImageFromData(11, 9, rgba.ctypes.data_as(C.POINTER(C.c_float)))
+    lib.Raylib_PostProcess(ih)
+    got = np.zeros_like(rgba)
+    lib.RaylibAMD_DumpImageRGBA(ih, got.ctypes.data_as(C.POINTER(C.c_float)))
+    want = oracle.postprocess(rgba)
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
+    lib.Raylib_DestroyImage(ih)
+
+
+def test_cell_math(lib):
+    from raylib_amd import tiling
+    for (w, h) in ((64, 64), (40, 28), (1920, 1080), (7, 9)):
+        assert lib.RaylibAMD_NumCells(w, h) == tiling.num_cells(w, h)
+        assert lib.RaylibAMD_CellBufferFloats(w, h, 0, 1) == w * h * 4
+        for world in (2, 3, 8):
+            tot = 0
+            for r in range(world):
+                assert lib.RaylibAMD_CellBufferFloats(w, h, r, world) == tiling.local_cells(w, h, r, world) * 256
+                tot += tiling.local_cells(w, h, r, world)
+            assert tot == tiling.num_cells(w, h)
+
+
+def test_render_without_device_fails_loudly(lib, workdir, capfd):
+    """No CPU fallback: on a box without a HIP device the render entry reports failure."""
+    if lib.RaylibAMD_DeviceAvailable():
+        pytest.skip("a device is present")
+    ses = helpers.session_for_case(lib, "cornell", workdir)
+    from raylib_amd import binding
+    st = ses.settings(8, 8, 1)
+    assert lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, 0, 1, None) == 0
+    img = ses.render(8, 8, 1)
+    assert (img[..., :3] == 0).all()
+    assert "FAILED" in capfd.readouterr().err
+    assert lib.Raylib_Initialize() == 0
+    ses.close()
