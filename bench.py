@@ -48,10 +48,15 @@ def cpu_baseline(workload, cam, gpu_rays_per_sample):
     obj, _ = getattr(scenes, workload["scene"])(os.path.join(tmp, "cpu.obj"), **workload["kw"])
     flat = objflat.load_obj(obj, orc, sun_illuminance=cam["sun"], sun_direction=cam["sun_dir"])
     w, h = workload["w"], workload["h"]
-    spp = max(1, min(workload["spp"], 8 if flat.triangles.shape[0] < 1000 else 1))
+    cores = os.cpu_count() or 1
+    # bounded sample: ~10-30 s of CPU work.  Few cores: 1/8 of the samples; many cores: the whole step
+    # (thread start-up and the reference's 100 ms completion poll would otherwise dominate).
+    if flat.triangles.shape[0] < 1000:
+        spp = workload["spp"] if cores >= 32 else max(1, workload["spp"] // 8)
+    else:
+        spp = 4 if cores >= 32 else 1
     camera = ffi.make_camera(cam["origin"], cam["look_at"], cam["fov"], w / h)
     st = ffi.make_settings(w, h, spp, max_path=workload["max_path"])
-    cores = os.cpu_count() or 1
     ref = ffi.load_ref(seeded=False)
     if ref is not None:
         scene = ref.scene_create(flat, 1)
