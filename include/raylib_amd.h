@@ -64,6 +64,9 @@ RAYLIB_API int32_t RaylibAMD_DeviceAvailable(void);
  */
 RAYLIB_API int32_t RaylibAMD_RenderDevice(const RendererSettings* settings, SceneHandle scene,
 	CameraHandle camera, uint32_t cellFirst, uint32_t cellStride, void* outDevice);
+/* Same, but the result is copied to host memory (RaylibAMD_CellBufferFloats(...) floats). */
+RAYLIB_API int32_t RaylibAMD_RenderCellsHost(const RendererSettings* settings, SceneHandle scene,
+	CameraHandle camera, uint32_t cellFirst, uint32_t cellStride, float* outHost);
 RAYLIB_API uint64_t RaylibAMD_CellBufferFloats(uint32_t width, uint32_t height, uint32_t cellFirst, uint32_t cellStride);
 RAYLIB_API uint32_t RaylibAMD_NumCells(uint32_t width, uint32_t height);
 

@@ -308,6 +308,13 @@ int32_t RaylibAMD_RenderDevice(const RendererSettings* settings, SceneHandle sce
 	return RenderInternal(settings, (Scene*)scene, (Camera*)camera, cellFirst, cellStride ? cellStride : 1, outDevice, nullptr) ? 1 : 0;
 }
 
+int32_t RaylibAMD_RenderCellsHost(const RendererSettings* settings, SceneHandle scene, CameraHandle camera,
+                                  uint32_t cellFirst, uint32_t cellStride, float* outHost)
+{
+	if (!settings || settings->viewportWidth == 0 || settings->viewportHeight == 0 || !outHost) return 0;
+	return RenderInternal(settings, (Scene*)scene, (Camera*)camera, cellFirst, cellStride ? cellStride : 1, nullptr, outHost) ? 1 : 0;
+}
+
 int32_t RaylibAMD_ClosestHit(SceneHandle sh, const float* rays, int32_t n, float tMin, void* outHits)
 {
 	Scene* s = (Scene*)sh;

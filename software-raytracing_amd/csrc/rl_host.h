@@ -144,7 +144,7 @@ struct RenderRequest {
 	uint64_t seed;
 	uint32_t cellFirst, cellStride;
 	void* outDevice;        // may be null
-	float* outHostRGBA;     // may be null; W*H*4 floats (only for full-image renders)
+	float* outHostRGBA;     // may be null; receives what outDevice would (row-major image or the rank's cells)
 };
 bool DeviceAvailable();
 bool DeviceRender(Scene& scene, const RenderRequest& req, RaylibAMDStats& stats);

@@ -5,15 +5,25 @@
 //   + - * / sqrt : IEEE binary32, correctly rounded (hipcc default for HIP), and the
 //                  file is compiled with -ffp-contract=off (no FMA contraction), so
 //                  these match the x86-64 reference build bit for bit;
-//   transcendentals: see each function.
+//   sinf cosf tanf acosf asinf atan2f expf logf powf : the reference build gets these from
+//                  glibc, whose results are NOT correctly rounded (up to ~0.8 ulp), so
+//                  "a good libm" is not enough to reproduce its pixels: a last-bit
+//                  difference moves a scattered direction, and a few such samples per
+//                  million flip a hit/miss decision and change a pixel by 1e-2.  They are
+//                  therefore restated operation by operation from glibc 2.35's algorithms
+//                  (csrc/rl_glibc_math.h, verified exhaustively against the host libm by
+//                  tools/check_glibc_math.cc) and run on the device's fp64/fp32 units.
+//   fmodf(x, 1)  : exact by definition.
+// RAYLIB_OCML_MATH=1 at build time selects the platform's OCML functions instead (faster,
+// <= 1-2 ulp from the above; used to price the exact versions).
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include "rl_glibc_math.h"
 
 namespace rl { namespace rtm {
 
-__device__ __forceinline__ float rsqrt_exact_div(float x) { return 1.0f / sqrtf(x); }
-
+#if defined(RAYLIB_OCML_MATH)
 __device__ __forceinline__ float sin_(float x)  { return sinf(x); }
 __device__ __forceinline__ float cos_(float x)  { return cosf(x); }
 __device__ __forceinline__ float tan_(float x)  { return tanf(x); }
@@ -23,6 +33,17 @@ __device__ __forceinline__ float atan2_(float y, float x) { return atan2f(y, x);
 __device__ __forceinline__ float exp_(float x)  { return expf(x); }
 __device__ __forceinline__ float log_(float x)  { return logf(x); }
 __device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
-__device__ __forceinline__ float fmod1_(float x) { return fmodf(x, 1.0f); }   // exact in any correct implementation
+#else
+__device__ __forceinline__ float sin_(float x)  { return rlm::sinf_(x); }
+__device__ __forceinline__ float cos_(float x)  { return rlm::cosf_(x); }
+__device__ __forceinline__ float tan_(float x)  { return rlm::tanf_(x); }
+__device__ __forceinline__ float acos_(float x) { return rlm::acosf_(x); }
+__device__ __forceinline__ float asin_(float x) { return rlm::asinf_(x); }
+__device__ __forceinline__ float atan2_(float y, float x) { return rlm::atan2f_(y, x); }
+__device__ __forceinline__ float exp_(float x)  { return rlm::expf_(x); }
+__device__ __forceinline__ float log_(float x)  { return rlm::logf_(x); }
+__device__ __forceinline__ float pow_(float x, float y) { return rlm::powf_(x, y); }
+#endif
+__device__ __forceinline__ float fmod1_(float x) { return fmodf(x, 1.0f); }
 
 }} // namespace rl::rtm

@@ -1118,7 +1118,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 
 	unsigned long long cnt[CNT_COUNT];
 	HIP_OK(hipMemcpyAsync(cnt, R.counters, sizeof(cnt), hipMemcpyDeviceToHost, R.stream));
-	if (req.outHostRGBA && rowMajor) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, outBytes, hipMemcpyDeviceToHost, R.stream));
+	if (req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, outBytes, hipMemcpyDeviceToHost, R.stream));
 	HIP_OK(hipStreamSynchronize(R.stream));
 
 	stats.rays = cnt[CNT_RAYS]; stats.nodesVisited = cnt[CNT_NODES]; stats.trisTested = cnt[CNT_TRIS];

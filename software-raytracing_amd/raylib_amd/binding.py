@@ -84,6 +84,7 @@ _EXPORTS = {
     "RaylibAMD_GetLastStats": (None, [C.POINTER(Stats)]),
     "RaylibAMD_DeviceAvailable": (C.c_int32, []),
     "RaylibAMD_RenderDevice": (C.c_int32, [C.POINTER(RendererSettings), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "RaylibAMD_RenderCellsHost": (C.c_int32, [C.POINTER(RendererSettings), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "RaylibAMD_CellBufferFloats": (C.c_uint64, [C.c_uint32] * 4),
     "RaylibAMD_NumCells": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "RaylibAMD_ClosestHit": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]),
@@ -167,6 +168,15 @@ class SceneSession:
         lib.RaylibAMD_DumpImageRGBA(img, _fp(out))
         lib.Raylib_DestroyImage(img)
         return out
+
+    def render_cells(self, w, h, spp, rank, world, max_path=5, tmin=1e-4, mode=RENDERMODE_DEFAULT):
+        """What rank `rank` of `world` renders: its cells back to back, (n_cells*64, 4) float32."""
+        st = self.settings(w, h, spp, max_path, tmin, mode)
+        n = self.lib.RaylibAMD_CellBufferFloats(w, h, rank, world)
+        out = np.zeros(max(n, 4), np.float32)
+        if self.lib.RaylibAMD_RenderCellsHost(C.byref(st), self.scene, self.camera, rank, world, _fp(out)) != 1:
+            raise RuntimeError("RaylibAMD_RenderCellsHost failed")
+        return out[:n].reshape(-1, 4)
 
     def stats(self):
         s = Stats()

@@ -95,8 +95,10 @@ def cornell_objects(tall_material=MIRROR, short_material=WHITE):
         ("leftwall", RED, [_quad((-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1))]),
         ("rightwall", GREEN, [_quad((1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1))]),
         ("light", LIGHT, [_quad((-0.24, 1.98, -0.22), (0.23, 1.98, -0.22), (0.23, 1.98, 0.16), (-0.24, 1.98, 0.16))]),
-        ("shortbox", short_material, _box((0.33, 0.3, 0.35), (0.6, 0.6, 0.6), -17.0)),
-        ("tallbox", tall_material, _box((-0.33, 0.6, -0.3), (0.6, 1.2, 0.6), 17.0)),
+        # the boxes float 1/1024 above the floor: coplanar duplicate surfaces would make the closest hit a tie,
+        # which the reference resolves by the shape of its randomly built BVH (reference geom/bvh.cc:43,92)
+        ("shortbox", short_material, _box((0.33, 0.3 + 1.0 / 1024, 0.35), (0.6, 0.6, 0.6), -17.0)),
+        ("tallbox", tall_material, _box((-0.33, 0.6 + 1.0 / 1024, -0.3), (0.6, 1.2, 0.6), 17.0)),
     ]
 
 

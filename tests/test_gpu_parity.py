@@ -3,14 +3,15 @@ path) and is compared with (a) golden vectors produced by the REAL reference bui
 (b) the CPU oracle on the same seeded inputs, (c) size-independent properties at
 BASELINE.json's full size.
 
-Tolerances (north_star: "per-pixel L2 error < 1e-4 vs reference"):
-  * integer / index work, AOV modes without transcendentals, closest-hit t, barycentrics,
-    normals, UVs: BIT-EXACT.
-  * path-traced radiance: the image-level per-pixel L2 error
-        sqrt(mean_pixels(|rgb_gpu - rgb_ref|^2))  must be < L2_TOL = 1e-4,
-    and at least BIT_EQUAL_MIN of the pixels must be bit-identical.  The remainder is
-    libm: device transcendentals (csrc/rl_math.h) vs glibc differ in the last ulp on a
-    few percent of calls.
+Tolerance.  north_star asks for "per-pixel L2 error < 1e-4 vs reference"; this suite
+asserts the stronger thing the implementation delivers: BIT-EXACT float32 pixels, hit
+records and AOVs against the reference's own outputs (every + - * / sqrt is IEEE and
+un-contracted on both sides, and the device runs glibc's exact transcendental algorithms,
+csrc/rl_glibc_math.h).  L2_TOL = 1e-4 is kept as the stated bound and checked too.
+The one exclusion: pixels whose primary ray hits two different surfaces at exactly the
+same t (a shared edge seen by an unjittered sample).  There the REFERENCE's answer depends
+on the shape of its randomly built BVH (reference geom/bvh.cc:43,92), so no
+single value is "the reference's"; `tie_mask` finds those pixels by brute force.
 """
 import ctypes as C
 import os
@@ -23,7 +24,30 @@ from helpers import ffi, bits
 pytestmark = pytest.mark.gpu
 
 L2_TOL = 1e-4
-BIT_EQUAL_MIN = 0.90
+FLT_MAX = 3.4028234663852886e38
+
+
+def tie_mask(oracle, flat, cam, w, h):
+    """Pixels whose unjittered primary ray has two or more triangles at the minimum t."""
+    ys, xs = np.mgrid[0:h, 0:w]
+    uv = np.stack([xs.ravel() / np.float32(w), ys.ravel() / np.float32(h)], 1).astype(np.float32)
+    rays = oracle.camera_rays(cam, uv, seed=1)[:, :6]
+    tmin = np.full(len(rays), np.inf, np.float32)
+    count = np.zeros(len(rays), np.int32)
+    for tri in flat.triangles:
+        hts = oracle.triangle_hit(np.repeat(tri[None], len(rays)), rays, 1e-4, FLT_MAX)
+        t = np.where(hts["hit"] == 1, hts["t"], np.inf).astype(np.float32)
+        closer = t < tmin
+        same = (t == tmin) & np.isfinite(t)
+        count = np.where(closer, 1, count + same.astype(np.int32))
+        tmin = np.minimum(tmin, t)
+    return (count > 1).reshape(h, w)
+
+
+def assert_same_outside_ties(img, want, ties, what):
+    assert ties.mean() < 0.02, "too many tie pixels for a meaningful comparison"
+    a, b = bits(img)[~ties], bits(want)[~ties]
+    assert np.array_equal(a, b), "%s: %d of %d non-tie pixels differ (L2 %.3e)" % (what, (a != b).any(-1).sum(), len(a), l2(img, want))
 
 
 def l2(a, b):
@@ -48,35 +72,36 @@ def sessions(gpu_lib, workdir):
 
 
 @pytest.mark.parametrize("name", list(helpers.CASES))
-def test_aov_modes_bit_exact_vs_reference_goldens(name, sessions, gpu_lib):
+def test_aov_modes_bit_exact_vs_reference_goldens(name, sessions, gpu_lib, oracle, workdir):
     g = golden(name)
     ses = sessions[name]
+    obj, c, flat = helpers.flat_for_case(name, workdir, oracle)
+    ties = tie_mask(oracle, flat, ffi.make_camera(c["origin"], c["look_at"], c["fov"], c["aspect"]), 64, 64)
     for mode in (1, 2, 4, 5):
-        img = ses.render(64, 64, 1, mode=mode)
-        want = g["mode%d" % mode]
-        if mode == 1 and name == "cutout_sky":
-            # albedo of a textured surface goes through powf(c, 2.2) (render/image.h:79-83)
-            assert l2(img, want) < L2_TOL and frac_bit_equal(img, want) > BIT_EQUAL_MIN
-        else:
-            assert np.array_equal(bits(img), bits(want)), "mode %d of %s" % (mode, name)
+        assert_same_outside_ties(ses.render(64, 64, 1, mode=mode), g["mode%d" % mode], ties, "mode %d of %s" % (mode, name))
+    # mode 3 (microsurface normal) has no golden: the reference reads an uninitialised tangent frame there
+    # (renderer.cc:89-93).  Without a normal map it must equal the surface-normal AOV.
+    if name != "cutout_sky":
+        assert np.array_equal(bits(ses.render(64, 64, 1, mode=3)), bits(ses.render(64, 64, 1, mode=2)))
 
 
 @pytest.mark.parametrize("name", list(helpers.CASES))
-def test_path_tracing_vs_reference_goldens(name, sessions, gpu_lib):
+def test_path_tracing_vs_reference_goldens(name, sessions, gpu_lib, oracle, workdir):
     g = golden(name)
     ses = sessions[name]
+    obj, c, flat = helpers.flat_for_case(name, workdir, oracle)
+    ties = tie_mask(oracle, flat, ffi.make_camera(c["origin"], c["look_at"], c["fov"], c["aspect"]), 64, 64)
     for spp in (1, 4, 16):
         img = ses.render(64, 64, spp)
         want = g["mode0_spp%d" % spp]
-        assert np.isfinite(img).all()
-        assert (img[..., 3] == 1.0).all()
-        e, f = l2(img, want), frac_bit_equal(img, want)
-        assert e < L2_TOL, "%s spp %d: L2 %.3e" % (name, spp, e)
-        assert f > BIT_EQUAL_MIN, "%s spp %d: only %.3f of pixels bit-equal" % (name, spp, f)
+        assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
+        assert_same_outside_ties(img, want, ties, "%s spp %d" % (name, spp))
+        keep = ~ties
+        assert l2(img[keep], want[keep]) < L2_TOL
 
 
 @pytest.mark.parametrize("name", list(helpers.CASES))
-def test_ragged_viewport_and_deeper_paths(name, gpu_lib, workdir):
+def test_ragged_viewport_and_deeper_paths(name, gpu_lib, workdir, oracle):
     """40x28 (not a multiple of the 8x8 cell), 3 spp, maxPathLength 8, another seed."""
     from raylib_amd import binding
     obj, c = helpers.build_case(name, workdir)
@@ -87,7 +112,9 @@ def test_ragged_viewport_and_deeper_paths(name, gpu_lib, workdir):
     img = ses.render(40, 28, 3, max_path=8)
     gpu_lib.RaylibAMD_SetSeed(1)
     want = golden(name)["mode0_40x28_spp3_len8"]
-    assert l2(img, want) < L2_TOL and frac_bit_equal(img, want) > BIT_EQUAL_MIN
+    _, _, flat = helpers.flat_for_case(name, workdir, oracle)
+    ties = tie_mask(oracle, flat, ffi.make_camera(c["origin"], c["look_at"], c["fov"], 40 / 28), 40, 28)
+    assert_same_outside_ties(img, want, ties, name)
     ses.close()
 
 
@@ -99,19 +126,7 @@ def test_closest_hit_vs_reference_goldens(name, sessions, gpu_lib):
     out = np.zeros(len(rays), ffi.HIT_DTYPE)
     assert gpu_lib.RaylibAMD_ClosestHit(ses.scene, rays.ctypes.data_as(C.POINTER(C.c_float)), len(rays), 1e-4, out.ctypes.data) == 1
     want = g["hits"]
-    if name == "cutout_sky":
-        # candidates on the cut-out card run powf in the alpha test; allow the texel-threshold flips libm can cause
-        assert (out["hit"] == want["hit"]).mean() > 0.999
-        same = out["t"] == want["t"]
-        assert same.mean() > 0.999
-    else:
-        assert np.array_equal(out["hit"], want["hit"])
-        assert np.array_equal(bits(out["t"]), bits(want["t"]))
-        m = want["hit"] == 1
-        # position, normal, UV and material agree except where two different triangles tie in t (reference bvh.cc:92)
-        agree = (bits(out["p"]) == bits(want["p"])).all(-1) & (bits(out["n"]) == bits(want["n"])).all(-1) & \
-                (bits(out["paramU"]) == bits(want["paramU"])) & (out["material"] == want["material"])
-        assert agree[m].mean() > 0.995
+    assert out.tobytes() == want.tobytes()      # hit flag, t, p, n, UV, material: every bit
 
 
 def test_soup_closest_hit_10k(gpu_lib, workdir):
@@ -134,32 +149,19 @@ def test_sample_zero_is_unjittered_and_matches_per_sample_golden(sessions):
     img = sessions["cornell"].render(64, 64, 1)
     s0 = g["mode0_spp4_samples"][:, :, 0, :]
     # spp 1 image == sample 0 of the 4-spp run * (1/1): same stream key (seed, pixel, 0)
-    assert l2(img, np.concatenate([s0, np.ones((64, 64, 1), np.float32)], -1)) < L2_TOL
-
-
-def _device_buffer(nfloats):
-    import torch
-    return torch.zeros(int(nfloats), dtype=torch.float32, device="cuda:0")
+    assert np.array_equal(bits(img[..., :3]), bits(s0 * np.float32(1.0)))
 
 
 @pytest.mark.parametrize("shape", [(64, 64), (40, 28)])
 def test_tile_union_is_bit_identical_to_full_render(shape, sessions, gpu_lib):
     """Multi-GPU correctness by construction: cells rendered in strided subsets (as N ranks would)
     assemble to exactly the 1-GPU image, because the RNG is keyed by pixel."""
-    import torch
     from raylib_amd import tiling
     w, h = shape
     ses = sessions["cornell_glass_sun"]
     full = ses.render(w, h, 4)
-    st = ses.settings(w, h, 4)
     for world in (2, 3, 8):
-        bufs = []
-        for r in range(world):
-            n = gpu_lib.RaylibAMD_CellBufferFloats(w, h, r, world)
-            t = _device_buffer(max(n, 4))
-            assert gpu_lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, r, world, C.c_void_p(t.data_ptr())) == 1
-            torch.cuda.synchronize()
-            bufs.append(t.cpu().numpy()[:n].reshape(-1, 4))
+        bufs = [ses.render_cells(w, h, 4, r, world) for r in range(world)]
         img = tiling.assemble(w, h, world, bufs)
         assert np.array_equal(bits(img), bits(full)), "world %d" % world
 
@@ -254,7 +256,7 @@ def test_full_size_windows_against_oracle(full_size, oracle, workdir):
         got = img[y0:y0 + 16, x0:x0 + 16]
         assert l2(got, want) < L2_TOL, "window %d,%d L2 %.3e" % (x0, y0, l2(got, want))
         eq += (bits(got[..., :3]) == bits(want[..., :3])).all(-1).sum(); tot += 256
-    assert eq / tot > 0.5
+    assert eq == tot, "%d of %d window pixels bit-equal" % (eq, tot)
     assert stats["cameraSamples"] == 1920 * 1080 * 64 and stats["pixels"] == 1920 * 1080
 
 
@@ -282,16 +284,8 @@ def test_full_size_properties(full_size, gpu_lib):
 
 
 def test_full_size_tile_union(full_size, gpu_lib):
-    import torch
     from raylib_amd import tiling
     ses, img, _ = full_size
-    st = ses.settings(1920, 1080, 64)
     world = 8
-    bufs = []
-    for r in range(world):
-        n = gpu_lib.RaylibAMD_CellBufferFloats(1920, 1080, r, world)
-        t = _device_buffer(n)
-        assert gpu_lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, r, world, C.c_void_p(t.data_ptr())) == 1
-        torch.cuda.synchronize()
-        bufs.append(t.cpu().numpy().reshape(-1, 4))
+    bufs = [ses.render_cells(1920, 1080, 64, r, world) for r in range(world)]
     assert np.array_equal(bits(tiling.assemble(1920, 1080, world, bufs)), bits(img))

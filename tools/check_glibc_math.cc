@@ -1,0 +1,88 @@
+// Exhaustive check of csrc/rl_glibc_math.h against the host libm (glibc).
+//   g++ -O2 -mfma -ffp-contract=off -pthread tools/check_glibc_math.cc -o /tmp/check_glibc_math && /tmp/check_glibc_math [fn...]
+// For every float bit pattern (or the stated sub-domain) the restated function must return
+// the same bits as libm (NaN == NaN regardless of payload/sign).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <atomic>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../software-raytracing_amd/csrc/rl_glibc_math.h"
+
+static bool same(float a, float b) { if (a != a && b != b) return true; return rlm::asuint(a) == rlm::asuint(b); }
+
+template <typename F, typename G>
+static uint64_t sweep1(const char* name, F mine, G ref, uint32_t lo = 0, uint64_t hi = 0x100000000ull)
+{
+	const int NT = std::thread::hardware_concurrency();
+	std::atomic<uint64_t> bad(0);
+	std::atomic<uint32_t> firstBad(0);
+	std::vector<std::thread> th;
+	for (int t = 0; t < NT; ++t) th.emplace_back([&, t] {
+		uint64_t local = 0;
+		for (uint64_t i = lo + (uint64_t)t; i < hi; i += NT) {
+			float x = rlm::asfloat((uint32_t)i);
+			float a = mine(x), b = ref(x);
+			if (!same(a, b)) { if (!local) firstBad = (uint32_t)i; ++local; }
+		}
+		bad += local;
+	});
+	for (auto& x : th) x.join();
+	uint32_t fb = firstBad;
+	printf("%-22s %12llu mismatches over [%08x, %llx)", name, (unsigned long long)bad.load(), lo, (unsigned long long)hi);
+	if (bad) { float x = rlm::asfloat(fb); printf("   e.g. x=%a (0x%08x): mine %a ref %a", x, fb, mine(x), ref(x)); }
+	printf("\n");
+	fflush(stdout);
+	return bad;
+}
+
+int main(int argc, char** argv)
+{
+	auto want = [&](const char* n) { if (argc < 2) return true; for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], n)) return true; return false; };
+	uint64_t bad = 0;
+	if (want("expf")) bad += sweep1("expf", rlm::expf_, expf);
+	if (want("logf")) bad += sweep1("logf", rlm::logf_, logf);
+	if (want("sinf")) bad += sweep1("sinf", rlm::sinf_, sinf);
+	if (want("cosf")) bad += sweep1("cosf", rlm::cosf_, cosf);
+	if (want("acosf")) bad += sweep1("acosf", rlm::acosf_, acosf);
+	if (want("powf")) {
+		const float ys[] = { 5.0f, 2.2f, 1.0f / 2.2f, 0.5f, 1.3f, 3.0f, -2.0f, 0.124f };
+		for (float y : ys) {
+			char nm[64]; snprintf(nm, sizeof(nm), "powf(x, %g)", y);
+			bad += sweep1(nm, [y](float x) { return rlm::powf_(x, y); }, [y](float x) { return powf(x, y); });
+		}
+		// the Beckmann fit exponent range (material.cc:119-121): x in (0,1), y in [0.3, 1.2]
+		for (int k = 0; k < 16; ++k) {
+			float y = 0.30f + 0.06f * k + 1e-3f * k * k;
+			char nm[64]; snprintf(nm, sizeof(nm), "powf(x, %g) x in (0,2)", y);
+			bad += sweep1(nm, [y](float x) { return rlm::powf_(x, y); }, [y](float x) { return powf(x, y); }, 0, 0x40000000ull);
+		}
+	}
+	if (want("asinf")) bad += sweep1("asinf", rlm::asinf_, asinf);
+	if (want("atanf")) bad += sweep1("atanf", rlm::atanf_, atanf);
+	if (want("tanf")) bad += sweep1("tanf", rlm::tanf_, tanf);
+	if (want("atan2f")) {
+		// all x for a few y, all y for a few x, plus unit-vector pairs like the sky lookup's (renderer.cc:171)
+		const float cs[] = { 1.0f, -1.0f, 0.5f, -0.25f, 1e-3f, -3.0f, 0.70710678f, 1e-20f, 0.0f, -0.0f };
+		for (float c : cs) {
+			char nm[64]; snprintf(nm, sizeof(nm), "atan2f(y, %g)", c);
+			bad += sweep1(nm, [c](float y) { return rlm::atan2f_(y, c); }, [c](float y) { return atan2f(y, c); });
+			snprintf(nm, sizeof(nm), "atan2f(%g, x)", c);
+			bad += sweep1(nm, [c](float x) { return rlm::atan2f_(c, x); }, [c](float x) { return atan2f(c, x); });
+		}
+		uint64_t b2 = 0; uint64_t st = 88172645463325252ull;
+		for (long i = 0; i < 200000000; ++i) {
+			st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+			float a = (float)((st >> 40) * (1.0 / 16777216.0) * 2 - 1), b = (float)(((st >> 8) & 0xffffff) * (1.0 / 16777216.0) * 2 - 1);
+			if (!same(rlm::atan2f_(a, b), atan2f(a, b))) ++b2;
+		}
+		printf("atan2f random pairs in [-1,1]^2: %llu mismatches of 200000000\n", (unsigned long long)b2);
+		bad += b2;
+	}
+	printf(bad ? "FAILED\n" : "ALL BIT-EXACT\n");
+	return bad ? 1 : 0;
+}
