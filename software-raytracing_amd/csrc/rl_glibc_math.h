@@ -218,23 +218,35 @@ RLM_FN float powf_(float x, float y)
 
 // ---------------------------------------------------------------------------------------
 // sinf / cosf  (glibc sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h; non-TOINT, FMA)
-struct SinCosTab { double sign[4]; double hpi_inv, hpi, c0, c1, s1, c2, s2, c3, s3, c4; };
+// __sincosf_table[0]; table [1] is the same with the cosine coefficients negated, which in
+// round-to-nearest is exactly "negate the cosine-branch result" (negation commutes with fma and
+// with the final rounding), so one set of constants serves both.
+#define RLM_SC_C0 0x1p+0
+#define RLM_SC_C1 -0x1.ffffffd0c621cp-2
+#define RLM_SC_S1 -0x1.555545995a603p-3
+#define RLM_SC_C2 0x1.55553e1068f19p-5
+#define RLM_SC_S2 0x1.1107605230bc4p-7
+#define RLM_SC_C3 -0x1.6c087e89a359dp-10
+#define RLM_SC_S3 -0x1.994eb3774cf24p-13
+#define RLM_SC_C4 0x1.99343027bf8c3p-16
 
-RLM_FN float sincosf_poly(double x, double x2, const SinCosTab& p, int n)
+// negcos: use __sincosf_table[1] (chosen by the caller when quadrant & 2)
+RLM_FN float sincosf_poly(double x, double x2, bool negcos, int n)
 {
 	if ((n & 1) == 0) {
 		double x3 = x * x2;
-		double s1 = fma_(x2, p.s3, p.s2);
+		double s1 = fma_(x2, RLM_SC_S3, RLM_SC_S2);
 		double x7 = x3 * x2;
-		double s = fma_(x3, p.s1, x);
+		double s = fma_(x3, RLM_SC_S1, x);
 		return (float)fma_(x7, s1, s);
 	} else {
 		double x4 = x2 * x2;
-		double c2 = fma_(x2, p.c4, p.c3);
-		double c1 = fma_(x2, p.c1, p.c0);
+		double c2 = fma_(x2, RLM_SC_C4, RLM_SC_C3);
+		double c1 = fma_(x2, RLM_SC_C1, RLM_SC_C0);
 		double x6 = x4 * x2;
-		double c = fma_(x4, p.c2, c1);
-		return (float)fma_(x6, c2, c);
+		double c = fma_(x4, RLM_SC_C2, c1);
+		float r = (float)fma_(x6, c2, c);
+		return negcos ? -r : r;
 	}
 }
 
@@ -261,34 +273,31 @@ RLM_FN double sincosf_reduce_large(uint32_t xi, int* np)
 	return x * 0x1.921FB54442D18p-62;
 }
 
+RLM_FN double sincosf_sign(int q) { q &= 3; return (q == 1 || q == 2) ? -1.0 : 1.0; }   // sign[] = {1,-1,-1,1}
+
 template <int COS>
 RLM_FN float sincosf_(float y)
 {
-	const SinCosTab P0 = { { 1.0, -1.0, -1.0, 1.0 }, 0x1.45f306dc9c883p+23, 0x1.921fb54442d18p+0,
-		0x1p+0, -0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3, 0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7,
-		-0x1.6c087e89a359dp-10, -0x1.994eb3774cf24p-13, 0x1.99343027bf8c3p-16 };
-	const SinCosTab P1 = { { 1.0, -1.0, -1.0, 1.0 }, 0x1.45f306dc9c883p+23, 0x1.921fb54442d18p+0,
-		-0x1p+0, 0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3, -0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7,
-		0x1.6c087e89a359dp-10, -0x1.994eb3774cf24p-13, -0x1.99343027bf8c3p-16 };
+	const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p+0;
 	double x = (double)y;
 	const uint32_t top = (asuint(y) >> 20) & 0x7ff;
 	int n;
 	if (top < ((asuint(0x1.921FB6p-1f) >> 20) & 0x7ff)) {
 		double x2 = x * x;
 		if (top < ((asuint(0x1p-12f) >> 20) & 0x7ff)) return COS ? 1.0f : y;
-		return sincosf_poly(x, x2, P0, COS);
+		return sincosf_poly(x, x2, false, COS);
 	} else if (top < ((asuint(120.0f) >> 20) & 0x7ff)) {
-		double r = x * P0.hpi_inv;
+		double r = x * hpi_inv;
 		n = ((int32_t)r + 0x800000) >> 24;
-		x = fma_(-(double)n, P0.hpi, x);
-		double s = P0.sign[n & 3];
-		return sincosf_poly(x * s, x * x, (n & 2) ? P1 : P0, COS ? (n ^ 1) : n);
+		x = fma_(-(double)n, hpi, x);
+		double s = sincosf_sign(n);
+		return sincosf_poly(x * s, x * x, (n & 2) != 0, COS ? (n ^ 1) : n);
 	} else if (top < 0x7f8) {
 		uint32_t xi = asuint(y);
 		int sign = xi >> 31;
 		x = sincosf_reduce_large(xi, &n);
-		double s = P0.sign[(n + sign) & 3];
-		return sincosf_poly(x * s, x * x, ((n + sign) & 2) ? P1 : P0, COS ? (n ^ 1) : n);
+		double s = sincosf_sign(n + sign);
+		return sincosf_poly(x * s, x * x, ((n + sign) & 2) != 0, COS ? (n ^ 1) : n);
 	}
 	return asfloat(0x7fc00000u);
 }

@@ -39,6 +39,9 @@
 namespace rl {
 
 #define RL_BLOCK 256
+#ifndef RL_JOB_CHUNK
+#define RL_JOB_CHUNK 256   /* jobs a wave takes per global atomic: 4 samples of one 8x8 cell */
+#endif
 
 // ---------------------------------------------------------------------------
 // device float3 (reference core/vec3.h conventions; see rl_host.h f3)
@@ -158,7 +161,7 @@ __device__ __forceinline__ Shade LoadShade(const DSceneView& S, int i)
 }
 
 // MicrofacetMaterial::AlphaTest for a candidate (reference render/material.cc:397-404 via geom/triangle.cc:48-54)
-__device__ __noinline__ bool AlphaTestCandidate(const DSceneView& S, int tri, float a, float b, Counters& c)
+__device__ __forceinline__ bool AlphaTestCandidate(const DSceneView& S, int tri, float a, float b, Counters& c)
 {
 	Shade sh = LoadShade(S, tri);
 	c.shaded++;
@@ -629,8 +632,11 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 // ---------------------------------------------------------------------------
 // The megakernel.  samples: [sampleCount][numLocalCells*64] float4.
 // pathStack: [maxPathLength][8][stackStride] floats (refl.xyz, sp, pdf, E.xyz).
+#ifndef RL_TRACE_MIN_WAVES
+#define RL_TRACE_MIN_WAVES 1
+#endif
 template <int STACK>
-__global__ void __launch_bounds__(RL_BLOCK)
+__global__ void __launch_bounds__(RL_BLOCK, RL_TRACE_MIN_WAVES)
 k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
         float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
@@ -648,22 +654,32 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	bool active = false;
 	bool exhausted = false;
 
+	// Wave-local job range: the wave takes RL_JOB_CHUNK consecutive jobs from the global counter
+	// with ONE atomic and deals them to its lanes itself.  (A returning atomic on one address
+	// saturates near 88 dequeues/us chip-wide -- MI355X_MICROARCH.md "dequeue" -- and one atomic
+	// per wave and bounce was exactly that rate: the kernel ran at the atomic's speed.)
+	uint32_t chunkNext = 0, chunkEnd = 0;
+	bool globalDone = false;
+
 	for (;;) {
-		// ---- refill idle lanes: wave64 ballot + prefix rank, one atomic per wave ----
+		// ---- refill idle lanes: wave64 ballot + prefix rank ----
 		const bool need = !active && !exhausted;
 		const unsigned long long mask = __ballot(need);
 		if (mask != 0ull) {
-			const uint32_t n = (uint32_t)__popcll(mask);
-			const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-			uint32_t base = 0;
-			if (lane == leader) base = atomicAdd(jobCounter, n);
-			base = __shfl(base, (int)leader);
+			if (chunkNext >= chunkEnd && !globalDone) {
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(jobCounter, (unsigned int)RL_JOB_CHUNK);
+				base = __shfl(base, 0);
+				if (base >= P.numJobs) { globalDone = true; }
+				else { chunkNext = base; chunkEnd = min(base + (uint32_t)RL_JOB_CHUNK, P.numJobs); }
+			}
+			const uint32_t avail = chunkEnd - chunkNext;
 			if (need) {
 				const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-				const uint32_t job = base + rank;
-				if (job >= P.numJobs) {
-					exhausted = true;
+				if (rank >= avail) {
+					if (globalDone) exhausted = true;   // else: served on a later trip from the next chunk
 				} else {
+					const uint32_t job = chunkNext + rank;
 					const JobPixel j = DecodeJob(P, job);
 					if (j.valid) {
 						// GenerateCell body, reference render/renderer.cc:232-239
@@ -684,6 +700,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 					}
 				}
 			}
+			chunkNext += min((uint32_t)__popcll(mask), avail);
 		}
 		if (__ballot(active) == 0ull) {
 			if (__ballot(!exhausted) == 0ull) break;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(HERE), "libraylib.so")
+LIB_PATH = os.environ.get("RAYLIB_LIB") or os.path.join(os.path.dirname(HERE), "libraylib.so")
 
 RENDERMODE_DEFAULT, RENDERMODE_ALBEDO, RENDERMODE_SURFACE_NORMAL, RENDERMODE_MICROSURFACE_NORMAL, \
     RENDERMODE_TEXCOORD, RENDERMODE_EMISSION, RENDERMODE_REFLECTANCE = range(7)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# PMC passes for the dominant kernel (k_trace).  Separate passes: FETCH_SIZE takes 3 of the 4 TCC
+# slots and WRITE_SIZE 2 (MI355X_MICROARCH.md, rocprofv3 PMC slots).  No tracing domains are combined
+# with --pmc.  Usage: tools/pmc_profile.sh <workload> <outdir>
+WL=${1:-cornell_1080p_64spp}
+OUT=${2:-/root/repo/gpurun_out/pmc_$WL}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $WL > $OUT/$name.log 2>&1; }
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR
+run grbm GRBM_GUI_ACTIVE
+find $OUT -name "*counter_collection.csv" | head
