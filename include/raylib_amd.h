@@ -39,6 +39,7 @@ typedef struct RaylibAMDStats {
 	uint32_t numNodes;        /* BVH nodes of the scene */
 	uint32_t numTriangles;
 	uint32_t bvhDepth;
+	uint64_t waveTrips;       /* bounce-loop trips summed over waves: rays / (64 * waveTrips) = share of lane slots that traced a ray */
 } RaylibAMDStats;
 
 /* Seed of the per-(pixel, sample) streams of include/raylib_amd_rng.h. */

@@ -93,7 +93,7 @@ struct DSceneView {
 };
 
 // Counters written by the kernels (one 64-bit atomic per wave and counter at exit).
-enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SHADED, CNT_TEXELS, CNT_SAMPLES, CNT_COUNT };
+enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SHADED, CNT_TEXELS, CNT_SAMPLES, CNT_TRIPS, CNT_COUNT };
 
 struct DRenderParams {
 	uint32_t width, height;
@@ -109,6 +109,7 @@ struct DRenderParams {
 	uint32_t numJobs;          // numLocalCells * sampleCount * 64
 	uint32_t stackStride;      // threads in the grid (path-stack column count)
 	uint32_t rowMajorOutput;   // 1: out[y*W+x]; 0: out[localCell*64 + p]
+	uint32_t jobChunk;         // jobs a wave takes from the global counter per atomic
 	DCamera camera;
 };
 

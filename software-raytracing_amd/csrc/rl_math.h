@@ -34,15 +34,22 @@ __device__ __forceinline__ float exp_(float x)  { return expf(x); }
 __device__ __forceinline__ float log_(float x)  { return logf(x); }
 __device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
 #else
-__device__ __forceinline__ float sin_(float x)  { return rlm::sinf_(x); }
-__device__ __forceinline__ float cos_(float x)  { return rlm::cosf_(x); }
-__device__ __forceinline__ float tan_(float x)  { return rlm::tanf_(x); }
-__device__ __forceinline__ float acos_(float x) { return rlm::acosf_(x); }
-__device__ __forceinline__ float asin_(float x) { return rlm::asinf_(x); }
-__device__ __forceinline__ float atan2_(float y, float x) { return rlm::atan2f_(y, x); }
-__device__ __forceinline__ float exp_(float x)  { return rlm::expf_(x); }
-__device__ __forceinline__ float log_(float x)  { return rlm::logf_(x); }
-__device__ __forceinline__ float pow_(float x, float y) { return rlm::powf_(x, y); }
+// Real calls, not inlined: the megakernel evaluates ~40 transcendentals per bounce at ~20 call sites;
+// inlined, k_trace was 72 KB of code against a 64 KB instruction cache shared by two CUs.
+#ifndef RL_MATH_INLINE
+#define RL_MATH_CALL __device__ __noinline__
+#else
+#define RL_MATH_CALL __device__ __forceinline__
+#endif
+RL_MATH_CALL float sin_(float x)  { return rlm::sinf_(x); }
+RL_MATH_CALL float cos_(float x)  { return rlm::cosf_(x); }
+RL_MATH_CALL float tan_(float x)  { return rlm::tanf_(x); }
+RL_MATH_CALL float acos_(float x) { return rlm::acosf_(x); }
+RL_MATH_CALL float asin_(float x) { return rlm::asinf_(x); }
+RL_MATH_CALL float atan2_(float y, float x) { return rlm::atan2f_(y, x); }
+RL_MATH_CALL float exp_(float x)  { return rlm::expf_(x); }
+RL_MATH_CALL float log_(float x)  { return rlm::logf_(x); }
+RL_MATH_CALL float pow_(float x, float y) { return rlm::powf_(x, y); }
 #endif
 __device__ __forceinline__ float fmod1_(float x) { return fmodf(x, 1.0f); }
 

@@ -39,8 +39,8 @@
 namespace rl {
 
 #define RL_BLOCK 256
-#ifndef RL_JOB_CHUNK
-#define RL_JOB_CHUNK 256   /* jobs a wave takes per global atomic: 4 samples of one 8x8 cell */
+#ifndef RL_REFILL_ROUNDS
+#define RL_REFILL_ROUNDS 4
 #endif
 
 // ---------------------------------------------------------------------------
@@ -70,7 +70,7 @@ __device__ __forceinline__ bool isZero(V3 a) { return a.x == 0.0f && a.y == 0.0f
 
 #define RL_PI 3.14159265359f   /* BRDF::PI, reference render/brdf.h:8 */
 
-struct Counters { uint32_t rays, nodes, tris, shaded, texels, samples; };
+struct Counters { uint32_t rays, nodes, tris, shaded, texels, samples, trips; };
 
 // ---------------------------------------------------------------------------
 // RNG (include/raylib_amd_rng.h); draws in the reference's program order.
@@ -99,19 +99,25 @@ __device__ __forceinline__ V3 RandomInUnitDisk(Rng& g)
 
 // ---------------------------------------------------------------------------
 // Texture2D::Sample (reference render/texture.cc:30-53, render/image.h:79-83)
-__device__ __forceinline__ float4 TexSample(const DSceneView& S, int tex, bool srgb, float u, float v, Counters& c)
+// Out of line (textured scenes only) and fed plain pointers, so that no caller-side struct has its
+// address taken (that would push it to scratch).
+__device__ __noinline__ float4 TexFetch(const DTexture* textures, const float* texels, int tex, bool srgb, float u, float v)
 {
-	const DTexture T = S.textures[tex];
+	const DTexture T = textures[tex];
 	u = rtm::fmod1_(u); if (u < 0.0f) u += 1.0f;
 	v = rtm::fmod1_(v); if (v < 0.0f) v += 1.0f; v = 1.0f - v;
 	if (isnan(u) || isinf(u)) u = 0.0f;
 	if (isnan(v) || isinf(v)) v = 0.0f;
 	int x = (int)((float)(uint32_t)(T.width - 1) * u);
 	int y = (int)((float)(uint32_t)(T.height - 1) * v);
-	float4 px = ((const float4*)S.texels)[T.offset + (uint32_t)(y * T.width + x)];
-	c.texels++;
+	float4 px = ((const float4*)texels)[T.offset + (uint32_t)(y * T.width + x)];
 	if (srgb) { px.x = rtm::pow_(px.x, 2.2f); px.y = rtm::pow_(px.y, 2.2f); px.z = rtm::pow_(px.z, 2.2f); px.w = rtm::pow_(px.w, 2.2f); }
 	return px;
+}
+__device__ __forceinline__ float4 TexSample(const DSceneView& S, int tex, bool srgb, float u, float v, Counters& c)
+{
+	c.texels++;
+	return TexFetch(S.textures, S.texels, tex, srgb, u, v);
 }
 
 struct Mat {   // DMaterial in registers
@@ -160,17 +166,27 @@ __device__ __forceinline__ Shade LoadShade(const DSceneView& S, int i)
 	return s;
 }
 
-// MicrofacetMaterial::AlphaTest for a candidate (reference render/material.cc:397-404 via geom/triangle.cc:48-54)
+// MicrofacetMaterial::AlphaTest for a candidate (reference render/material.cc:397-404 via geom/triangle.cc:48-54).
+// Returns bit 0 = passes, bit 1 = a texel was fetched.  Out of line: only leaves flagged as textured reach it.
+__device__ __noinline__ int AlphaTestCandidateNI(const DTriShade* shade, const DMaterial* materials, const DTexture* textures,
+                                                 const float* texels, int tri, float a, float b)
+{
+	const float4* p = (const float4*)(shade + tri);
+	const float4 q2 = p[2], q3 = p[3];
+	const float s0 = q2.y, t0 = q2.z, s1 = q2.w, t1 = q3.x, s2 = q3.y, t2 = q3.z;
+	const DMaterial* M = materials + __float_as_int(q3.w);
+	if (M->type != MAT_MICROFACET || M->tex[0] < 0) return 1;
+	float U = (1 - a - b) * s0 + a * s1 + b * s2;
+	float V = (1 - a - b) * t0 + a * t1 + b * t2;
+	float4 px = TexFetch(textures, texels, M->tex[0], true, U, V);
+	return (px.w >= 0.5f ? 1 : 0) | 2;
+}
 __device__ __forceinline__ bool AlphaTestCandidate(const DSceneView& S, int tri, float a, float b, Counters& c)
 {
-	Shade sh = LoadShade(S, tri);
+	const int r = AlphaTestCandidateNI(S.shade, S.materials, S.textures, S.texels, tri, a, b);
 	c.shaded++;
-	const DMaterial* M = S.materials + sh.material;
-	if (M->type != MAT_MICROFACET || M->tex[0] < 0) return true;
-	float U = (1 - a - b) * sh.s0 + a * sh.s1 + b * sh.s2;
-	float V = (1 - a - b) * sh.t0 + a * sh.t1 + b * sh.t2;
-	float4 px = TexSample(S, M->tex[0], true, U, V, c);
-	return px.w >= 0.5f;
+	if (r & 2) c.texels++;
+	return (r & 1) != 0;
 }
 
 // Slab test of one child box against [tMin, tMax] (reference geom/aabb.h:39-54:
@@ -188,6 +204,22 @@ __device__ __forceinline__ bool Slab(float mnx, float mny, float mnz, float mxx,
 	tn = fmaxf(tn, c0); tf = fminf(tf, c1);
 	tNear = tn;
 	return !(tf * 1.0000004f < tn);
+}
+
+// First traversal step only: true when the ray misses both child boxes of the root node.
+__device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float tMin)
+{
+	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+	const float4* np = (const float4*)(S.nodes);
+	const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+	const int4 k = ((const int4*)np)[3];
+	float tl, tr;
+	bool hl = Slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, nx, ny, nz, tMin, FLT_MAX, tl);
+	bool hr = Slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, nx, ny, nz, tMin, FLT_MAX, tr);
+	hl = hl && (k.x != DNODE_EMPTY);
+	hr = hr && (k.y != DNODE_EMPTY);
+	return !(hl || hr);
 }
 
 // stk: this lane's column of the LDS stack; entry k at stk[k * RL_BLOCK].
@@ -282,7 +314,7 @@ __device__ __forceinline__ V3 WorldToLocal(const Surf& s, V3 v) { return v3(dot(
 // ---- microfacet BRDF pieces (reference render/brdf.h, render/material.cc:16-190) ----
 __device__ __forceinline__ float Clampf(float val, float lo, float hi) { return fmaxf(lo, fminf(hi, val)); }
 
-__device__ float ErfInv(float x)
+__device__ __noinline__ float ErfInv(float x)
 {
 	float w, p;
 	x = Clampf(x, -.99999f, .99999f);
@@ -312,7 +344,7 @@ __device__ float ErfInv(float x)
 	}
 	return p * x;
 }
-__device__ float Erf(float x)
+__device__ __noinline__ float Erf(float x)
 {
 	const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f;
 	const float p = 0.3275911f;
@@ -646,7 +678,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t numSlots = P.numLocalCells * 64u;
 
-	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = 0;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
 	Rng g; g.s.state = 0;
 	V3 o = v3s(0.0f), d = v3s(0.0f);
 	int depth = 0;
@@ -654,7 +686,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	bool active = false;
 	bool exhausted = false;
 
-	// Wave-local job range: the wave takes RL_JOB_CHUNK consecutive jobs from the global counter
+	// Wave-local job range: the wave takes P.jobChunk (64..1024) consecutive jobs from the global counter
 	// with ONE atomic and deals them to its lanes itself.  (A returning atomic on one address
 	// saturates near 88 dequeues/us chip-wide -- MI355X_MICROARCH.md "dequeue" -- and one atomic
 	// per wave and bounce was exactly that rate: the kernel ran at the atomic's speed.)
@@ -663,21 +695,26 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 
 	for (;;) {
 		// ---- refill idle lanes: wave64 ballot + prefix rank ----
-		const bool need = !active && !exhausted;
-		const unsigned long long mask = __ballot(need);
-		if (mask != 0ull) {
+		// Up to RL_REFILL_ROUNDS rounds: a fresh camera ray that misses both boxes of the root node can
+		// only run the (sun-less) miss shader, so it is finished here and its lane takes another job at
+		// once instead of occupying a lane slot through a whole bounce trip (in a 16:9 Cornell frame
+		// more than half of the camera samples never touch the scene).
+		for (int round = 0; round < RL_REFILL_ROUNDS; ++round) {
+			const bool need = !active && !exhausted;
+			const unsigned long long mask = __ballot(need);
+			if (mask == 0ull) break;
 			if (chunkNext >= chunkEnd && !globalDone) {
 				uint32_t base = 0;
-				if (lane == 0) base = atomicAdd(jobCounter, (unsigned int)RL_JOB_CHUNK);
+				if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
 				base = __shfl(base, 0);
 				if (base >= P.numJobs) { globalDone = true; }
-				else { chunkNext = base; chunkEnd = min(base + (uint32_t)RL_JOB_CHUNK, P.numJobs); }
+				else { chunkNext = base; chunkEnd = min(base + P.jobChunk, P.numJobs); }
 			}
 			const uint32_t avail = chunkEnd - chunkNext;
 			if (need) {
 				const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 				if (rank >= avail) {
-					if (globalDone) exhausted = true;   // else: served on a later trip from the next chunk
+					if (globalDone) exhausted = true;   // else: served in a later round / trip from the next chunk
 				} else {
 					const uint32_t job = chunkNext + rank;
 					const JobPixel j = DecodeJob(P, job);
@@ -697,6 +734,12 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 						outIndex = j.sample * numSlots + j.slot;
 						active = true;
 						c.samples++;
+						if (!S.hasSun && P.maxPathLength > 0 && RootMiss(S, o, d, P.rayTMin)) {
+							c.rays++; c.nodes++;   // the closest-hit query this replaces fetches the root node and stops
+							const V3 L = MissShader<STACK>(S, R, o, d, P.rayTMin, stk, c);
+							samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+							active = false;
+						}
 					}
 				}
 			}
@@ -708,6 +751,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 		}
 
 		// ---- one bounce for every active lane (TraceScene, reference render/renderer.cc:114-208) ----
+		if (lane == 0) c.trips++;
 		if (active) {
 			bool done = false;
 			V3 L = v3s(0.0f);
@@ -732,6 +776,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 						st[5 * (size_t)P.stackStride] = E.x; st[6 * (size_t)P.stackStride] = E.y; st[7 * (size_t)P.stackStride] = E.z;
 						o = s.p; d = outD;
 						depth++;
+						if (depth >= P.maxPathLength) done = true;   // the next TraceScene returns 0 at once (renderer.cc:120-123); L stays 0
 					} else {
 						L = v3s(0.0f) + E;                        // radiance(0) += Emitted, renderer.cc:137,151
 						done = true;
@@ -760,7 +805,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	}
 
 	// ---- counters: wave reduction, one atomic per wave and counter ----
-	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples };
+	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples, c.trips };
 	for (int k = 0; k < CNT_COUNT; ++k) {
 		unsigned long long v = vals[k];
 		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -810,7 +855,7 @@ k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsig
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t numSlots = P.numLocalCells * 64u;
 	const uint32_t slot = blockIdx.x * RL_BLOCK + threadIdx.x;
-	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = 0;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
 	bool valid = false;
 	uint32_t x = 0, y = 0;
 	if (slot < numSlots) {
@@ -870,7 +915,7 @@ k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsig
 		else out[slot] = valid ? px : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	}
 	const uint32_t lane = threadIdx.x & 63u;
-	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples };
+	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples, c.trips };
 	for (int k = 0; k < CNT_COUNT; ++k) {
 		unsigned long long v = vals[k];
 		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -888,7 +933,7 @@ k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float t
 	int* stk = s_stack + threadIdx.x;
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;
-	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = 0;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
 	const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
 	HitRec h;
 	DHitOut r; memset(&r, 0, sizeof(r)); r.material = -1;
@@ -1110,6 +1155,12 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 			uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)R.numCUs * blocksPerCU, (jobs64 + RL_BLOCK - 1) / RL_BLOCK);
 			if (blocks < 1) blocks = 1;
 			P.stackStride = blocks * RL_BLOCK;
+			{   // jobs per global atomic: ~1/8 of a wave's share, a multiple of 64 (one cell at one sample), 64..1024
+				const uint64_t waves = (uint64_t)blocks * (RL_BLOCK / 64);
+				uint64_t chunk = (jobs64 / (waves * 8)) & ~63ull;
+				if (const char* e = getenv("RAYLIB_JOB_CHUNK")) chunk = (uint64_t)atoi(e);
+				P.jobChunk = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, chunk));
+			}
 			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
 			HIP_OK(hipMemsetAsync(R.jobCounter, 0, sizeof(unsigned int), R.stream));
 			HIP_OK(hipEventRecord(R.ev[2], R.stream));
@@ -1140,6 +1191,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 
 	stats.rays = cnt[CNT_RAYS]; stats.nodesVisited = cnt[CNT_NODES]; stats.trisTested = cnt[CNT_TRIS];
 	stats.shadedHits = cnt[CNT_SHADED]; stats.texFetches = cnt[CNT_TEXELS]; stats.cameraSamples = cnt[CNT_SAMPLES];
+	stats.waveTrips = cnt[CNT_TRIPS];
 	uint64_t px = 0;
 	for (uint32_t k = 0; k < numLocalCells; ++k) {
 		const uint32_t cell = req.cellFirst + k * stride, cx = cell % cellsX, cy = cell / cellsX;

@@ -27,7 +27,8 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64),
                 ("shadedHits", C.c_uint64), ("texFetches", C.c_uint64), ("cameraSamples", C.c_uint64),
                 ("pixels", C.c_uint64), ("kernelMs", C.c_double), ("traceKernelMs", C.c_double), ("wallMs", C.c_double),
-                ("traceLaunches", C.c_uint32), ("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("bvhDepth", C.c_uint32)]
+                ("traceLaunches", C.c_uint32), ("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("bvhDepth", C.c_uint32),
+                ("waveTrips", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

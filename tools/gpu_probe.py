@@ -37,6 +37,7 @@ ses2 = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, W / H)
 for spp in (4, 64):
     t = time.time(); img = ses2.render(W, H, spp); dt = time.time() - t
     s = ses2.stats()
+    print("   lane slots tracing: %.3f  shading: %.3f" % (s.rays / (64.0 * s.waveTrips), s.shadedHits / (64.0 * s.waveTrips)))
     print("1080p spp", spp, "wall %.3f s kernel %.1f ms trace %.1f ms rays %d  Mrays/s %.1f mean %.5f" % (
         dt, s.kernelMs, s.traceKernelMs, s.rays, s.rays / s.traceKernelMs / 1e3, img[..., :3].mean()))
     print("   ", s.as_dict())
