@@ -275,6 +275,9 @@ RLM_FN double sincosf_reduce_large(uint32_t xi, int* np)
 
 RLM_FN double sincosf_sign(int q) { q &= 3; return (q == 1 || q == 2) ? -1.0 : 1.0; }   // sign[] = {1,-1,-1,1}
 
+// |y| < 120 (the only range the renderer produces): one path for both glibc branches.  For |y| < pi/4
+// glibc skips the reduction; running it anyway yields n = 0, x - 0*hpi = x and sign 1, i.e. the same
+// operands, so the results are identical and lanes on either side of pi/4 do not diverge.
 template <int COS>
 RLM_FN float sincosf_(float y)
 {
@@ -282,11 +285,8 @@ RLM_FN float sincosf_(float y)
 	double x = (double)y;
 	const uint32_t top = (asuint(y) >> 20) & 0x7ff;
 	int n;
-	if (top < ((asuint(0x1.921FB6p-1f) >> 20) & 0x7ff)) {
-		double x2 = x * x;
+	if (top < ((asuint(120.0f) >> 20) & 0x7ff)) {
 		if (top < ((asuint(0x1p-12f) >> 20) & 0x7ff)) return COS ? 1.0f : y;
-		return sincosf_poly(x, x2, false, COS);
-	} else if (top < ((asuint(120.0f) >> 20) & 0x7ff)) {
 		double r = x * hpi_inv;
 		n = ((int32_t)r + 0x800000) >> 24;
 		x = fma_(-(double)n, hpi, x);
@@ -304,49 +304,62 @@ RLM_FN float sincosf_(float y)
 RLM_FN float sinf_(float x) { return sincosf_<0>(x); }
 RLM_FN float cosf_(float x) { return sincosf_<1>(x); }
 
+// sinf(y) and cosf(y) together: one reduction, both polynomials (each identical to the separate calls).
+RLM_FN void sincosf_both(float y, float* outSin, float* outCos)
+{
+	const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p+0;
+	const uint32_t top = (asuint(y) >> 20) & 0x7ff;
+	if (top < ((asuint(120.0f) >> 20) & 0x7ff) && top >= ((asuint(0x1p-12f) >> 20) & 0x7ff)) {
+		double x = (double)y;
+		double r = x * hpi_inv;
+		int n = ((int32_t)r + 0x800000) >> 24;
+		x = fma_(-(double)n, hpi, x);
+		const double xs = x * sincosf_sign(n), x2 = x * x;
+		const bool neg = (n & 2) != 0;
+		*outSin = sincosf_poly(xs, x2, neg, n);
+		*outCos = sincosf_poly(xs, x2, neg, n ^ 1);
+		return;
+	}
+	*outSin = sincosf_<0>(y);
+	*outCos = sincosf_<1>(y);
+}
+
 // ---------------------------------------------------------------------------------------
 // fdlibm-derived float routines (glibc sysdeps/ieee754/flt-32/e_acosf.c, e_asinf.c,
 // s_atanf.c, e_atan2f.c, s_tanf.c + k_tanf.c + e_rem_pio2f.c); float arithmetic, no FMA.
 RLM_FN float acosf_(float x)
 {
+	// Same operations per input as glibc's three-way branch (|x|<0.5, x<-0.5, x>0.5), arranged so that a
+	// wave whose lanes fall into different ranges evaluates the shared rational p(z)/q(z) once: only the
+	// choice of z and the short tails differ.  Values computed for a range the lane is not in are discarded.
 	const float one = 1.0000000000e+00f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f,
 		pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
 		pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f,
 		qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
-	float z, p, q, r, w, s, c, df;
-	int32_t hx = (int32_t)asuint(x), ix = hx & 0x7fffffff;
-	if (ix == 0x3f800000) {
-		if (hx > 0) return 0.0f;
-		return pi + 2.0f * pio2_lo;
-	} else if (ix > 0x3f800000) {
+	const int32_t hx = (int32_t)asuint(x), ix = hx & 0x7fffffff;
+	if (ix >= 0x3f800000) {
+		if (ix == 0x3f800000) return (hx > 0) ? 0.0f : pi + 2.0f * pio2_lo;
 		return (x - x) / (x - x);
 	}
-	if (ix < 0x3f000000) {
-		if (ix <= 0x23000000) return pio2_hi + pio2_lo;
-		z = x * x;
-		p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-		q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-		r = p / q;
-		return pio2_hi - (x - (pio2_lo - r * x));
-	} else if (hx < 0) {
-		z = (one + x) * 0.5f;
-		p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-		q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-		s = sqrtf_(z);
-		r = p / q;
-		w = r * s - pio2_lo;
-		return pi - 2.0f * (s + w);
-	} else {
-		z = (one - x) * 0.5f;
-		s = sqrtf_(z);
-		df = asfloat(asuint(s) & 0xfffff000u);
-		c = (z - df * df) / (s + df);
-		p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-		q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-		r = p / q;
-		w = r * s + c;
-		return 2.0f * (df + w);
-	}
+	const bool small = ix < 0x3f000000;
+	if (small && ix <= 0x23000000) return pio2_hi + pio2_lo;
+	const bool neg = hx < 0;
+	const float z = small ? x * x : (neg ? (one + x) * 0.5f : (one - x) * 0.5f);
+	const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+	const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+	const float r = p / q;
+	const float s = sqrtf_(z);
+	// |x| < 0.5
+	const float rSmall = pio2_hi - (x - (pio2_lo - r * x));
+	// x < -0.5
+	const float wNeg = r * s - pio2_lo;
+	const float rNeg = pi - 2.0f * (s + wNeg);
+	// x > 0.5
+	const float df = asfloat(asuint(s) & 0xfffff000u);
+	const float c = (z - df * df) / (s + df);
+	const float wPos = r * s + c;
+	const float rPos = 2.0f * (df + wPos);
+	return small ? rSmall : (neg ? rNeg : rPos);
 }
 
 // asinf (glibc e_asinf.c: glibc's own minimax p0..p4, not fdlibm's rational)
@@ -529,11 +542,12 @@ RLM_FN float tanf_(float x)
 	const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p+0;
 	const uint32_t ux = asuint(x);
 	const int32_t ix = (int32_t)(ux & 0x7fffffff);
-	if (ix <= 0x3f490fda) return kernel_tanf(x, 0.0f, 1);
 	if (ix >= 0x7f800000) return x - x;
 	double dx = (double)x;
 	int n;
 	if (((ux >> 20) & 0x7ff) < 0x42f) {
+		// glibc calls __kernel_tanf(x, 0, 1) directly for |x| <= pi/4; the reduction gives n = 0,
+		// dx = x - 0*hpi = x, head x and tail 0 there, i.e. the same call -- one path, no divergence.
 		double r = dx * hpi_inv;
 		n = ((int32_t)r + 0x800000) >> 24;
 		double nh = (double)n * hpi;

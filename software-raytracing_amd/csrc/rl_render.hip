@@ -85,7 +85,8 @@ __device__ __forceinline__ V3 RandomInUnitSphere(Rng& g)
 	float z = 1.0f - 2.0f * u1;
 	float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
 	float phi = 2.0f * 3.141592f * u2;
-	return v3(r * rtm::cos_(phi), r * rtm::sin_(phi), z);
+	float sn, cs; rtm::sincos_(phi, &sn, &cs);
+	return v3(r * cs, r * sn, z);
 }
 // reference core/random.cc:42-50
 __device__ __forceinline__ V3 RandomInUnitDisk(Rng& g)
@@ -94,7 +95,8 @@ __device__ __forceinline__ V3 RandomInUnitDisk(Rng& g)
 	float u2 = Next(g);
 	float r = sqrtf(u1);
 	float theta = 2.0f * 3.14159265358979323846f * u2;
-	return v3(r * rtm::cos_(theta), r * rtm::sin_(theta), 0.0f);
+	float sn, cs; rtm::sincos_(theta, &sn, &cs);
+	return v3(r * cs, r * sn, 0.0f);
 }
 
 // ---------------------------------------------------------------------------
@@ -365,8 +367,7 @@ __device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slo
 	const float Pi = RL_PI;
 	if ((double)cosThetaI > .9999) {
 		float r = sqrtf(-rtm::log_(1.0f - U1));
-		float sinPhi = rtm::sin_(2 * Pi * U2);
-		float cosPhi = rtm::cos_(2 * Pi * U2);
+		float sinPhi, cosPhi; rtm::sincos_(2 * Pi * U2, &sinPhi, &cosPhi);
 		*slope_x = r * cosPhi;
 		*slope_y = r * sinPhi;
 		return;

@@ -48,6 +48,10 @@ int main(int argc, char** argv)
 	if (want("logf")) bad += sweep1("logf", rlm::logf_, logf);
 	if (want("sinf")) bad += sweep1("sinf", rlm::sinf_, sinf);
 	if (want("cosf")) bad += sweep1("cosf", rlm::cosf_, cosf);
+	if (want("sincos")) {
+		bad += sweep1("sincosf_both.sin", [](float x) { float s, c; rlm::sincosf_both(x, &s, &c); return s; }, sinf);
+		bad += sweep1("sincosf_both.cos", [](float x) { float s, c; rlm::sincosf_both(x, &s, &c); return c; }, cosf);
+	}
 	if (want("acosf")) bad += sweep1("acosf", rlm::acosf_, acosf);
 	if (want("powf")) {
 		const float ys[] = { 5.0f, 2.2f, 1.0f / 2.2f, 0.5f, 1.3f, 3.0f, -2.0f, 0.124f };
