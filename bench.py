@@ -86,6 +86,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # under torch.distributed.run the gather path is used even with one rank (so it can be exercised on a 1-GPU box)
+    distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     os.environ["RAYLIB_DEVICE"] = str(local_rank)
@@ -98,7 +100,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if distributed:
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     lib = binding.load()
@@ -115,8 +117,8 @@ def main():
     st = ses.settings(w, h, wl["spp"], max_path=wl["max_path"])
 
     # device buffers: this rank's cells (padded to equal size for the gather) and, on rank 0, the frame
-    if world > 1:
-        pad_floats = tiling.padded_cells(w, h, world) * 64 * 4
+    if distributed:
+        pad_floats = max(tiling.padded_cells(w, h, world) * 64 * 4, w * h * 4 if world == 1 else 0)
         mine = torch.zeros(pad_floats, dtype=torch.float32, device=dev)
         gathered = [torch.zeros(pad_floats, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
         frame = torch.zeros(h * w, 4, dtype=torch.float32, device=dev) if rank == 0 else None
@@ -128,13 +130,16 @@ def main():
     acc = dict(rays=0, trace_ms=0.0, launches=0, bytes=0, nodes=0, tris=0, shaded=0, texels=0, samples=0, kernel_ms=0.0)
 
     def step(record):
-        ok = lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank if world > 1 else 0, world, C.c_void_p(mine.data_ptr()))
+        ok = lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(mine.data_ptr()))
         if ok != 1:
             raise SystemExit("RaylibAMD_RenderDevice failed")
-        if world > 1:
+        if distributed:
             dist.gather(mine, gathered, dst=0)               # one RCCL gather per frame
             if rank == 0:
-                frame[plan[1]] = torch.stack(gathered).reshape(-1, 4)[plan[0]]
+                if world == 1:
+                    frame.copy_(gathered[0][: h * w * 4].view(h * w, 4))   # one rank renders the row-major frame directly
+                else:
+                    frame[plan[1]] = torch.stack(gathered).reshape(-1, 4)[plan[0]]
         if record:
             lib.RaylibAMD_GetLastStats(C.byref(stats))
             acc["rays"] += stats.rays; acc["trace_ms"] += stats.traceKernelMs; acc["launches"] += stats.traceLaunches
@@ -148,7 +153,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +164,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -211,7 +216,7 @@ def main():
         sys.stdout.flush()
 
     ses.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

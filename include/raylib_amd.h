@@ -75,6 +75,11 @@ RAYLIB_API uint32_t RaylibAMD_NumCells(uint32_t width, uint32_t height);
  * {hit, t, p[3], n[3], paramU, paramV, material} as in oracle/flat_scene.h FlatHit). */
 RAYLIB_API int32_t RaylibAMD_ClosestHit(SceneHandle scene, const float* rays, int32_t n, float tMin, void* outHits);
 
+/* Test hook: out[i] = f(x[i] [, y[i]]) evaluated by the DEVICE math the megakernel uses (csrc/rl_math.h).
+ * fn: 0 sinf, 1 cosf, 2 tanf, 3 acosf, 4 asinf, 5 atan2f(x,y), 6 expf, 7 logf, 8 powf(x,y), 9/10 sincos (sin / cos
+ * part), 11 sqrtf, 12 x / y, 13 fmodf(x, 1).  y may be NULL for one-argument functions. */
+RAYLIB_API int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int32_t n, float* out);
+
 /* ---- host-logic introspection (no GPU needed) ---------------------------------- */
 /* Flattened scene as the kernels see it.  Triangle record = 26 words, material record =
  * 19 words, both laid out as oracle/flat_scene.h FlatTriangle / FlatMaterial. */

@@ -250,8 +250,11 @@ void Raylib_Render(const RendererSettings* settings, SceneHandle scene, CameraHa
 	if (settings->viewportWidth != img->width || settings->viewportHeight != img->height)
 		img->Reallocate(settings->viewportWidth, settings->viewportHeight, 0.0f, 0.0f, 0.0f, 1.0f);   // renderer.cc:292-296
 	if ((size_t)img->width * img->height == 0) return;
-	if (!RenderInternal(settings, (Scene*)scene, (Camera*)camera, 0, 1, nullptr, img->rgba.data()))
+	void* dev = DeviceImagePixels(*img);   // the frame stays resident for Raylib_PostProcess
+	img->devValid = false;
+	if (!RenderInternal(settings, (Scene*)scene, (Camera*)camera, 0, 1, dev, img->rgba.data()))
 		fprintf(stderr, "Raylib_Render: FAILED (no HIP device or invalid arguments); the image was not written\n");
+	else img->devValid = (dev != nullptr);
 }
 
 int32_t Raylib_Denoise(ImageHandle, int32_t, ImageHandle, ImageHandle, ImageHandle)
@@ -263,7 +266,10 @@ void Raylib_PostProcess(ImageHandle h)
 {
 	Image* img = (Image*)h;
 	if (!img) return;
-	PostProcessHost(*img);
+	if (!DevicePostProcess(*img)) {
+		Log("Raylib_PostProcess: no HIP device, running on the host");
+		PostProcessHost(*img);
+	}
 }
 
 int32_t Raylib_IsDenoiserSupported(void) { return 0; }
@@ -313,6 +319,12 @@ int32_t RaylibAMD_RenderCellsHost(const RendererSettings* settings, SceneHandle 
 {
 	if (!settings || settings->viewportWidth == 0 || settings->viewportHeight == 0 || !outHost) return 0;
 	return RenderInternal(settings, (Scene*)scene, (Camera*)camera, cellFirst, cellStride ? cellStride : 1, nullptr, outHost) ? 1 : 0;
+}
+
+int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int32_t n, float* out)
+{
+	if (!x || !out) return 0;
+	return DeviceEvalMath(fn, x, y, n, out) ? 1 : 0;
 }
 
 int32_t RaylibAMD_ClosestHit(SceneHandle sh, const float* rays, int32_t n, float tMin, void* outHits)

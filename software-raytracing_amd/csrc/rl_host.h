@@ -66,6 +66,14 @@ static_assert(sizeof(HostMaterial) == 76, "HostMaterial layout");
 struct Image {
 	uint32_t width = 0, height = 0;
 	std::vector<float> rgba;          // 4 floats per pixel, row 0 = top
+	// device-resident copy (float4 per pixel): written by Raylib_Render, consumed by Raylib_PostProcess
+	void* devPixels = nullptr;
+	size_t devBytes = 0;
+	bool devValid = false;
+	Image() = default;
+	Image(const Image& o) : width(o.width), height(o.height), rgba(o.rgba) {}
+	Image& operator=(const Image& o) { width = o.width; height = o.height; rgba = o.rgba; devValid = false; return *this; }
+	~Image();
 	void Reallocate(uint32_t w, uint32_t h, float r, float g, float b, float a);
 };
 
@@ -149,7 +157,10 @@ struct RenderRequest {
 bool DeviceAvailable();
 bool DeviceRender(Scene& scene, const RenderRequest& req, RaylibAMDStats& stats);
 bool DeviceClosestHit(Scene& scene, const float* rays, int32_t n, float tMin, void* outHits);
-bool DevicePostProcess(Image& img);
+bool DevicePostProcess(Image& img);          // Image2D::PostProcess on the device; false when no device
+void* DeviceImagePixels(Image& img);          // (re)allocates img.devPixels for width*height float4; nullptr when no device
+void DeviceFreePixels(void* p);
+bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out);
 void DeviceReleaseScene(DeviceScene* dev);
 void DeviceShutdown();
 

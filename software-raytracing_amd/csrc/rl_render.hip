@@ -950,6 +950,73 @@ k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float t
 	out[i] = r;
 }
 
+// Image2D::PostProcess, pass 1: maxWhiteLuminance = max(1, max_i luminance_i) (reference render/image.cc:62-72).
+// Luminances <= 1 cannot change the result, and for floats >= 1 the ordering of the values is the ordering of
+// their bit patterns, so one integer atomicMax per wave suffices; NaN compares false in the reference and is skipped.
+__global__ void __launch_bounds__(RL_BLOCK)
+k_pp_max(const float4* __restrict__ px, size_t n, unsigned int* __restrict__ whiteBits)
+{
+	float m = 1.0f;
+	for (size_t i = (size_t)blockIdx.x * RL_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RL_BLOCK) {
+		const float4 p = px[i];
+		const float L = dot(v3(p.x, p.y, p.z), v3(0.2126f, 0.7152f, 0.0722f));
+		if (m < L) m = L;
+	}
+	for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_down(m, off); if (m < o) m = o; }
+	if ((threadIdx.x & 63) == 0 && m > 1.0f) atomicMax(whiteBits, __float_as_uint(m));
+}
+
+// pass 2 (reference render/image.cc:76-102)
+__global__ void __launch_bounds__(RL_BLOCK)
+k_pp_map(float4* __restrict__ px, size_t n, const unsigned int* __restrict__ whiteBits)
+{
+	const size_t i = (size_t)blockIdx.x * RL_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const float maxWhiteLuminance = __uint_as_float(*whiteBits);
+	float4 p = px[i];
+	V3 rgb = v3(p.x, p.y, p.z);
+	const float luminanceOld = dot(rgb, v3(0.2126f, 0.7152f, 0.0722f));
+	if (luminanceOld <= 0.0001f) rgb = v3s(0.0f);
+	else {
+		const float numerator = luminanceOld * (1.0f + (luminanceOld / (maxWhiteLuminance * maxWhiteLuminance)));
+		const float luminanceNew = numerator / (1.0f + luminanceOld);
+		rgb = rgb * (luminanceNew / luminanceOld);
+	}
+	// min(vec3(1), rgb) with std::min's operand order (core/vec3.h:151-156): (rgb < 1) ? rgb : 1
+	rgb = v3(rgb.x < 1.0f ? rgb.x : 1.0f, rgb.y < 1.0f ? rgb.y : 1.0f, rgb.z < 1.0f ? rgb.z : 1.0f);
+	const float K = 1.0f / 2.2f;
+	p.x = rtm::pow_(rgb.x, K); p.y = rtm::pow_(rgb.y, K); p.z = rtm::pow_(rgb.z, K);
+	px[i] = p;
+}
+
+// Test hook: evaluate one device math routine on an array (tests compare with the host libm bit for bit).
+__global__ void __launch_bounds__(RL_BLOCK)
+k_eval_math(int fn, const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ out)
+{
+	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const float a = x[i], b = y ? y[i] : 0.0f;
+	float r = 0.0f, s, c;
+	switch (fn) {
+		case 0: r = rtm::sin_(a); break;
+		case 1: r = rtm::cos_(a); break;
+		case 2: r = rtm::tan_(a); break;
+		case 3: r = rtm::acos_(a); break;
+		case 4: r = rtm::asin_(a); break;
+		case 5: r = rtm::atan2_(a, b); break;
+		case 6: r = rtm::exp_(a); break;
+		case 7: r = rtm::log_(a); break;
+		case 8: r = rtm::pow_(a, b); break;
+		case 9: rtm::sincos_(a, &s, &c); r = s; break;
+		case 10: rtm::sincos_(a, &s, &c); r = c; break;
+		case 11: r = sqrtf(a); break;
+		case 12: r = a / b; break;
+		case 13: r = rtm::fmod1_(a); break;
+		default: break;
+	}
+	out[i] = r;
+}
+
 // ===========================================================================
 // Host runtime
 // ===========================================================================
@@ -1248,7 +1315,72 @@ bool DeviceClosestHit(Scene& sc, const float* rays, int32_t n, float tMin, void*
 	return true;
 }
 
-bool DevicePostProcess(Image&) { return false; }
+bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out)
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	if (!EnsureRuntime()) return false;
+	HIP_OK(hipSetDevice(g_rt.device));
+	if (n <= 0) return true;
+	float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+	HIP_OK(hipMalloc(&dx, (size_t)n * 4)); HIP_OK(hipMalloc(&dout, (size_t)n * 4));
+	HIP_OK(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
+	if (y) { HIP_OK(hipMalloc(&dy, (size_t)n * 4)); HIP_OK(hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice)); }
+	hipLaunchKernelGGL(k_eval_math, dim3(((uint32_t)n + RL_BLOCK - 1) / RL_BLOCK), dim3(RL_BLOCK), 0, g_rt.stream, fn, dx, dy, n, dout);
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipStreamSynchronize(g_rt.stream));
+	HIP_OK(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+	(void)hipFree(dx); (void)hipFree(dout); if (dy) (void)hipFree(dy);
+	return true;
+}
+
+void* DeviceImagePixels(Image& img)
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	if (!EnsureRuntime()) return nullptr;
+	const size_t need = (size_t)img.width * img.height * sizeof(float4);
+	if (need == 0) return nullptr;
+	if (img.devPixels && img.devBytes >= need) return img.devPixels;
+	if (img.devPixels) { (void)hipFree(img.devPixels); img.devPixels = nullptr; img.devBytes = 0; }
+	if (hipMalloc(&img.devPixels, need) != hipSuccess) { img.devPixels = nullptr; return nullptr; }
+	img.devBytes = need;
+	img.devValid = false;
+	return img.devPixels;
+}
+
+void DeviceFreePixels(void* p)
+{
+	if (!p) return;
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	if (g_rt.ok) (void)hipFree(p);
+}
+
+// Image2D::PostProcess (reference render/image.cc:44-103) on the device: k_pp_max finds the white point
+// (max is exact in any order), k_pp_map applies extended Reinhard on luminance, the clamp and gamma 1/2.2
+// with glibc's exact powf.  Bit-identical to the host statement of the same function.
+bool DevicePostProcess(Image& img)
+{
+	const size_t n = (size_t)img.width * img.height;
+	if (n == 0) return true;
+	float4* px = (float4*)DeviceImagePixels(img);
+	if (!px) return false;
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	HIP_OK(hipSetDevice(g_rt.device));
+	if (!img.devValid) HIP_OK(hipMemcpyAsync(px, img.rgba.data(), n * sizeof(float4), hipMemcpyHostToDevice, g_rt.stream));
+	unsigned int one; { float f = 1.0f; memcpy(&one, &f, 4); }
+	HIP_OK(hipMemcpyAsync(g_rt.jobCounter, &one, sizeof(one), hipMemcpyHostToDevice, g_rt.stream));
+	const uint32_t blocks = (uint32_t)std::min<size_t>((n + RL_BLOCK - 1) / RL_BLOCK, 2048);
+	hipLaunchKernelGGL(k_pp_max, dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, px, n, g_rt.jobCounter);
+	HIP_OK(hipGetLastError());
+	hipLaunchKernelGGL(k_pp_map, dim3((uint32_t)((n + RL_BLOCK - 1) / RL_BLOCK)), dim3(RL_BLOCK), 0, g_rt.stream, px, n, g_rt.jobCounter);
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipMemcpyAsync(img.rgba.data(), px, n * sizeof(float4), hipMemcpyDeviceToHost, g_rt.stream));
+	float white = 1.0f;
+	HIP_OK(hipMemcpyAsync(&white, g_rt.jobCounter, 4, hipMemcpyDeviceToHost, g_rt.stream));
+	HIP_OK(hipStreamSynchronize(g_rt.stream));
+	img.devValid = true;
+	Log("Max white luminance: %f", white);
+	return true;
+}
 
 void DeviceReleaseScene(DeviceScene* D)
 {

@@ -88,6 +88,7 @@ _EXPORTS = {
     "RaylibAMD_RenderCellsHost": (C.c_int32, [C.POINTER(RendererSettings), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "RaylibAMD_CellBufferFloats": (C.c_uint64, [C.c_uint32] * 4),
     "RaylibAMD_NumCells": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+    "RaylibAMD_EvalDeviceMath": (C.c_int32, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "RaylibAMD_ClosestHit": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]),
     "RaylibAMD_SceneNumTriangles": (C.c_int32, [C.c_void_p]),
     "RaylibAMD_SceneNumMaterials": (C.c_int32, [C.c_void_p]),

@@ -13,6 +13,9 @@
 #include <vector>
 #include "../software-raytracing_amd/csrc/rl_glibc_math.h"
 
+#ifndef RL_CHECK_STRIDE
+#define RL_CHECK_STRIDE 1   /* 1 = every float; the CPU test suite uses a prime stride */
+#endif
 static bool same(float a, float b) { if (a != a && b != b) return true; return rlm::asuint(a) == rlm::asuint(b); }
 
 template <typename F, typename G>
@@ -24,7 +27,7 @@ static uint64_t sweep1(const char* name, F mine, G ref, uint32_t lo = 0, uint64_
 	std::vector<std::thread> th;
 	for (int t = 0; t < NT; ++t) th.emplace_back([&, t] {
 		uint64_t local = 0;
-		for (uint64_t i = lo + (uint64_t)t; i < hi; i += NT) {
+		for (uint64_t i = lo + (uint64_t)t * RL_CHECK_STRIDE; i < hi; i += (uint64_t)NT * RL_CHECK_STRIDE) {
 			float x = rlm::asfloat((uint32_t)i);
 			float a = mine(x), b = ref(x);
 			if (!same(a, b)) { if (!local) firstBad = (uint32_t)i; ++local; }
@@ -53,6 +56,12 @@ int main(int argc, char** argv)
 		bad += sweep1("sincosf_both.cos", [](float x) { float s, c; rlm::sincosf_both(x, &s, &c); return c; }, cosf);
 	}
 	if (want("acosf")) bad += sweep1("acosf", rlm::acosf_, acosf);
+	if (want("quick")) {   // reduced two-argument coverage for the test suite
+		const float ys[] = { 5.0f, 2.2f, 1.0f / 2.2f, 0.77f };
+		for (float y : ys) bad += sweep1("powf(x, y)", [y](float x) { return rlm::powf_(x, y); }, [y](float x) { return powf(x, y); });
+		bad += sweep1("atan2f(y, 0.3)", [](float y) { return rlm::atan2f_(y, 0.3f); }, [](float y) { return atan2f(y, 0.3f); });
+		bad += sweep1("atan2f(-0.7, x)", [](float x) { return rlm::atan2f_(-0.7f, x); }, [](float x) { return atan2f(-0.7f, x); });
+	}
 	if (want("powf")) {
 		const float ys[] = { 5.0f, 2.2f, 1.0f / 2.2f, 0.5f, 1.3f, 3.0f, -2.0f, 0.124f };
 		for (float y : ys) {
