@@ -75,6 +75,28 @@ RAYLIB_API uint32_t RaylibAMD_NumCells(uint32_t width, uint32_t height);
  * {hit, t, p[3], n[3], paramU, paramV, material} as in oracle/flat_scene.h FlatHit). */
 RAYLIB_API int32_t RaylibAMD_ClosestHit(SceneHandle scene, const float* rays, int32_t n, float tMin, void* outHits);
 
+/* ---- procedural scene elements ----------------------------------------------------------
+ * The reference's two procedural demo scenes (src/main.cc:913-984) `new` its C++ classes (Sphere, Cube, Triangle,
+ * Lambertian, Metal, ...) in the application and pass the object pointers to Raylib_AddSceneElement.  A C ABI
+ * cannot accept foreign C++ objects, so the same elements are created through the library instead; the handles
+ * returned here are what Raylib_AddSceneElement accepts.  Elements and materials are owned by the library and
+ * BORROWED by scenes (destroy them after the scene, like OBJ models). */
+typedef uintptr_t MaterialHandle;
+/* type: 0 Lambertian(albedo) 1 Mirror(albedo) 2 Dielectric(ior, transmission) 3 Microfacet(albedo, roughness, metallic, emissive)
+ *       4 Metal(albedo, fuzziness) 5 DiffuseLight(albedo = intensity)      (reference render/material.h:50-270) */
+RAYLIB_API MaterialHandle RaylibAMD_CreateMaterial(int32_t type, const float albedo[3], float roughness, float metallic,
+	const float emissive[3], float ior, const float transmission[3], float fuzziness);
+RAYLIB_API int32_t RaylibAMD_DestroyMaterial(MaterialHandle material);
+/* reference geom/sphere.h:11-16 */
+RAYLIB_API SceneElementHandle RaylibAMD_CreateSphere(float cx, float cy, float cz, float radius, MaterialHandle material);
+/* reference geom/cube.h:24-31 (Cube::FromMinMaxBounds) */
+RAYLIB_API SceneElementHandle RaylibAMD_CreateCube(const float minBounds[3], const float maxBounds[3], float timeStartMove,
+	const float velocity[3], MaterialHandle material);
+/* reference geom/triangle.h:12-15; UVs as SetParameterization (s0 t0 s1 t1 s2 t2), may be NULL */
+RAYLIB_API SceneElementHandle RaylibAMD_CreateTriangle(const float v0[3], const float v1[3], const float v2[3],
+	const float n0[3], const float n1[3], const float n2[3], const float uv[6], MaterialHandle material);
+RAYLIB_API int32_t RaylibAMD_DestroySceneElement(SceneElementHandle element);
+
 /* Test hook: out[i] = f(x[i] [, y[i]]) evaluated by the DEVICE math the megakernel uses (csrc/rl_math.h).
  * fn: 0 sinf, 1 cosf, 2 tanf, 3 acosf, 4 asinf, 5 atan2f(x,y), 6 expf, 7 logf, 8 powf(x,y), 9/10 sincos (sin / cos
  * part), 11 sqrtf, 12 x / y, 13 fmodf(x, 1).  y may be NULL for one-argument functions. */

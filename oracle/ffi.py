@@ -31,6 +31,10 @@ MAT_DTYPE = np.dtype([
 ])
 assert MAT_DTYPE.itemsize == 76
 
+SPHERE_DTYPE = np.dtype([("center", "f4", 3), ("radius", "f4"), ("material", "i4")])
+CUBE_DTYPE = np.dtype([("minBounds", "f4", 3), ("maxBounds", "f4", 3), ("timeStartMove", "f4"), ("velocity", "f4", 3), ("material", "i4")])
+assert SPHERE_DTYPE.itemsize == 20 and CUBE_DTYPE.itemsize == 44
+
 HIT_DTYPE = np.dtype([
     ("hit", "i4"), ("t", "f4"), ("p", "f4", 3), ("n", "f4", 3), ("paramU", "f4"), ("paramV", "f4"), ("material", "i4"),
 ])
@@ -60,7 +64,9 @@ class FlatSceneDesc(C.Structure):
                 ("textures", C.POINTER(FlatTexture)), ("numTextures", C.c_int32),
                 ("numShapes", C.c_int32),
                 ("sunIlluminance", C.c_float * 3), ("sunDirection", C.c_float * 3),
-                ("skyTexture", C.c_int32)]
+                ("skyTexture", C.c_int32),
+                ("spheres", C.c_void_p), ("numSpheres", C.c_int32),
+                ("cubes", C.c_void_p), ("numCubes", C.c_int32)]
 
 
 class OracleCounters(C.Structure):
@@ -85,7 +91,9 @@ class FlatScene:
     """Host-side flat scene: numpy arrays + textures; builds a FlatSceneDesc on demand."""
 
     def __init__(self, triangles, materials, textures=(), num_shapes=None,
-                 sun_illuminance=(0, 0, 0), sun_direction=(0.0, -1.0, -0.5), sky_texture=-1):
+                 sun_illuminance=(0, 0, 0), sun_direction=(0.0, -1.0, -0.5), sky_texture=-1, spheres=(), cubes=()):
+        self.spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE) if len(spheres) else np.zeros(0, SPHERE_DTYPE)
+        self.cubes = np.ascontiguousarray(cubes, dtype=CUBE_DTYPE) if len(cubes) else np.zeros(0, CUBE_DTYPE)
         self.triangles = np.ascontiguousarray(triangles, dtype=TRI_DTYPE)
         self.materials = np.ascontiguousarray(materials, dtype=MAT_DTYPE)
         self.textures = [np.ascontiguousarray(t, dtype=np.float32) for t in textures]  # each (H, W, 4)
@@ -110,6 +118,10 @@ class FlatScene:
         d.sunIlluminance[:] = self.sun_illuminance
         d.sunDirection[:] = self.sun_direction
         d.skyTexture = self.sky_texture
+        d.spheres = self.spheres.ctypes.data if len(self.spheres) else None
+        d.numSpheres = len(self.spheres)
+        d.cubes = self.cubes.ctypes.data if len(self.cubes) else None
+        d.numCubes = len(self.cubes)
         return d
 
 

@@ -71,6 +71,11 @@ typedef struct FlatSettings {
 	uint32_t renderMode;
 } FlatSettings;
 
+/* Analytic primitives added with Raylib_AddSceneElement in the reference's procedural scenes
+ * (reference src/main.cc:913-984): geom/sphere.h:8-26, geom/cube.h:8-42. */
+typedef struct FlatSphere { float center[3]; float radius; int32_t material; } FlatSphere;
+typedef struct FlatCube { float minBounds[3]; float maxBounds[3]; float timeStartMove; float velocity[3]; int32_t material; } FlatCube;
+
 typedef struct FlatSceneDesc {
 	const FlatTriangle* triangles; int32_t numTriangles;
 	const FlatMaterial* materials; int32_t numMaterials;
@@ -79,6 +84,9 @@ typedef struct FlatSceneDesc {
 	float sunIlluminance[3];
 	float sunDirection[3];      /* un-normalised; Scene normalises (reference geom/scene.h:20) */
 	int32_t skyTexture;         /* -1 = none */
+	/* scene elements are added in this order: the OBJ root (if numTriangles > 0), the spheres, the cubes */
+	const FlatSphere* spheres; int32_t numSpheres;
+	const FlatCube* cubes;     int32_t numCubes;
 } FlatSceneDesc;
 
 /* Closest-hit record returned by both checkers (reference geom/hit.h:16-36). */

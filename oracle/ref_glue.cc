@@ -28,6 +28,8 @@
 #include "geom/triangle.h"
 #include "geom/static_mesh.h"
 #include "geom/scene.h"
+#include "geom/sphere.h"
+#include "geom/cube.h"
 #include "render/camera.h"
 #include "render/material.h"
 #include "render/texture.h"
@@ -172,6 +174,7 @@ void* ref_scene_create(const FlatSceneDesc* desc, uint64_t buildSeed)
 	}
 
 	int32_t nShapes = desc->numShapes > 0 ? desc->numShapes : 1;
+	if (desc->numTriangles == 0) nShapes = 0;
 	rs->meshes.resize(nShapes);
 	for (int32_t s = 0; s < nShapes; ++s) rs->meshes[s] = new StaticMesh;
 	for (int32_t i = 0; i < desc->numTriangles; ++i) {
@@ -182,7 +185,9 @@ void* ref_scene_create(const FlatSceneDesc* desc, uint64_t buildSeed)
 	}
 	for (StaticMesh* m : rs->meshes) m->CalculateBounds();
 
-	if (nShapes == 1) {
+	if (nShapes == 0) {
+		rs->root = nullptr;
+	} else if (nShapes == 1) {
 		rs->root = rs->meshes[0];
 	} else {
 		std::vector<Hitable*> hs(rs->meshes.begin(), rs->meshes.end());
@@ -191,7 +196,15 @@ void* ref_scene_create(const FlatSceneDesc* desc, uint64_t buildSeed)
 	}
 	for (StaticMesh* m : rs->meshes) m->Finalize();
 
-	rs->scene.AddSceneElement(rs->root);
+	if (desc->numTriangles > 0) rs->scene.AddSceneElement(rs->root);
+	for (int32_t i = 0; i < desc->numSpheres; ++i) {
+		const FlatSphere& f = desc->spheres[i];
+		rs->scene.AddSceneElement(new Sphere(V(f.center), f.radius, rs->materials[f.material]));
+	}
+	for (int32_t i = 0; i < desc->numCubes; ++i) {
+		const FlatCube& f = desc->cubes[i];
+		rs->scene.AddSceneElement(new Cube(V(f.minBounds), V(f.maxBounds), f.timeStartMove, V(f.velocity), rs->materials[f.material]));
+	}
 	rs->scene.SetSunIlluminance(V(desc->sunIlluminance));
 	rs->scene.SetSunDirection(V(desc->sunDirection));
 	if (desc->skyTexture >= 0) rs->scene.SetSkyPanorama((ImageHandle)rs->images[desc->skyTexture].get());

@@ -33,6 +33,8 @@ Registry<OBJModel> g_objModels;
 Registry<Camera>   g_cameras;
 Registry<Image>    g_images;
 Registry<Scene>    g_scenes;
+Registry<MaterialObj>  g_materials;
+Registry<SceneElement> g_elements;
 
 std::mutex g_stateMu;
 uint64_t g_seed = 1;
@@ -190,11 +192,17 @@ SceneHandle Raylib_CreateScene(void)
 	return (SceneHandle)s;
 }
 
-void Raylib_AddSceneElement(SceneHandle, SceneElementHandle)
+void Raylib_AddSceneElement(SceneHandle sh, SceneElementHandle eh)
 {
-	// The reference casts the handle to its C++ `Hitable*` (raylib.cc:258-262): that is a
-	// C++-ABI contract (vtables, class layouts), not a C one.  See INTEGRATION.md.
-	Log("Raylib_AddSceneElement: foreign C++ Hitable objects are not supported by this library; use OBJ models");
+	// The reference casts the handle to its C++ `Hitable*` (raylib.cc:258-262): a C++-ABI contract (vtables, class
+	// layouts), not a C one.  Elements made by RaylibAMD_CreateSphere / Cube / Triangle are accepted; see INTEGRATION.md.
+	Scene* s = (Scene*)sh; SceneElement* e = (SceneElement*)eh;
+	if (!s || !e) return;
+	if (!g_elements.contains(e)) {
+		Log("Raylib_AddSceneElement: not an element created by this library (foreign C++ Hitable objects are not supported)");
+		return;
+	}
+	if (!s->finalized) s->elements.push_back(e);   // reference geom/scene.cc:15-21: ignored after Finalize
 }
 
 void Raylib_AddOBJModelToScene(SceneHandle sh, OBJModelHandle oh)
@@ -319,6 +327,78 @@ int32_t RaylibAMD_RenderCellsHost(const RendererSettings* settings, SceneHandle 
 {
 	if (!settings || settings->viewportWidth == 0 || settings->viewportHeight == 0 || !outHost) return 0;
 	return RenderInternal(settings, (Scene*)scene, (Camera*)camera, cellFirst, cellStride ? cellStride : 1, nullptr, outHost) ? 1 : 0;
+}
+
+MaterialHandle RaylibAMD_CreateMaterial(int32_t type, const float albedo[3], float roughness, float metallic,
+                                        const float emissive[3], float ior, const float transmission[3], float fuzziness)
+{
+	if (type < 0 || type > MAT_DIFFUSE_LIGHT) return 0;
+	MaterialObj* M = new MaterialObj; memset(&M->m, 0, sizeof(M->m));
+	HostMaterial& m = M->m;
+	m.type = type;
+	for (int i = 0; i < 5; ++i) m.tex[i] = -1;
+	auto clamp01 = [](float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); };
+	for (int i = 0; i < 3; ++i) {
+		m.albedo[i] = albedo ? albedo[i] : 0.0f;
+		m.emissive[i] = emissive ? emissive[i] : 0.0f;
+		m.transmission[i] = transmission ? transmission[i] : 1.0f;
+	}
+	m.roughness = roughness; m.metallic = metallic; m.ior = ior; m.fuzziness = fuzziness;
+	// constructor-side clamps of the reference (render/material.h:79-82,107,236-238)
+	if (type == MAT_LAMBERTIAN) for (int i = 0; i < 3; ++i) m.albedo[i] = clamp01(m.albedo[i]);
+	if (type == MAT_METAL) m.fuzziness = clamp01(m.fuzziness);
+	if (type == MAT_MICROFACET) { for (int i = 0; i < 3; ++i) m.albedo[i] = clamp01(m.albedo[i]); m.roughness = clamp01(m.roughness); m.metallic = clamp01(m.metallic); }
+	g_materials.add(M);
+	return (MaterialHandle)M;
+}
+int32_t RaylibAMD_DestroyMaterial(MaterialHandle h)
+{
+	MaterialObj* M = (MaterialObj*)h;
+	if (g_materials.eraseFirst(M)) { delete M; return 1; }
+	return 0;
+}
+static SceneElement* NewElement(PrimKind kind, MaterialHandle mh)
+{
+	MaterialObj* M = (MaterialObj*)mh;
+	if (!M || !g_materials.contains(M)) return nullptr;
+	SceneElement* e = new SceneElement; memset(e, 0, sizeof(*e));
+	e->kind = kind; e->material = M;
+	g_elements.add(e);
+	return e;
+}
+SceneElementHandle RaylibAMD_CreateSphere(float cx, float cy, float cz, float radius, MaterialHandle material)
+{
+	SceneElement* e = NewElement(PRIM_SPHERE, material);
+	if (!e) return 0;
+	e->center = F3(cx, cy, cz); e->radius = radius;
+	return (SceneElementHandle)e;
+}
+SceneElementHandle RaylibAMD_CreateCube(const float mn[3], const float mx[3], float timeStartMove, const float velocity[3], MaterialHandle material)
+{
+	if (!mn || !mx) return 0;
+	SceneElement* e = NewElement(PRIM_CUBE, material);
+	if (!e) return 0;
+	e->minBounds = F3(mn[0], mn[1], mn[2]); e->maxBounds = F3(mx[0], mx[1], mx[2]); e->timeStartMove = timeStartMove;
+	e->velocity = velocity ? F3(velocity[0], velocity[1], velocity[2]) : F3(0, 0, 0);
+	return (SceneElementHandle)e;
+}
+SceneElementHandle RaylibAMD_CreateTriangle(const float v0[3], const float v1[3], const float v2[3],
+                                            const float n0[3], const float n1[3], const float n2[3], const float uv[6], MaterialHandle material)
+{
+	if (!v0 || !v1 || !v2 || !n0 || !n1 || !n2) return 0;
+	SceneElement* e = NewElement(PRIM_TRIANGLE, material);
+	if (!e) return 0;
+	HostTriangle& t = e->tri;
+	t.v0 = F3(v0[0], v0[1], v0[2]); t.v1 = F3(v1[0], v1[1], v1[2]); t.v2 = F3(v2[0], v2[1], v2[2]);
+	t.n0 = F3(n0[0], n0[1], n0[2]); t.n1 = F3(n1[0], n1[1], n1[2]); t.n2 = F3(n2[0], n2[1], n2[2]);
+	if (uv) { t.s0 = uv[0]; t.t0 = uv[1]; t.s1 = uv[2]; t.t1 = uv[3]; t.s2 = uv[4]; t.t2 = uv[5]; }
+	return (SceneElementHandle)e;
+}
+int32_t RaylibAMD_DestroySceneElement(SceneElementHandle h)
+{
+	SceneElement* e = (SceneElement*)h;
+	if (g_elements.eraseFirst(e)) { delete e; return 1; }
+	return 0;
 }
 
 int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int32_t n, float* out)

@@ -42,14 +42,20 @@ constexpr uint32_t kMaxLeaf = 4;
 constexpr float kCostTraverse = 1.0f, kCostTri = 1.0f;
 
 struct Builder {
-	const std::vector<HostTriangle>& tris;
+	std::vector<uint8_t> kind;      // per primitive: PRIM_TRIANGLE / PRIM_SPHERE / PRIM_CUBE
 	std::vector<Box> triBox;
 	std::vector<f3> centroid;
 	std::vector<uint32_t> order;
 	std::vector<TmpNode> tmp;
 	uint32_t maxDepth = 0;
 
-	explicit Builder(const std::vector<HostTriangle>& t) : tris(t) {}
+	// a leaf is either <= kMaxLeaf triangles or exactly one analytic primitive
+	bool leafAllowed(uint32_t b, uint32_t e) const {
+		if (e - b == 1) return true;
+		if (e - b > kMaxLeaf) return false;
+		for (uint32_t i = b; i < e; ++i) if (kind[order[i]] != PRIM_TRIANGLE) return false;
+		return true;
+	}
 
 	int32_t build(uint32_t b, uint32_t e, uint32_t depth) {
 		TmpNode node;
@@ -96,10 +102,10 @@ struct Builder {
 		uint32_t mid;
 		if (bestAxis < 0) {
 			// all centroids coincide: split by index
-			if (n <= kMaxLeaf) return makeLeaf();
+			if (leafAllowed(b, e)) return makeLeaf();
 			mid = b + n / 2;
 		} else {
-			if (n <= kMaxLeaf && bestCost >= kCostTri * n) return makeLeaf();
+			if (leafAllowed(b, e) && bestCost >= kCostTri * n) return makeLeaf();
 			float lo = axisOf(cb.mn, bestAxis), hi = axisOf(cb.mx, bestAxis);
 			const float scale = (float)kBins / (hi - lo);
 			auto it = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t t) {
@@ -121,14 +127,14 @@ inline void storeBox(float* mn, float* mx, const Box& b) {
 	mn[0] = b.mn.x; mn[1] = b.mn.y; mn[2] = b.mn.z;
 	mx[0] = b.mx.x; mx[1] = b.mx.y; mx[2] = b.mx.z;
 }
-inline int32_t leafRef(uint32_t first, uint32_t count) { return ~(int32_t)((first << 4) | (count - 1)); }
+inline int32_t leafRef(uint32_t first, uint32_t kind, uint32_t count) { return ~(int32_t)((first << 6) | (kind << 4) | (count - 1)); }
 
 } // namespace
 
-void BuildBVH(const std::vector<HostTriangle>& tris, BVH& out)
+void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 {
 	out.nodes.clear(); out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
-	const uint32_t n = (uint32_t)tris.size();
+	const uint32_t n = (uint32_t)prims.size();
 	Box empty; empty.mn = F3(FLT_MAX, FLT_MAX, FLT_MAX); empty.mx = F3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
 
 	if (n == 0) {
@@ -139,34 +145,45 @@ void BuildBVH(const std::vector<HostTriangle>& tris, BVH& out)
 		return;
 	}
 
-	Builder B(tris);
-	B.triBox.resize(n); B.centroid.resize(n); B.order.resize(n);
+	Builder B;
+	B.kind.resize(n); B.triBox.resize(n); B.centroid.resize(n); B.order.resize(n);
 	for (uint32_t i = 0; i < n; ++i) {
-		const HostTriangle& t = tris[i];
-		Box b; b.mn = fmin3(fmin3(t.v0, t.v1), t.v2); b.mx = fmax3(fmax3(t.v0, t.v1), t.v2);
+		Box b; b.mn = prims[i].mn; b.mx = prims[i].mx;
+		B.kind[i] = prims[i].kind;
 		B.triBox[i] = b;
 		B.centroid[i] = F3(0.5f * (b.mn.x + b.mx.x), 0.5f * (b.mn.y + b.mx.y), 0.5f * (b.mn.z + b.mx.z));
 		B.order[i] = i;
 	}
 	B.tmp.reserve(2 * (size_t)n);
 	int32_t root = B.build(0, n, 0);
-	out.triOrder = B.order;
+
+	// Leaf references.  Triangle leaves index the triangle arrays in leaf order (out.triOrder lists the
+	// original triangle index of every slot); an analytic primitive's leaf carries its index in its own array.
+	const std::vector<TmpNode>& T = B.tmp;
+	std::vector<int32_t> leafCode(T.size(), 0);
+	for (size_t t = 0; t < T.size(); ++t) {
+		if (T[t].left >= 0) continue;
+		const uint32_t k = B.kind[B.order[T[t].first]];
+		if (k == PRIM_TRIANGLE) {
+			const uint32_t first = (uint32_t)out.triOrder.size();
+			for (uint32_t i = 0; i < T[t].count; ++i) out.triOrder.push_back(prims[B.order[T[t].first + i]].index);
+			leafCode[t] = leafRef(first, PRIM_TRIANGLE, T[t].count);
+		} else {
+			leafCode[t] = leafRef(prims[B.order[T[t].first]].index, k, 1);
+		}
+	}
 
 	// Emit two-box nodes in depth-first order.  A tree that is a single leaf still
 	// gets one inner node (left = the leaf, right = empty).
-	const std::vector<TmpNode>& T = B.tmp;
 	if (T[root].left < 0) {
 		DNode nd; memset(&nd, 0, sizeof(nd));
 		storeBox(nd.lmin, nd.lmax, T[root].box); storeBox(nd.rmin, nd.rmax, empty);
-		nd.left = leafRef(T[root].first, T[root].count); nd.right = DNODE_EMPTY;
+		nd.left = leafCode[root]; nd.right = DNODE_EMPTY;
 		out.nodes.push_back(nd);
 		out.depth = 1;
 		return;
 	}
 	std::vector<int32_t> emitIndex(T.size(), -1);
-	struct Item { int32_t tmp; };
-	std::vector<int32_t> stack; stack.push_back(root);
-	// first pass: assign indices to inner nodes in DFS preorder
 	int32_t next = 0;
 	{
 		std::vector<int32_t> st; st.push_back(root);
@@ -185,8 +202,8 @@ void BuildBVH(const std::vector<HostTriangle>& tris, BVH& out)
 		DNode nd; memset(&nd, 0, sizeof(nd));
 		const TmpNode& L = T[T[t].left]; const TmpNode& R = T[T[t].right];
 		storeBox(nd.lmin, nd.lmax, L.box); storeBox(nd.rmin, nd.rmax, R.box);
-		nd.left = (L.left < 0) ? leafRef(L.first, L.count) : emitIndex[T[t].left];
-		nd.right = (R.left < 0) ? leafRef(R.first, R.count) : emitIndex[T[t].right];
+		nd.left = (L.left < 0) ? leafCode[T[t].left] : emitIndex[T[t].left];
+		nd.right = (R.left < 0) ? leafCode[T[t].right] : emitIndex[T[t].right];
 		out.nodes[emitIndex[t]] = nd;
 	}
 	out.depth = B.maxDepth;   // leaves at depth d => at most d inner nodes above them
@@ -209,7 +226,8 @@ bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris)
 		Item it = st.back(); st.pop_back();
 		if (it.ref == DNODE_EMPTY) continue;
 		if (it.ref < 0) {
-			uint32_t code = (uint32_t)~it.ref, first = code >> 4, count = (code & 7u) + 1;
+			uint32_t code = (uint32_t)~it.ref, first = code >> 6, count = (code & 7u) + 1;
+			if (((code >> 4) & 3u) != PRIM_TRIANGLE) continue;   // analytic primitive: nothing to check against triangles
 			for (uint32_t k = 0; k < count; ++k) {
 				if (first + k >= bvh.triOrder.size()) return false;
 				uint32_t ti = bvh.triOrder[first + k];

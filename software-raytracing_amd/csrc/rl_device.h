@@ -12,7 +12,8 @@ namespace rl {
 // children (the reference keeps one box per heap node and chases a pointer per
 // child: geom/bvh.h:20-22, 48 B + vtable).
 //   child >= 0            : inner node index
-//   child <  0, != EMPTY  : leaf, ~child = (firstTri << 4) | (alphaTested << 3) | (count - 1)
+//   child <  0, != EMPTY  : leaf, ~child = (first << 6) | (kind << 4) | (alphaTested << 3) | (count - 1)
+//                           kind 0: `count` (<= 4) triangles from `first`; kind 1 / 2: sphere / cube number `first`
 //   child == DNODE_EMPTY  : nothing (box is inverted, never hit)
 #define DNODE_EMPTY ((int32_t)0x80000000)
 struct alignas(64) DNode {
@@ -45,6 +46,12 @@ struct alignas(64) DTriShade {
 	int32_t material;
 };
 static_assert(sizeof(DTriShade) == 64, "DTriShade");
+
+// Analytic primitives of the reference's procedural scenes (geom/sphere.h:22-25, geom/cube.h:36-41).
+struct alignas(16) DSphere { float center[3]; float radius; int32_t material; int32_t pad[3]; };
+static_assert(sizeof(DSphere) == 32, "DSphere");
+struct alignas(16) DCube { float minBounds[3]; float timeStartMove; float maxBounds[3]; int32_t material; float velocity[3]; int32_t pad; };
+static_assert(sizeof(DCube) == 48, "DCube");
 
 // Material record, 80 B (fields as reference render/material.h, see rl_host.h HostMaterial).
 struct alignas(16) DMaterial {
@@ -85,6 +92,8 @@ struct DSceneView {
 	const DMaterial* materials;
 	const DTexture* textures;
 	const float* texels;       // float4 pool
+	const DSphere* spheres;
+	const DCube* cubes;
 	float sunIlluminance[3];
 	float sunDirection[3];     // normalised
 	int32_t skyTexture;        // -1 = none

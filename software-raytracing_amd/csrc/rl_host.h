@@ -105,14 +105,35 @@ struct BVH {
 	uint32_t depth = 0;
 	float sahCost = 0.0f;
 };
-// Binned-SAH BVH2 over triangle bounds.  Leaves hold <= 4 triangles.
-void BuildBVH(const std::vector<HostTriangle>& tris, BVH& out);
+// Binned-SAH BVH2 over primitive bounds.  A leaf holds <= 4 triangles or one analytic primitive.
+enum PrimKind { PRIM_TRIANGLE = 0, PRIM_SPHERE = 1, PRIM_CUBE = 2 };
+struct PrimRef { f3 mn, mx; uint8_t kind; uint32_t index; };
+void BuildBVH(const std::vector<PrimRef>& prims, BVH& out);
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris);
+
+// Scene elements created through include/raylib_amd.h (the reference's procedural scenes `new` C++ objects in the
+// application instead: src/main.cc:913-984).  A material is owned by the library and shared by reference.
+struct MaterialObj { HostMaterial m; };
+struct SceneElement {
+	PrimKind kind;
+	MaterialObj* material;
+	// sphere (reference geom/sphere.h:22-25)
+	f3 center; float radius;
+	// cube (reference geom/cube.h:36-41)
+	f3 minBounds, maxBounds; float timeStartMove; f3 velocity;
+	// loose triangle (reference geom/triangle.h)
+	HostTriangle tri;
+};
+struct HostSphere { f3 center; float radius; int32_t material; };
+struct HostCube { f3 minBounds, maxBounds; float timeStartMove; f3 velocity; int32_t material; };
 
 struct DeviceScene;   // rl_render.hip
 
 struct Scene {
 	std::vector<OBJModel*> models;    // borrowed (reference raylib.cc:264-268)
+	std::vector<SceneElement*> elements;   // borrowed (reference raylib.cc:258-262)
+	std::vector<HostSphere> spheres;  // flattened at Finalize
+	std::vector<HostCube> cubes;
 	Image* sky = nullptr;             // borrowed (reference raylib.cc:270-273)
 	f3 sunIlluminance = F3(0, 0, 0);
 	f3 sunDirection;

@@ -30,6 +30,7 @@ __device__ __forceinline__ float tan_(float x)  { return tanf(x); }
 __device__ __forceinline__ float acos_(float x) { return acosf(x); }
 __device__ __forceinline__ float asin_(float x) { return asinf(x); }
 __device__ __forceinline__ float atan2_(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ float atan_(float x) { return atanf(x); }
 __device__ __forceinline__ float exp_(float x)  { return expf(x); }
 __device__ __forceinline__ float log_(float x)  { return logf(x); }
 __device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
@@ -48,6 +49,7 @@ RL_MATH_CALL float tan_(float x)  { return rlm::tanf_(x); }
 RL_MATH_CALL float acos_(float x) { return rlm::acosf_(x); }
 RL_MATH_CALL float asin_(float x) { return rlm::asinf_(x); }
 RL_MATH_CALL float atan2_(float y, float x) { return rlm::atan2f_(y, x); }
+RL_MATH_CALL float atan_(float x) { return rlm::atanf_(x); }
 RL_MATH_CALL float exp_(float x)  { return rlm::expf_(x); }
 RL_MATH_CALL float log_(float x)  { return rlm::logf_(x); }
 RL_MATH_CALL float pow_(float x, float y) { return rlm::powf_(x, y); }

@@ -142,7 +142,7 @@ __device__ __forceinline__ Mat LoadMat(const DSceneView& S, int i)
 
 // ---------------------------------------------------------------------------
 // Closest hit on the flat BVH2.
-struct HitRec { float t, a, b; int tri; };
+struct HitRec { float t, a, b; int tri; };   // tri: triangle slot, or (kind << 28) | index for sphere (1) / cube (2, with the face in a)
 
 struct Tri { V3 v0, n, u, v; float uv, uu, vv, denom; };
 __device__ __forceinline__ Tri LoadTri(const DSceneView& S, int i)
@@ -225,13 +225,62 @@ __device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float 
 }
 
 // stk: this lane's column of the LDS stack; entry k at stk[k * RL_BLOCK].
+// Sphere::Hit (reference geom/sphere.cc:3-45): open interval (t_min, t_max); the near root if it is inside, else the
+// far root.  t_max is the current best t (the reference compares all hits afterwards; same closest hit).
+__device__ __noinline__ bool SphereHit(const DSphere* spheres, int index, V3 o, V3 d, float t_min, float tBest, float& outT)
+{
+	const float4 q = ((const float4*)(spheres + index))[0];
+	const V3 center = v3(q.x, q.y, q.z); const float radius = q.w;
+	V3 oc = o - center;
+	float a = dot(d, d);
+	float b = dot(oc, d);
+	float c = dot(oc, oc) - radius * radius;
+	float D = b * b - a * c;
+	if (D > 0.0f) {
+		float temp = (-b - sqrtf(b * b - a * c)) / a;
+		if (t_min < temp && temp < FLT_MAX) { outT = temp; return temp < tBest; }   // the reference takes this root and compares later
+		temp = (-b + sqrtf(b * b - a * c)) / a;
+		if (t_min < temp && temp < FLT_MAX) { outT = temp; return temp < tBest; }
+	}
+	return false;
+}
+// Cube::Hit (reference geom/cube.cc:3-43): slab box moving with velocity * max(0, rayTime - timeStartMove); closed
+// interval [t_min, t_max]; entry face by the reference's float == chain (outFace 0..5 = -x +x -y +y -z +z, 6 = none matched).
+__device__ __noinline__ bool CubeHit(const DCube* cubes, int index, V3 o, V3 d, float rayTime, float t_min, float tBest, float& outT, int& outFace)
+{
+	const float4* p = (const float4*)(cubes + index);
+	const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+	const V3 velocity = v3(q2.x, q2.y, q2.z);
+	const V3 movement = velocity * fmaxf(0.0f, rayTime - q0.w);
+	const V3 mn = v3(q0.x, q0.y, q0.z) + movement, mx = v3(q1.x, q1.y, q1.z) + movement;
+	const float t1 = (mn.x - o.x) / d.x, t2 = (mx.x - o.x) / d.x;
+	const float t3 = (mn.y - o.y) / d.y, t4 = (mx.y - o.y) / d.y;
+	const float t5 = (mn.z - o.z) / d.z, t6 = (mx.z - o.z) / d.z;
+	// std::max(a, b) = (a < b) ? b : a; std::min(a, b) = (b < a) ? b : a
+	#define RL_STDMAX(a, b) (((a) < (b)) ? (b) : (a))
+	#define RL_STDMIN(a, b) (((b) < (a)) ? (b) : (a))
+	const float mnx = RL_STDMIN(t1, t2), mny = RL_STDMIN(t3, t4), mnz = RL_STDMIN(t5, t6);
+	const float mxx = RL_STDMAX(t1, t2), mxy = RL_STDMAX(t3, t4), mxz = RL_STDMAX(t5, t6);
+	const float m12 = RL_STDMAX(mnx, mny); const float t7 = RL_STDMAX(m12, mnz);
+	const float n12 = RL_STDMIN(mxx, mxy); const float t8 = RL_STDMIN(n12, mxz);
+	#undef RL_STDMAX
+	#undef RL_STDMIN
+	if (t8 < 0 || t7 > t8) return false;
+	if (t_min <= t7 && t7 <= FLT_MAX && t7 < tBest) {
+		outT = t7;
+		outFace = (t7 == t1) ? 0 : (t7 == t2) ? 1 : (t7 == t3) ? 2 : (t7 == t4) ? 3 : (t7 == t5) ? 4 : (t7 == t6) ? 5 : 6;
+		return true;
+	}
+	return false;
+}
+
 // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (cheap steps:
 // one 64-byte record, two slab tests), THEN the wave intersects leaves together.  With a single
 // "if inner else leaf" loop a wave pays node + leaf cost on every trip as soon as one lane is at a leaf, and
 // the ~4x dearer triangle code ran with a handful of lanes (measured: 14 % VALU lane utilisation on the
 // 298 k-triangle scene).
 template <int STACK, bool ANYHIT>
-__device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float tMin, HitRec& best, int* stk, Counters& c)
+__device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c)
 {
 	c.rays++;
 	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -267,26 +316,37 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 			else { --sp; cur = stk[sp * RL_BLOCK]; }
 		}
 		if (cur == DONE) break;
-		// ---- leaf: <= 4 triangles stored back to back ----
+		// ---- leaf: <= 4 triangles stored back to back, or one analytic primitive ----
 		{
 			const uint32_t code = (uint32_t)~cur;
-			const int first = (int)(code >> 4);
+			const int first = (int)(code >> 6);
 			const int count = (int)(code & 7u) + 1;
 			const bool alpha = (code & 8u) != 0;
-			for (int i = 0; i < count; ++i) {
-				const Tri T = LoadTri(S, first + i);
+			const uint32_t kind = (code >> 4) & 3u;
+			if (kind == 0u) {
+				for (int i = 0; i < count; ++i) {
+					const Tri T = LoadTri(S, first + i);
+					c.tris++;
+					// reference geom/triangle.cc:22-27
+					const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
+					if (!(t >= tMin && t <= FLT_MAX && t < best.t)) continue;
+					const V3 p = o + t * d;
+					const V3 w = p - T.v0;
+					const float wv = dot(w, T.v), wu = dot(w, T.u);
+					const float pa = (T.uv * wv - T.vv * wu) / T.denom;
+					const float pb = (T.uv * wu - T.uu * wv) / T.denom;
+					if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
+						if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
+						best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
+						if (ANYHIT) return true;
+					}
+				}
+			} else {
 				c.tris++;
-				// reference geom/triangle.cc:22-27
-				const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
-				if (!(t >= tMin && t <= FLT_MAX && t < best.t)) continue;
-				const V3 p = o + t * d;
-				const V3 w = p - T.v0;
-				const float wv = dot(w, T.v), wu = dot(w, T.u);
-				const float pa = (T.uv * wv - T.vv * wu) / T.denom;
-				const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
-					if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
-					best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
+				float t = 0.0f; int face = 0;
+				const bool hit = (kind == 1u) ? SphereHit(S.spheres, first, o, d, tMin, best.t, t) : CubeHit(S.cubes, first, o, d, rayTime, tMin, best.t, t, face);
+				if (hit) {
+					best.t = t; best.a = (kind == 2u) ? __int_as_float(face) : 0.0f; best.b = 0.0f; best.tri = (int)((kind << 28) | (uint32_t)first);
 					if (ANYHIT) return true;
 				}
 			}
@@ -302,21 +362,48 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 // Surface interaction (reference geom/hit.h:16-36)
 struct Surf { float t; V3 p, n; float U, V; V3 tangent, bitangent; };
 
-// reference geom/triangle.cc:43-47 + geom/hit.cc:6-18
-__device__ __forceinline__ void BuildSurface(const Shade& sh, V3 o, V3 d, const HitRec& h, Surf& s, bool basis)
+// HitResult for the winning primitive (reference geom/triangle.cc:43-47, geom/sphere.cc:19-41, geom/cube.cc:24-38)
+// + the tangent frame (geom/hit.cc:6-18).  Returns the material index.
+__device__ __forceinline__ int BuildSurface(const DSceneView& S, V3 o, V3 d, const HitRec& h, Surf& s, bool basis, Counters& c)
 {
+	int material;
 	s.t = h.t;
 	s.p = o + h.t * d;
-	const float a = h.a, b = h.b;
-	s.n = normalize((1 - a - b) * sh.n0 + a * sh.n1 + b * sh.n2);
-	s.U = (1 - a - b) * sh.s0 + a * sh.s1 + b * sh.s2;
-	s.V = (1 - a - b) * sh.t0 + a * sh.t1 + b * sh.t2;
+	const uint32_t kind = ((uint32_t)h.tri) >> 28;
+	if (kind == 0u) {
+		const Shade sh = LoadShade(S, h.tri);
+		c.shaded++;
+		const float a = h.a, b = h.b;
+		s.n = normalize((1 - a - b) * sh.n0 + a * sh.n1 + b * sh.n2);
+		s.U = (1 - a - b) * sh.s0 + a * sh.s1 + b * sh.s2;
+		s.V = (1 - a - b) * sh.t0 + a * sh.t1 + b * sh.t2;
+		material = sh.material;
+	} else if (kind == 1u) {
+		const float4* p = (const float4*)(S.spheres + (h.tri & 0x0fffffff));
+		const float4 q = p[0];
+		material = __float_as_int(p[1].x);
+		c.shaded++;
+		const V3 center = v3(q.x, q.y, q.z);
+		s.n = (s.p - center) / q.w;
+		const V3 op = s.p - center;
+		s.U = rtm::atan_(op.y / op.x);
+		s.V = rtm::acos_(op.z / q.w);
+	} else {
+		const float4* p = (const float4*)(S.cubes + (h.tri & 0x0fffffff));
+		material = __float_as_int(p[1].w);
+		c.shaded++;
+		const int face = __float_as_int(h.a);
+		s.n = (face == 0) ? v3(-1.0f, 0.0f, 0.0f) : (face == 1) ? v3(1.0f, 0.0f, 0.0f) : (face == 2) ? v3(0.0f, -1.0f, 0.0f)
+		    : (face == 3) ? v3(0.0f, 1.0f, 0.0f) : (face == 4) ? v3(0.0f, 0.0f, -1.0f) : (face == 5) ? v3(0.0f, 0.0f, 1.0f) : v3s(0.0f);
+		s.U = 0.0f; s.V = 0.0f;   // the reference leaves paramU / paramV unset for cubes
+	}
 	if (basis) {
 		V3 T = (fabsf(s.n.x) > 0.9f) ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
 		V3 B = normalize(cross(T, s.n));
 		T = normalize(cross(s.n, B));
 		s.tangent = T; s.bitangent = B;
 	}
+	return material;
 }
 __device__ __forceinline__ V3 LocalToWorld(const Surf& s, V3 v)
 {
@@ -619,13 +706,13 @@ __device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 in
 
 // ---------------------------------------------------------------------------
 // Camera::GetCameraRay (reference render/camera.h:44-53)
-__device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rng& g, V3& o, V3& d)
+__device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rng& g, V3& o, V3& d, float& rayTime)
 {
 	V3 rd = k.lensRadius * RandomInUnitDisk(g);
 	V3 cu = ld3(k.u), cv = ld3(k.v);
 	V3 offset = (cu * rd.x) + (cv * rd.y);
 	float captureTime = k.beginTime + k.timePeriod * Next(g);
-	(void)captureTime;   // ray.t is only consumed by the moving Cube primitive, which triangle scenes do not contain
+	rayTime = captureTime;   // ray.t: consumed by the moving Cube primitive (geom/cube.cc:5), inherited by scattered rays
 	V3 origin = ld3(k.origin);
 	o = origin + offset;
 	d = normalize(ld3(k.top_left) + s * ld3(k.horizontal) + (1.0f - t) * ld3(k.vertical) - origin - offset);
@@ -635,7 +722,7 @@ struct SkyRot { float m0[3], m1[3], m2[3]; };   // Rotator(yaw 90).rotate rows, 
 
 // Miss shader: sky panorama + sun (reference render/renderer.cc:155-199)
 template <int STACK>
-__device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTMin, int* stk, Counters& c)
+__device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTime, float rayTMin, int* stk, Counters& c)
 {
 	V3 missResult = v3s(0.0f);
 	if (S.skyTexture >= 0) {
@@ -653,7 +740,7 @@ __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V
 	}
 	if (S.hasSun) {
 		HitRec tmp;
-		if (!Traverse<STACK, true>(S, o, -ld3(S.sunDirection), rayTMin, tmp, stk, c)) missResult = missResult + ld3(S.sunIlluminance);
+		if (!Traverse<STACK, true>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c)) missResult = missResult + ld3(S.sunIlluminance);
 	}
 	return missResult;
 }
@@ -696,6 +783,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
 	Rng g; g.s.state = 0;
 	V3 o = v3s(0.0f), d = v3s(0.0f);
+	float rayTime = 0.0f;
 	int depth = 0;
 	uint32_t outIndex = 0;
 	bool active = false;
@@ -744,7 +832,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 							u += (Next(g) - 0.5f) * 2.0f / imageWidth;
 							v += (Next(g) - 0.5f) * 2.0f / imageHeight;
 						}
-						CameraRay(P.camera, u, v, g, o, d);
+						CameraRay(P.camera, u, v, g, o, d, rayTime);
 						depth = 0;
 						outIndex = j.sample * numSlots + j.slot;
 						active = true;
@@ -757,7 +845,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 							if (sunQuick) {
 								c.rays++; c.nodes++;   // the closest-hit query this replaces fetches the root node and stops
 								DSceneView Sq = S; Sq.hasSun = 0;
-								V3 L = MissShader<STACK>(Sq, R, o, d, P.rayTMin, stk, c);
+								V3 L = MissShader<STACK>(Sq, R, o, d, rayTime, P.rayTMin, stk, c);
 								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
 								samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
 								active = false;
@@ -782,12 +870,9 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				done = true;                                   // renderer.cc:120-123
 			} else {
 				HitRec h;
-				if (Traverse<STACK, false>(S, o, d, P.rayTMin, h, stk, c)) {
-					const Shade sh = LoadShade(S, h.tri);
-					c.shaded++;
+				if (Traverse<STACK, false>(S, o, d, rayTime, P.rayTMin, h, stk, c)) {
 					Surf s;
-					BuildSurface(sh, o, d, h, s, true);
-					const Mat m = LoadMat(S, sh.material);
+					const Mat m = LoadMat(S, BuildSurface(S, o, d, h, s, true, c));
 					V3 refl = v3s(0.0f), outD = v3s(0.0f);
 					float pdf = 0.0f, sp = 0.0f;
 					const bool scattered = Scatter(S, m, d, s, g, c, refl, outD, pdf, sp);
@@ -805,7 +890,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 						done = true;
 					}
 				} else {
-					L = MissShader<STACK>(S, R, o, d, P.rayTMin, stk, c);
+					L = MissShader<STACK>(S, R, o, d, rayTime, P.rayTMin, stk, c);
 					done = true;
 				}
 			}
@@ -890,28 +975,22 @@ k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsig
 	V3 debugValue = v3s(0.0f);
 	if (valid) {
 		Rng g; g.s = raylib_rng_begin(P.seed, y * P.width + x, 0);
-		V3 o, d;
-		CameraRay(P.camera, (float)x / (float)P.width, (float)y / (float)P.height, g, o, d);
+		V3 o, d; float rayTime;
+		CameraRay(P.camera, (float)x / (float)P.width, (float)y / (float)P.height, g, o, d, rayTime);
 		c.samples++;
 		HitRec h;
-		if (Traverse<STACK, false>(S, o, d, P.rayTMin, h, stk, c)) {
-			const Shade sh = LoadShade(S, h.tri);
-			c.shaded++;
+		if (Traverse<STACK, false>(S, o, d, rayTime, P.rayTMin, h, stk, c)) {
 			Surf s;
-			BuildSurface(sh, o, d, h, s, true);
-			const Mat m = LoadMat(S, sh.material);
+			const Mat m = LoadMat(S, BuildSurface(S, o, d, h, s, true, c));
 			const uint32_t mode = P.renderMode;
 			if (mode == RAYLIB_RENDERMODE_Albedo) {
 				debugValue = GetAlbedo(S, m, s.U, s.V, c);
 				if (IsMirrorLike(S, m, s.U, s.V, c)) {
 					HitRec h2;
 					const V3 d2 = reflect(d, s.n);
-					if (Traverse<STACK, false>(S, s.p, d2, P.rayTMin, h2, stk, c)) {
-						const Shade sh2 = LoadShade(S, h2.tri);
-						c.shaded++;
+					if (Traverse<STACK, false>(S, s.p, d2, rayTime, P.rayTMin, h2, stk, c)) {
 						Surf s2;
-						BuildSurface(sh2, s.p, d2, h2, s2, false);
-						const Mat m2 = LoadMat(S, sh2.material);
+						const Mat m2 = LoadMat(S, BuildSurface(S, s.p, d2, h2, s2, false, c));
 						debugValue = GetAlbedo(S, m2, s2.U, s2.V, c);
 					}
 				}
@@ -960,14 +1039,13 @@ k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float t
 	const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
 	HitRec h;
 	DHitOut r; memset(&r, 0, sizeof(r)); r.material = -1;
-	if (Traverse<STACK, false>(S, o, d, tMin, h, stk, c)) {
-		const Shade sh = LoadShade(S, h.tri);
+	if (Traverse<STACK, false>(S, o, d, 0.0f, tMin, h, stk, c)) {
 		Surf s;
-		BuildSurface(sh, o, d, h, s, false);
+		const int material = BuildSurface(S, o, d, h, s, false, c);
 		r.hit = 1; r.t = s.t;
 		r.p[0] = s.p.x; r.p[1] = s.p.y; r.p[2] = s.p.z;
 		r.n[0] = s.n.x; r.n[1] = s.n.y; r.n[2] = s.n.z;
-		r.paramU = s.U; r.paramV = s.V; r.material = sh.material;
+		r.paramU = s.U; r.paramV = s.V; r.material = material;
 	}
 	out[i] = r;
 }
@@ -1048,6 +1126,7 @@ k_eval_math(int fn, const float* __restrict__ x, const float* __restrict__ y, in
 struct DeviceScene {
 	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
 	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
+	DSphere* spheres = nullptr; DCube* cubes = nullptr;
 	DSceneView view;
 	SkyRot skyRot;
 	uint32_t bvhDepth = 0;
@@ -1168,9 +1247,25 @@ bool UploadScene(Scene& sc)
 	if (!Upload(D->materials, mats.data(), mats.size())) return false;
 	if (!Upload(D->textures, texs.data(), texs.size())) return false;
 	if (!Upload(D->texels, pool.data(), pool.size())) return false;
+	std::vector<DSphere> dsph(sc.spheres.size());
+	for (size_t i = 0; i < dsph.size(); ++i) {
+		memset(&dsph[i], 0, sizeof(DSphere));
+		dsph[i].center[0] = sc.spheres[i].center.x; dsph[i].center[1] = sc.spheres[i].center.y; dsph[i].center[2] = sc.spheres[i].center.z;
+		dsph[i].radius = sc.spheres[i].radius; dsph[i].material = sc.spheres[i].material;
+	}
+	std::vector<DCube> dcub(sc.cubes.size());
+	for (size_t i = 0; i < dcub.size(); ++i) {
+		memset(&dcub[i], 0, sizeof(DCube));
+		const HostCube& h = sc.cubes[i];
+		dcub[i].minBounds[0] = h.minBounds.x; dcub[i].minBounds[1] = h.minBounds.y; dcub[i].minBounds[2] = h.minBounds.z; dcub[i].timeStartMove = h.timeStartMove;
+		dcub[i].maxBounds[0] = h.maxBounds.x; dcub[i].maxBounds[1] = h.maxBounds.y; dcub[i].maxBounds[2] = h.maxBounds.z; dcub[i].material = h.material;
+		dcub[i].velocity[0] = h.velocity.x; dcub[i].velocity[1] = h.velocity.y; dcub[i].velocity[2] = h.velocity.z;
+	}
+	if (!Upload(D->spheres, dsph.data(), dsph.size())) return false;
+	if (!Upload(D->cubes, dcub.data(), dcub.size())) return false;
 	DSceneView& V = D->view;
 	V.nodes = D->nodes; V.isect = D->isect; V.shade = D->shade; V.materials = D->materials;
-	V.textures = D->textures; V.texels = D->texels;
+	V.textures = D->textures; V.texels = D->texels; V.spheres = D->spheres; V.cubes = D->cubes;
 	V.sunIlluminance[0] = sc.sunIlluminance.x; V.sunIlluminance[1] = sc.sunIlluminance.y; V.sunIlluminance[2] = sc.sunIlluminance.z;
 	V.sunDirection[0] = sc.sunDirection.x; V.sunDirection[1] = sc.sunDirection.y; V.sunDirection[2] = sc.sunDirection.z;
 	V.skyTexture = sc.skyTexture;
@@ -1409,7 +1504,7 @@ void DeviceReleaseScene(DeviceScene* D)
 	if (!D) return;
 	std::lock_guard<std::mutex> lk(g_rt.lock);
 	(void)hipFree(D->nodes); (void)hipFree(D->isect); (void)hipFree(D->shade);
-	(void)hipFree(D->materials); (void)hipFree(D->textures); (void)hipFree(D->texels);
+	(void)hipFree(D->materials); (void)hipFree(D->textures); (void)hipFree(D->texels); (void)hipFree(D->spheres); (void)hipFree(D->cubes);
 	delete D;
 }
 

@@ -74,13 +74,43 @@ void Scene::Finalize()
 		}
 		shapeBase += m->numShapes;
 	}
+	// elements added with Raylib_AddSceneElement: spheres, cubes, loose triangles; each brings its material
+	spheres.clear(); cubes.clear();
+	for (SceneElement* e : elements) {
+		const int32_t mat = (int32_t)materials.size();
+		HostMaterial hm = e->material->m;
+		for (int k = 0; k < 5; ++k) hm.tex[k] = -1;
+		materials.push_back(hm);
+		if (e->kind == PRIM_SPHERE) { HostSphere s; s.center = e->center; s.radius = e->radius; s.material = mat; spheres.push_back(s); }
+		else if (e->kind == PRIM_CUBE) { HostCube c; c.minBounds = e->minBounds; c.maxBounds = e->maxBounds; c.timeStartMove = e->timeStartMove; c.velocity = e->velocity; c.material = mat; cubes.push_back(c); }
+		else { HostTriangle t = e->tri; t.material = mat; t.shape = shapeBase++; triangles.push_back(t); }
+	}
 	skyTexture = -1;
 	if (sky) {
 		skyCopy = std::make_shared<Image>(*sky);
 		skyTexture = (int32_t)textures.size();
 		textures.push_back(skyCopy);
 	}
-	BuildBVH(triangles, bvh);
+	std::vector<PrimRef> prims;
+	prims.reserve(triangles.size() + spheres.size() + cubes.size());
+	for (size_t i = 0; i < triangles.size(); ++i) {
+		const HostTriangle& t = triangles[i];
+		PrimRef p; p.mn = fmin3(fmin3(t.v0, t.v1), t.v2); p.mx = fmax3(fmax3(t.v0, t.v1), t.v2); p.kind = PRIM_TRIANGLE; p.index = (uint32_t)i;
+		prims.push_back(p);
+	}
+	for (size_t i = 0; i < spheres.size(); ++i) {   // reference geom/sphere.cc:47-52
+		const f3 R = F3(spheres[i].radius, spheres[i].radius, spheres[i].radius);
+		PrimRef p; p.mn = spheres[i].center - R; p.mx = spheres[i].center + R; p.kind = PRIM_SPHERE; p.index = (uint32_t)i;
+		prims.push_back(p);
+	}
+	for (size_t i = 0; i < cubes.size(); ++i) {
+		// The reference builds its BVH with t0 = t1 = 0 (geom/scene.cc:28, geom/cube.cc:45-52): a moving cube that has left
+		// that box is not found by later rays.  A GPU build that wants the same pixels must cull with the same box.
+		const f3 m0 = cubes[i].velocity * (0.0f - cubes[i].timeStartMove > 0.0f ? 0.0f - cubes[i].timeStartMove : 0.0f);
+		PrimRef p; p.mn = cubes[i].minBounds + m0; p.mx = cubes[i].maxBounds + m0; p.kind = PRIM_CUBE; p.index = (uint32_t)i;
+		prims.push_back(p);
+	}
+	BuildBVH(prims, bvh);
 	// leaves that contain a triangle whose material has an albedo texture run the
 	// cut-out test inside traversal (reference geom/triangle.cc:54, material.cc:397-404)
 	std::vector<uint8_t> alpha(triangles.size(), 0);
@@ -92,7 +122,8 @@ void Scene::Finalize()
 	if (any) {
 		auto patch = [&](int32_t& ref) {
 			if (ref >= 0 || ref == DNODE_EMPTY) return;
-			uint32_t code = (uint32_t)~ref, first = code >> 4, count = (code & 7u) + 1;
+			uint32_t code = (uint32_t)~ref, first = code >> 6, count = (code & 7u) + 1;
+			if (((code >> 4) & 3u) != PRIM_TRIANGLE) return;
 			for (uint32_t k = 0; k < count; ++k) if (alpha[bvh.triOrder[first + k]]) { code |= 8u; break; }
 			ref = ~(int32_t)code;
 		};

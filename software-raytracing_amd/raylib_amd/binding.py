@@ -88,6 +88,12 @@ _EXPORTS = {
     "RaylibAMD_RenderCellsHost": (C.c_int32, [C.POINTER(RendererSettings), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "RaylibAMD_CellBufferFloats": (C.c_uint64, [C.c_uint32] * 4),
     "RaylibAMD_NumCells": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+    "RaylibAMD_CreateMaterial": (C.c_void_p, [C.c_int32, C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float), C.c_float]),
+    "RaylibAMD_DestroyMaterial": (C.c_int32, [C.c_void_p]),
+    "RaylibAMD_CreateSphere": (C.c_void_p, [C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "RaylibAMD_CreateCube": (C.c_void_p, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float), C.c_void_p]),
+    "RaylibAMD_CreateTriangle": (C.c_void_p, [C.POINTER(C.c_float)] * 7 + [C.c_void_p]),
+    "RaylibAMD_DestroySceneElement": (C.c_int32, [C.c_void_p]),
     "RaylibAMD_EvalDeviceMath": (C.c_int32, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "RaylibAMD_ClosestHit": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]),
     "RaylibAMD_SceneNumTriangles": (C.c_int32, [C.c_void_p]),
@@ -120,6 +126,65 @@ def load(path=LIB_PATH):
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def create_material(lib, mat):
+    """mat: one record of the oracle's MAT_DTYPE layout (type, albedo, roughness, metallic, emissive, ior, transmission, fuzziness)."""
+    return lib.RaylibAMD_CreateMaterial(int(mat["type"]), _f3(mat["albedo"]), float(mat["roughness"]), float(mat["metallic"]),
+                                        _f3(mat["emissive"]), float(mat["ior"]), _f3(mat["transmission"]), float(mat["fuzziness"]))
+
+
+class ProceduralSession:
+    """A scene made of analytic elements through the C-ABI (what the reference's CUI does with C++ objects,
+    src/main.cc:913-984): materials -> spheres / cubes -> Raylib_AddSceneElement -> FinalizeScene."""
+
+    def __init__(self, lib, materials, spheres=(), cubes=(), origin=(0, 0, 3), look_at=(0, 0, -1), fov=45.0, aspect=1.0,
+                 sun=(0, 0, 0), sun_dir=(0.0, -1.0, -0.5), aperture=0.0, focal=1.0, shutter=(0.0, 0.0)):
+        self.lib = lib
+        self.mats = [create_material(lib, m) for m in materials]
+        assert all(self.mats)
+        self.scene = lib.Raylib_CreateScene()
+        self.camera = lib.Raylib_CreateCamera()
+        self.elems = []
+        for s in spheres:
+            e = lib.RaylibAMD_CreateSphere(float(s["center"][0]), float(s["center"][1]), float(s["center"][2]), float(s["radius"]), self.mats[int(s["material"])])
+            self.elems.append(e); lib.Raylib_AddSceneElement(self.scene, e)
+        for c in cubes:
+            e = lib.RaylibAMD_CreateCube(_f3(c["minBounds"]), _f3(c["maxBounds"]), float(c["timeStartMove"]), _f3(c["velocity"]), self.mats[int(c["material"])])
+            self.elems.append(e); lib.Raylib_AddSceneElement(self.scene, e)
+        assert all(self.elems)
+        lib.Raylib_SetSunIlluminance(self.scene, *[float(x) for x in sun])
+        lib.Raylib_SetSunDirection(self.scene, *[float(x) for x in sun_dir])
+        lib.Raylib_FinalizeScene(self.scene)
+        lib.Raylib_CameraSetPosition(self.camera, *[float(x) for x in origin])
+        lib.Raylib_CameraSetLookAt(self.camera, *[float(x) for x in look_at])
+        lib.Raylib_CameraSetPerspective(self.camera, float(fov), float(aspect))
+        lib.Raylib_CameraSetLens(self.camera, float(aperture), float(focal))
+        lib.Raylib_CameraSetMotion(self.camera, float(shutter[0]), float(shutter[1]))
+
+    settings = None
+
+    def render(self, w, h, spp, max_path=5, tmin=1e-4, mode=RENDERMODE_DEFAULT):
+        lib = self.lib
+        st = RendererSettings(int(w), int(h), int(spp), int(max_path), float(tmin), int(mode))
+        img = lib.Raylib_CreateImage(w, h)
+        lib.Raylib_Render(C.byref(st), self.scene, self.camera, img)
+        out = np.zeros((h, w, 4), np.float32)
+        lib.RaylibAMD_DumpImageRGBA(img, _fp(out))
+        lib.Raylib_DestroyImage(img)
+        return out
+
+    def close(self):
+        lib = self.lib
+        lib.Raylib_DestroyScene(self.scene); lib.Raylib_DestroyCamera(self.camera)
+        for e in self.elems:
+            lib.RaylibAMD_DestroySceneElement(e)
+        for m in self.mats:
+            lib.RaylibAMD_DestroyMaterial(m)
 
 
 class SceneSession:

@@ -59,6 +59,21 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, "done", {k: v.shape for k, v in out.items() if k.startswith("mode0_spp")})
 
+    # ---- procedural scene: spheres, a moving cube, Metal / DiffuseLight / Dielectric / Mirror -----------------------
+    flat, c = helpers.procedural_flat()
+    scene = ref.scene_create(flat, BUILD_SEED)
+    cam = ffi.make_camera(c["origin"], c["look_at"], c["fov"], c["aspect"], c["aperture"], c["focal"], *c["shutter"])
+    out = {}
+    for spp in (1, 4, 16):
+        out["mode0_spp%d" % spp] = ref.render(scene, cam, ffi.make_settings(96, 64, spp), seed=SEED)
+    for mode in (1, 2, 5):
+        out["mode%d" % mode] = ref.render(scene, cam, ffi.make_settings(96, 64, 1, mode=mode), seed=SEED)
+    rays = helpers.random_rays(2048, 12, extent=2.0)
+    out["hit_rays"] = rays
+    out["hits"] = ref.closest_hit(scene, rays, 1e-4)
+    np.savez_compressed(os.path.join(HERE, "procedural.npz"), **out)
+    print("procedural done")
+
     # ---- function-level known answers ------------------------------------------------
     rng = np.random.RandomState(17)
     kat = {}

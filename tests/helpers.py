@@ -77,3 +77,34 @@ def random_rays(n, seed, extent=4.0):
     d = rng.normal(size=(n, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
     return np.concatenate([o, d.astype(np.float32)], axis=1).astype(np.float32)
+
+
+def procedural_case():
+    """Analytic scene in the spirit of the reference's FourSpheres / RandomSpheres demos (src/main.cc:913-984):
+    every material class, a moving cube (shutter open), depth of field, a sun."""
+    mats = np.zeros(6, ffi.MAT_DTYPE)
+    for m in mats:
+        for k in ("texAlbedo", "texNormal", "texRoughness", "texMetallic", "texEmissive"):
+            m[k] = -1
+        m["transmission"] = (1, 1, 1)
+    mats[0]["type"] = ffi.MAT_MICROFACET; mats[0]["albedo"] = (1, 1, 1); mats[0]["roughness"] = 0.0
+    mats[1]["type"] = ffi.MAT_DIELECTRIC; mats[1]["ior"] = 1.5; mats[1]["transmission"] = (1, 0.5, 0.5)
+    mats[2]["type"] = ffi.MAT_LAMBERTIAN; mats[2]["albedo"] = (0.8, 0.3, 0.3)
+    mats[3]["type"] = ffi.MAT_METAL; mats[3]["albedo"] = (0.8, 0.6, 0.2); mats[3]["fuzziness"] = 0.3
+    mats[4]["type"] = ffi.MAT_DIFFUSE_LIGHT; mats[4]["albedo"] = (4, 4, 4)
+    mats[5]["type"] = ffi.MAT_MIRROR; mats[5]["albedo"] = (0.9, 0.9, 0.95)
+    sph = np.zeros(5, ffi.SPHERE_DTYPE)
+    sph[0] = ((0, -100.5, -1), 100.0, 0); sph[1] = ((-1, 0.02, -1), 0.5, 1); sph[2] = ((0, 0.02, -1), 0.5, 2)
+    sph[3] = ((1, 0.02, -1), 0.5, 3); sph[4] = ((0, 2.5, -1), 0.7, 4)
+    cub = np.zeros(2, ffi.CUBE_DTYPE)
+    cub[0] = ((-0.3, -0.45, 0.2), (0.3, -0.1, 0.6), 0.0, (0.5, 0, 0), 2)
+    cub[1] = ((1.2, -0.45, -0.3), (1.6, 0.4, 0.1), 0.0, (0, 0, 0), 5)
+    cam = dict(origin=(0, 0.5, 3), look_at=(0, 0, -1), fov=45.0, aspect=1.5, aperture=0.05, focal=4.0, shutter=(0.0, 1.0),
+               sun=(1, 1, 1), sun_dir=(0.0, -1.0, -0.3))
+    return mats, sph, cub, cam
+
+
+def procedural_flat():
+    mats, sph, cub, cam = procedural_case()
+    return ffi.FlatScene(np.zeros(0, ffi.TRI_DTYPE), mats, spheres=sph, cubes=cub, num_shapes=0,
+                         sun_illuminance=cam["sun"], sun_direction=cam["sun_dir"]), cam

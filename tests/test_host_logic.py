@@ -196,6 +196,34 @@ def test_postprocess_matches_oracle(lib, oracle):
     lib.Raylib_DestroyImage(ih)
 
 
+def test_procedural_elements_registry(lib):
+    """Materials / elements made by the library are accepted by Raylib_AddSceneElement; anything else is refused."""
+    import ctypes as C
+    f3 = lambda *v: (C.c_float * 3)(*v)
+    m = lib.RaylibAMD_CreateMaterial(0, f3(2.0, 0.5, -1.0), 0.0, 0.0, None, 0.0, None, 0.0)
+    assert m and lib.RaylibAMD_CreateMaterial(9, None, 0, 0, None, 0, None, 0) is None
+    sp = lib.RaylibAMD_CreateSphere(0.0, 0.0, 0.0, 1.0, m)
+    cu = lib.RaylibAMD_CreateCube(f3(0, 0, 0), f3(1, 1, 1), 0.0, f3(0, 0, 0), m)
+    tr = lib.RaylibAMD_CreateTriangle(f3(0, 0, 0), f3(1, 0, 0), f3(0, 1, 0), f3(0, 0, 1), f3(0, 0, 1), f3(0, 0, 1), None, m)
+    assert sp and cu and tr
+    assert lib.RaylibAMD_CreateSphere(0.0, 0.0, 0.0, 1.0, 12345) is None          # not a material of this library
+    sc = lib.Raylib_CreateScene()
+    for e in (sp, cu, tr):
+        lib.Raylib_AddSceneElement(sc, e)
+    lib.Raylib_AddSceneElement(sc, 0xdeadbeef)                                     # foreign pointer: ignored with a log line
+    lib.Raylib_FinalizeScene(sc)
+    assert lib.RaylibAMD_SceneNumTriangles(sc) == 1 and lib.RaylibAMD_SceneNumMaterials(sc) == 3
+    mats = np.zeros(3, ffi.MAT_DTYPE)
+    lib.RaylibAMD_SceneExportMaterials(sc, mats.ctypes.data)
+    assert np.array_equal(mats["albedo"][0], np.array([1.0, 0.5, 0.0], np.float32))   # Lambertian saturates (material.h:79-82)
+    nodes, depth, sah = C.c_uint32(), C.c_uint32(), C.c_float()
+    assert lib.RaylibAMD_SceneBVHInfo(sc, C.byref(nodes), C.byref(depth), C.byref(sah)) == 1 and nodes.value >= 2
+    assert lib.Raylib_DestroyScene(sc) == 1
+    for e in (sp, cu, tr):
+        assert lib.RaylibAMD_DestroySceneElement(e) == 1 and lib.RaylibAMD_DestroySceneElement(e) == 0
+    assert lib.RaylibAMD_DestroyMaterial(m) == 1 and lib.RaylibAMD_DestroyMaterial(m) == 0
+
+
 def test_cell_math(lib):
     from raylib_amd import tiling
     for (w, h) in ((64, 64), (40, 28), (1920, 1080), (7, 9)):
