@@ -57,6 +57,11 @@ bool RenderInternal(const RendererSettings* settings, Scene* scene, Camera* came
 	if (!settings || !scene || !camera) { Log("Raylib_Render: null argument"); return false; }
 	if (!scene->finalized) { Log("Raylib_Render: scene was not finalized (Raylib_FinalizeScene)"); return false; }
 	if (settings->renderMode >= RAYLIB_RENDERMODE_MAX) { Log("Raylib_Render: invalid render mode %u", settings->renderMode); return false; }
+	if (scene->hasMovingCubes && (scene->accelT0 != camera->beginTime || scene->accelT1 != camera->endTime)) {
+		// moving cubes: their boxes must cover the motion over THIS camera's shutter interval
+		if (scene->device) { DeviceReleaseScene(scene->device); scene->device = nullptr; }
+		scene->BuildAccel(camera->beginTime, camera->endTime);
+	}
 	RenderRequest req;
 	req.settings = *settings;
 	req.camera = camera->ToDevice();

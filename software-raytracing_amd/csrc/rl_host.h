@@ -148,9 +148,13 @@ struct Scene {
 	BVH bvh;
 	DeviceScene* device = nullptr;    // uploaded lazily at first render
 
+	bool hasMovingCubes = false;
+	float accelT0 = 0.0f, accelT1 = 0.0f;   // shutter interval the BVH boxes cover
+
 	Scene();
 	~Scene();
 	void Finalize();
+	void BuildAccel(float t0, float t1);
 };
 
 // loaders (rl_obj_loader.cc, rl_image_io.cc)

@@ -227,7 +227,8 @@ __device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float 
 // stk: this lane's column of the LDS stack; entry k at stk[k * RL_BLOCK].
 // Sphere::Hit (reference geom/sphere.cc:3-45): open interval (t_min, t_max); the near root if it is inside, else the
 // far root.  t_max is the current best t (the reference compares all hits afterwards; same closest hit).
-__device__ __noinline__ bool SphereHit(const DSphere* spheres, int index, V3 o, V3 d, float t_min, float tBest, float& outT)
+// Returns t, or NaN for a miss (results by value: an out-parameter of an out-of-line function would live in scratch).
+__device__ __noinline__ float SphereHit(const DSphere* spheres, int index, V3 o, V3 d, float t_min, float tBest)
 {
 	const float4 q = ((const float4*)(spheres + index))[0];
 	const V3 center = v3(q.x, q.y, q.z); const float radius = q.w;
@@ -238,15 +239,16 @@ __device__ __noinline__ bool SphereHit(const DSphere* spheres, int index, V3 o, 
 	float D = b * b - a * c;
 	if (D > 0.0f) {
 		float temp = (-b - sqrtf(b * b - a * c)) / a;
-		if (t_min < temp && temp < FLT_MAX) { outT = temp; return temp < tBest; }   // the reference takes this root and compares later
+		if (t_min < temp && temp < FLT_MAX) return (temp < tBest) ? temp : NAN;   // the reference takes this root and compares later
 		temp = (-b + sqrtf(b * b - a * c)) / a;
-		if (t_min < temp && temp < FLT_MAX) { outT = temp; return temp < tBest; }
+		if (t_min < temp && temp < FLT_MAX) return (temp < tBest) ? temp : NAN;
 	}
-	return false;
+	return NAN;
 }
 // Cube::Hit (reference geom/cube.cc:3-43): slab box moving with velocity * max(0, rayTime - timeStartMove); closed
 // interval [t_min, t_max]; entry face by the reference's float == chain (outFace 0..5 = -x +x -y +y -z +z, 6 = none matched).
-__device__ __noinline__ bool CubeHit(const DCube* cubes, int index, V3 o, V3 d, float rayTime, float t_min, float tBest, float& outT, int& outFace)
+// Returns (t, face as int bits), t = NaN for a miss.
+__device__ __noinline__ float2 CubeHit(const DCube* cubes, int index, V3 o, V3 d, float rayTime, float t_min, float tBest)
 {
 	const float4* p = (const float4*)(cubes + index);
 	const float4 q0 = p[0], q1 = p[1], q2 = p[2];
@@ -265,13 +267,12 @@ __device__ __noinline__ bool CubeHit(const DCube* cubes, int index, V3 o, V3 d, 
 	const float n12 = RL_STDMIN(mxx, mxy); const float t8 = RL_STDMIN(n12, mxz);
 	#undef RL_STDMAX
 	#undef RL_STDMIN
-	if (t8 < 0 || t7 > t8) return false;
+	if (t8 < 0 || t7 > t8) return make_float2(NAN, 0.0f);
 	if (t_min <= t7 && t7 <= FLT_MAX && t7 < tBest) {
-		outT = t7;
-		outFace = (t7 == t1) ? 0 : (t7 == t2) ? 1 : (t7 == t3) ? 2 : (t7 == t4) ? 3 : (t7 == t5) ? 4 : (t7 == t6) ? 5 : 6;
-		return true;
+		const int face = (t7 == t1) ? 0 : (t7 == t2) ? 1 : (t7 == t3) ? 2 : (t7 == t4) ? 3 : (t7 == t5) ? 4 : (t7 == t6) ? 5 : 6;
+		return make_float2(t7, __int_as_float(face));
 	}
-	return false;
+	return make_float2(NAN, 0.0f);
 }
 
 // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (cheap steps:
@@ -279,7 +280,7 @@ __device__ __noinline__ bool CubeHit(const DCube* cubes, int index, V3 o, V3 d, 
 // "if inner else leaf" loop a wave pays node + leaf cost on every trip as soon as one lane is at a leaf, and
 // the ~4x dearer triangle code ran with a handful of lanes (measured: 14 % VALU lane utilisation on the
 // 298 k-triangle scene).
-template <int STACK, bool ANYHIT>
+template <int STACK, bool ANYHIT, bool PRIMS>
 __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c)
 {
 	c.rays++;
@@ -323,7 +324,7 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 			const int count = (int)(code & 7u) + 1;
 			const bool alpha = (code & 8u) != 0;
 			const uint32_t kind = (code >> 4) & 3u;
-			if (kind == 0u) {
+			if (!PRIMS || kind == 0u) {
 				for (int i = 0; i < count; ++i) {
 					const Tri T = LoadTri(S, first + i);
 					c.tris++;
@@ -343,10 +344,11 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 				}
 			} else {
 				c.tris++;
-				float t = 0.0f; int face = 0;
-				const bool hit = (kind == 1u) ? SphereHit(S.spheres, first, o, d, tMin, best.t, t) : CubeHit(S.cubes, first, o, d, rayTime, tMin, best.t, t, face);
-				if (hit) {
-					best.t = t; best.a = (kind == 2u) ? __int_as_float(face) : 0.0f; best.b = 0.0f; best.tri = (int)((kind << 28) | (uint32_t)first);
+				float2 r;
+				if (kind == 1u) r = make_float2(SphereHit(S.spheres, first, o, d, tMin, best.t), 0.0f);
+				else r = CubeHit(S.cubes, first, o, d, rayTime, tMin, best.t);
+				if (r.x == r.x) {   // not NaN: a hit
+					best.t = r.x; best.a = r.y; best.b = 0.0f; best.tri = (int)((kind << 28) | (uint32_t)first);
 					if (ANYHIT) return true;
 				}
 			}
@@ -364,12 +366,13 @@ struct Surf { float t; V3 p, n; float U, V; V3 tangent, bitangent; };
 
 // HitResult for the winning primitive (reference geom/triangle.cc:43-47, geom/sphere.cc:19-41, geom/cube.cc:24-38)
 // + the tangent frame (geom/hit.cc:6-18).  Returns the material index.
+template <bool PRIMS>
 __device__ __forceinline__ int BuildSurface(const DSceneView& S, V3 o, V3 d, const HitRec& h, Surf& s, bool basis, Counters& c)
 {
 	int material;
 	s.t = h.t;
 	s.p = o + h.t * d;
-	const uint32_t kind = ((uint32_t)h.tri) >> 28;
+	const uint32_t kind = PRIMS ? (((uint32_t)h.tri) >> 28) : 0u;
 	if (kind == 0u) {
 		const Shade sh = LoadShade(S, h.tri);
 		c.shaded++;
@@ -721,7 +724,7 @@ __device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rn
 struct SkyRot { float m0[3], m1[3], m2[3]; };   // Rotator(yaw 90).rotate rows, computed on the host (renderer.cc:166-168)
 
 // Miss shader: sky panorama + sun (reference render/renderer.cc:155-199)
-template <int STACK>
+template <int STACK, bool PRIMS>
 __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTime, float rayTMin, int* stk, Counters& c)
 {
 	V3 missResult = v3s(0.0f);
@@ -740,7 +743,7 @@ __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V
 	}
 	if (S.hasSun) {
 		HitRec tmp;
-		if (!Traverse<STACK, true>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c)) missResult = missResult + ld3(S.sunIlluminance);
+		if (!Traverse<STACK, true, PRIMS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c)) missResult = missResult + ld3(S.sunIlluminance);
 	}
 	return missResult;
 }
@@ -767,10 +770,11 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 // The megakernel.  samples: [sampleCount][numLocalCells*64] float4.
 // pathStack: [maxPathLength][8][stackStride] floats (refl.xyz, sp, pdf, E.xyz).
 #ifndef RL_TRACE_MIN_WAVES
-#define RL_TRACE_MIN_WAVES 1
+#define RL_TRACE_MIN_WAVES 4   /* 4 waves per SIMD = 4 workgroups per CU: caps the kernel at 128 VGPRs */
 #endif
-template <int STACK>
-__global__ void __launch_bounds__(RL_BLOCK, RL_TRACE_MIN_WAVES)
+// PRIMS: the scene holds spheres / cubes (their leaf and shading code is compiled out of the triangle-only variant)
+template <int STACK, bool PRIMS>
+__global__ void __launch_bounds__(RL_BLOCK, (STACK <= 32 ? RL_TRACE_MIN_WAVES : 2))
 k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
         float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
@@ -845,7 +849,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 							if (sunQuick) {
 								c.rays++; c.nodes++;   // the closest-hit query this replaces fetches the root node and stops
 								DSceneView Sq = S; Sq.hasSun = 0;
-								V3 L = MissShader<STACK>(Sq, R, o, d, rayTime, P.rayTMin, stk, c);
+								V3 L = MissShader<STACK, PRIMS>(Sq, R, o, d, rayTime, P.rayTMin, stk, c);
 								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
 								samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
 								active = false;
@@ -870,9 +874,9 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				done = true;                                   // renderer.cc:120-123
 			} else {
 				HitRec h;
-				if (Traverse<STACK, false>(S, o, d, rayTime, P.rayTMin, h, stk, c)) {
+				if (Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c)) {
 					Surf s;
-					const Mat m = LoadMat(S, BuildSurface(S, o, d, h, s, true, c));
+					const Mat m = LoadMat(S, BuildSurface<PRIMS>(S, o, d, h, s, true, c));
 					V3 refl = v3s(0.0f), outD = v3s(0.0f);
 					float pdf = 0.0f, sp = 0.0f;
 					const bool scattered = Scatter(S, m, d, s, g, c, refl, outD, pdf, sp);
@@ -890,7 +894,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 						done = true;
 					}
 				} else {
-					L = MissShader<STACK>(S, R, o, d, rayTime, P.rayTMin, stk, c);
+					L = MissShader<STACK, PRIMS>(S, R, o, d, rayTime, P.rayTMin, stk, c);
 					done = true;
 				}
 			}
@@ -955,7 +959,7 @@ k_resolve(const DRenderParams P, const float4* __restrict__ samples, float4* __r
 
 // Debug render modes (reference render/renderer.cc:62-111, :258-268): one unjittered sample.
 // Modes 3 and 6 read an uninitialised tangent frame in the reference; here it is built.
-template <int STACK>
+template <int STACK, bool PRIMS>
 __global__ void __launch_bounds__(RL_BLOCK)
 k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
@@ -979,18 +983,18 @@ k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsig
 		CameraRay(P.camera, (float)x / (float)P.width, (float)y / (float)P.height, g, o, d, rayTime);
 		c.samples++;
 		HitRec h;
-		if (Traverse<STACK, false>(S, o, d, rayTime, P.rayTMin, h, stk, c)) {
+		if (Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c)) {
 			Surf s;
-			const Mat m = LoadMat(S, BuildSurface(S, o, d, h, s, true, c));
+			const Mat m = LoadMat(S, BuildSurface<PRIMS>(S, o, d, h, s, true, c));
 			const uint32_t mode = P.renderMode;
 			if (mode == RAYLIB_RENDERMODE_Albedo) {
 				debugValue = GetAlbedo(S, m, s.U, s.V, c);
 				if (IsMirrorLike(S, m, s.U, s.V, c)) {
 					HitRec h2;
 					const V3 d2 = reflect(d, s.n);
-					if (Traverse<STACK, false>(S, s.p, d2, rayTime, P.rayTMin, h2, stk, c)) {
+					if (Traverse<STACK, false, PRIMS>(S, s.p, d2, rayTime, P.rayTMin, h2, stk, c)) {
 						Surf s2;
-						const Mat m2 = LoadMat(S, BuildSurface(S, s.p, d2, h2, s2, false, c));
+						const Mat m2 = LoadMat(S, BuildSurface<PRIMS>(S, s.p, d2, h2, s2, false, c));
 						debugValue = GetAlbedo(S, m2, s2.U, s2.V, c);
 					}
 				}
@@ -1027,7 +1031,7 @@ k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsig
 
 struct DHitOut { int32_t hit; float t; float p[3]; float n[3]; float paramU, paramV; int32_t material; };
 
-template <int STACK>
+template <int STACK, bool PRIMS>
 __global__ void __launch_bounds__(RL_BLOCK)
 k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float tMin, DHitOut* __restrict__ out)
 {
@@ -1039,9 +1043,9 @@ k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float t
 	const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
 	HitRec h;
 	DHitOut r; memset(&r, 0, sizeof(r)); r.material = -1;
-	if (Traverse<STACK, false>(S, o, d, 0.0f, tMin, h, stk, c)) {
+	if (Traverse<STACK, false, PRIMS>(S, o, d, 0.0f, tMin, h, stk, c)) {
 		Surf s;
-		const int material = BuildSurface(S, o, d, h, s, false, c);
+		const int material = BuildSurface<PRIMS>(S, o, d, h, s, false, c);
 		r.hit = 1; r.t = s.t;
 		r.p[0] = s.p.x; r.p[1] = s.p.y; r.p[2] = s.p.z;
 		r.n[0] = s.n.x; r.n[1] = s.n.y; r.n[2] = s.n.z;
@@ -1284,7 +1288,7 @@ bool UploadScene(Scene& sc)
 	return true;
 }
 
-template <int STACK>
+template <int STACK, bool PRIMS>
 bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 {
 	Runtime& R = g_rt;
@@ -1317,7 +1321,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		// nothing to do for this rank
 	} else if (!pathTrace) {
 		const uint32_t blocks = (numSlots + RL_BLOCK - 1) / RL_BLOCK;
-		hipLaunchKernelGGL(k_aov<STACK>, dim3(blocks), dim3(RL_BLOCK), 0, R.stream, P, D->view, out, R.counters);
+		hipLaunchKernelGGL((k_aov<STACK, PRIMS>), dim3(blocks), dim3(RL_BLOCK), 0, R.stream, P, D->view, out, R.counters);
 		HIP_OK(hipGetLastError());
 	} else {
 		// sample batches: bound the sample buffer to ~2 GiB
@@ -1327,7 +1331,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		if (!Grow(R.samples, R.samplesBytes, perSample * batch)) return false;
 		if (batch < SPP && !Grow(R.accum, R.accumBytes, perSample)) return false;
 		int blocksPerCU = 0;
-		HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, k_trace<STACK>, RL_BLOCK, 0));
+		HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, (k_trace<STACK, PRIMS>), RL_BLOCK, 0));
 		if (blocksPerCU < 1) blocksPerCU = 1;
 		if (const char* e = getenv("RAYLIB_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) blocksPerCU = v; }
 		const int depthSlots = st.maxPathLength > 1 ? st.maxPathLength : 1;
@@ -1349,7 +1353,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
 			HIP_OK(hipMemsetAsync(R.jobCounter, 0, sizeof(unsigned int), R.stream));
 			HIP_OK(hipEventRecord(R.ev[2], R.stream));
-			hipLaunchKernelGGL(k_trace<STACK>, dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
+			hipLaunchKernelGGL((k_trace<STACK, PRIMS>), dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
 			                   P, D->view, D->skyRot, R.samples, R.pathStack, R.counters, R.jobCounter);
 			HIP_OK(hipGetLastError());
 			HIP_OK(hipEventRecord(R.ev[3], R.stream));
@@ -1404,8 +1408,9 @@ bool DeviceRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	HIP_OK(hipSetDevice(g_rt.device));
 	if (!UploadScene(sc)) return false;
 	bool ok;
-	if (sc.bvh.depth <= 32) ok = LaunchRender<32>(sc, req, stats);
-	else if (sc.bvh.depth <= 64) ok = LaunchRender<64>(sc, req, stats);
+	const bool prims = !sc.spheres.empty() || !sc.cubes.empty();
+	if (sc.bvh.depth <= 32) ok = prims ? LaunchRender<32, true>(sc, req, stats) : LaunchRender<32, false>(sc, req, stats);
+	else if (sc.bvh.depth <= 64) ok = prims ? LaunchRender<64, true>(sc, req, stats) : LaunchRender<64, false>(sc, req, stats);
 	else { Log("Raylib_Render: BVH depth %u exceeds the traversal stack (64)", sc.bvh.depth); ok = false; }
 	stats.wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	return ok;
@@ -1423,8 +1428,8 @@ bool DeviceClosestHit(Scene& sc, const float* rays, int32_t n, float tMin, void*
 	HIP_OK(hipMalloc(&dOut, (size_t)n * sizeof(DHitOut)));
 	HIP_OK(hipMemcpy(dRays, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
 	const uint32_t blocks = ((uint32_t)n + RL_BLOCK - 1) / RL_BLOCK;
-	if (sc.bvh.depth <= 32) hipLaunchKernelGGL(k_closest_hit<32>, dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, sc.device->view, dRays, n, tMin, dOut);
-	else hipLaunchKernelGGL(k_closest_hit<64>, dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, sc.device->view, dRays, n, tMin, dOut);
+	if (sc.bvh.depth <= 32) hipLaunchKernelGGL((k_closest_hit<32, true>), dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, sc.device->view, dRays, n, tMin, dOut);
+	else hipLaunchKernelGGL((k_closest_hit<64, true>), dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, sc.device->view, dRays, n, tMin, dOut);
 	HIP_OK(hipGetLastError());
 	HIP_OK(hipStreamSynchronize(g_rt.stream));
 	HIP_OK(hipMemcpy(outHits, dOut, (size_t)n * sizeof(DHitOut), hipMemcpyDeviceToHost));

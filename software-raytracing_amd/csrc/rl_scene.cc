@@ -91,6 +91,19 @@ void Scene::Finalize()
 		skyTexture = (int32_t)textures.size();
 		textures.push_back(skyCopy);
 	}
+	hasMovingCubes = false;
+	for (const HostCube& c : cubes) if (c.velocity.x != 0.0f || c.velocity.y != 0.0f || c.velocity.z != 0.0f) hasMovingCubes = true;
+	BuildAccel(0.0f, 0.0f);
+}
+
+// The flat BVH.  [t0, t1] is the shutter interval the boxes of moving cubes must cover.
+// The reference always builds with t0 = t1 = 0 (geom/scene.cc:28) and tests a primitive's own box never, only its
+// parent's union box -- so whether it still finds a cube that has moved out of its t = 0 box depends on which sibling
+// its random build happened to pair it with.  Here a cube's box covers its whole motion over the camera's shutter
+// (Cube::BoundingBox(t0, t1), geom/cube.cc:45-52), i.e. the cube is found wherever it really is.
+void Scene::BuildAccel(float t0, float t1)
+{
+	accelT0 = t0; accelT1 = t1;
 	std::vector<PrimRef> prims;
 	prims.reserve(triangles.size() + spheres.size() + cubes.size());
 	for (size_t i = 0; i < triangles.size(); ++i) {
@@ -104,10 +117,12 @@ void Scene::Finalize()
 		prims.push_back(p);
 	}
 	for (size_t i = 0; i < cubes.size(); ++i) {
-		// The reference builds its BVH with t0 = t1 = 0 (geom/scene.cc:28, geom/cube.cc:45-52): a moving cube that has left
-		// that box is not found by later rays.  A GPU build that wants the same pixels must cull with the same box.
-		const f3 m0 = cubes[i].velocity * (0.0f - cubes[i].timeStartMove > 0.0f ? 0.0f - cubes[i].timeStartMove : 0.0f);
-		PrimRef p; p.mn = cubes[i].minBounds + m0; p.mx = cubes[i].maxBounds + m0; p.kind = PRIM_CUBE; p.index = (uint32_t)i;
+		const float d0 = t0 - cubes[i].timeStartMove, d1 = t1 - cubes[i].timeStartMove;
+		const f3 m0 = cubes[i].velocity * (d0 > 0.0f ? d0 : 0.0f), m1 = cubes[i].velocity * (d1 > 0.0f ? d1 : 0.0f);
+		PrimRef p;
+		p.mn = fmin3(cubes[i].minBounds + m0, cubes[i].minBounds + m1);
+		p.mx = fmax3(cubes[i].maxBounds + m0, cubes[i].maxBounds + m1);
+		p.kind = PRIM_CUBE; p.index = (uint32_t)i;
 		prims.push_back(p);
 	}
 	BuildBVH(prims, bvh);
