@@ -768,7 +768,7 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 
 // ---------------------------------------------------------------------------
 // The megakernel.  samples: [sampleCount][numLocalCells*64] float4.
-// pathStack: [maxPathLength][8][stackStride] floats (refl.xyz, sp, pdf, E.xyz).
+// pathStack: [maxPathLength][stackStride] records of 2 float4 (refl.xyz, sp | pdf, E.xyz).
 #ifndef RL_TRACE_MIN_WAVES
 #define RL_TRACE_MIN_WAVES 4   /* 4 waves per SIMD = 4 workgroups per CU: caps the kernel at 128 VGPRs */
 #endif
@@ -882,10 +882,10 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 					const bool scattered = Scatter(S, m, d, s, g, c, refl, outD, pdf, sp);
 					const V3 E = Emitted(S, m, s, c);
 					if (scattered && pdf > 0.0f) {
-						float* st = pathStack + (size_t)depth * 8u * P.stackStride + gtid;
-						st[0] = refl.x; st[P.stackStride] = refl.y; st[2 * (size_t)P.stackStride] = refl.z;
-						st[3 * (size_t)P.stackStride] = sp; st[4 * (size_t)P.stackStride] = pdf;
-						st[5 * (size_t)P.stackStride] = E.x; st[6 * (size_t)P.stackStride] = E.y; st[7 * (size_t)P.stackStride] = E.z;
+						// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
+						float4* st = (float4*)pathStack + ((size_t)depth * P.stackStride + gtid) * 2u;
+						st[0] = make_float4(refl.x, refl.y, refl.z, sp);
+						st[1] = make_float4(pdf, E.x, E.y, E.z);
 						o = s.p; d = outD;
 						depth++;
 						if (depth >= P.maxPathLength) done = true;   // the next TraceScene returns 0 at once (renderer.cc:120-123); L stays 0
@@ -901,10 +901,11 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 			if (done) {
 				// fold back to the camera: radiance = (0 + refl*Li*sp/pdf) + E at every vertex
 				for (int k = depth - 1; k >= 0; --k) {
-					const float* st = pathStack + (size_t)k * 8u * P.stackStride + gtid;
-					const V3 refl = v3(st[0], st[P.stackStride], st[2 * (size_t)P.stackStride]);
-					const float sp = st[3 * (size_t)P.stackStride], pdf = st[4 * (size_t)P.stackStride];
-					const V3 E = v3(st[5 * (size_t)P.stackStride], st[6 * (size_t)P.stackStride], st[7 * (size_t)P.stackStride]);
+					const float4* st = (const float4*)pathStack + ((size_t)k * P.stackStride + gtid) * 2u;
+					const float4 r0 = st[0], r1 = st[1];
+					const V3 refl = v3(r0.x, r0.y, r0.z);
+					const float sp = r0.w, pdf = r1.x;
+					const V3 E = v3(r1.y, r1.z, r1.w);
 					V3 radiance = v3s(0.0f);
 					radiance = radiance + refl * L * sp / pdf;
 					radiance = radiance + E;
