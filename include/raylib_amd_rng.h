@@ -48,12 +48,18 @@ RAYLIB_RNG_FN uint64_t raylib_rng_mix64(uint64_t z)
 	return z ^ (z >> 31);
 }
 
-RAYLIB_RNG_FN RaylibRngStream raylib_rng_begin(uint64_t seed, uint32_t pixelIndex, uint32_t sampleIndex)
+/* mixedSeed = raylib_rng_mix64(seed): the same for every stream of a render, so callers may hoist it. */
+RAYLIB_RNG_FN RaylibRngStream raylib_rng_begin_mixed(uint64_t mixedSeed, uint32_t pixelIndex, uint32_t sampleIndex)
 {
 	RaylibRngStream s;
 	uint64_t key = ((uint64_t)pixelIndex << 32) | (uint64_t)sampleIndex;
-	s.state = raylib_rng_mix64(raylib_rng_mix64(seed) ^ key);
+	s.state = raylib_rng_mix64(mixedSeed ^ key);
 	return s;
+}
+
+RAYLIB_RNG_FN RaylibRngStream raylib_rng_begin(uint64_t seed, uint32_t pixelIndex, uint32_t sampleIndex)
+{
+	return raylib_rng_begin_mixed(raylib_rng_mix64(seed), pixelIndex, sampleIndex);
 }
 
 RAYLIB_RNG_FN uint32_t raylib_rng_next_u32(RaylibRngStream* s)

@@ -119,6 +119,9 @@ struct DRenderParams {
 	uint32_t stackStride;      // threads in the grid (path-stack column count)
 	uint32_t rowMajorOutput;   // 1: out[y*W+x]; 0: out[localCell*64 + p]
 	uint32_t jobChunk;         // jobs a wave takes from the global counter per atomic
+	uint32_t magicSamples;     // floor(2^32 / sampleCount), floor(2^32 / cellsX): division by multiply-high in DecodeJob
+	uint32_t magicCellsX;
+	uint64_t seedMixed;        // raylib_rng_mix64(seed), hoisted out of the per-sample stream set-up
 	DCamera camera;
 };
 

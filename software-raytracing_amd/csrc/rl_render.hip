@@ -755,10 +755,14 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 	JobPixel j;
 	const uint32_t p = job & 63u;
 	const uint32_t rest = job >> 6;
-	const uint32_t sLocal = rest % P.sampleCount;
-	const uint32_t cellLocal = rest / P.sampleCount;
+	// n / d with d fixed per launch: q = mulhi(n, floor(2^32 / d)) is at most a few short; correct it
+	uint32_t cellLocal = __umulhi(rest, P.magicSamples);
+	uint32_t sLocal = rest - cellLocal * P.sampleCount;
+	while (sLocal >= P.sampleCount) { sLocal -= P.sampleCount; ++cellLocal; }
 	const uint32_t cell = P.cellFirst + cellLocal * P.cellStride;
-	const uint32_t cx = cell % P.cellsX, cy = cell / P.cellsX;
+	uint32_t cy = __umulhi(cell, P.magicCellsX);
+	uint32_t cx = cell - cy * P.cellsX;
+	while (cx >= P.cellsX) { cx -= P.cellsX; ++cy; }
 	j.x = cx * 8u + (p & 7u); j.y = cy * 8u + (p >> 3);
 	j.slot = cellLocal * 64u + p;
 	j.sample = sLocal;
@@ -828,7 +832,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 					if (j.valid) {
 						// GenerateCell body, reference render/renderer.cc:232-239
 						const uint32_t s = P.sampleBegin + j.sample;
-						g.s = raylib_rng_begin(P.seed, j.y * P.width + j.x, s);
+						g.s = raylib_rng_begin_mixed(P.seedMixed, j.y * P.width + j.x, s);
 						const float imageWidth = (float)P.width, imageHeight = (float)P.height;
 						float u = (float)j.x / imageWidth;
 						float v = (float)j.y / imageHeight;
@@ -1309,6 +1313,8 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	P.renderMode = st.renderMode; P.seed = req.seed; P.cellsX = cellsX; P.cellsY = cellsY;
 	P.cellFirst = req.cellFirst; P.cellStride = stride; P.numLocalCells = numLocalCells;
 	P.rowMajorOutput = rowMajor ? 1u : 0u; P.camera = req.camera;
+	P.seedMixed = raylib_rng_mix64(req.seed);
+	P.magicCellsX = cellsX > 1 ? (uint32_t)(0x100000000ull / cellsX) : 0xFFFFFFFFu;
 
 	const size_t outBytes = rowMajor ? (size_t)W * H * sizeof(float4) : (size_t)numSlots * sizeof(float4);
 	float4* out = (float4*)req.outDevice;
@@ -1339,6 +1345,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		for (uint32_t s0 = 0; s0 < SPP; s0 += batch) {
 			const uint32_t cnt = std::min(batch, SPP - s0);
 			P.sampleBegin = s0; P.sampleCount = cnt;
+			P.magicSamples = cnt > 1 ? (uint32_t)(0x100000000ull / cnt) : 0xFFFFFFFFu;
 			const uint64_t jobs64 = (uint64_t)numLocalCells * cnt * 64u;
 			if (jobs64 > 0xFFFFFF00ull) { Log("Raylib_Render: job count overflow"); return false; }
 			P.numJobs = (uint32_t)jobs64;
