@@ -324,6 +324,24 @@ RLM_FN void sincosf_both(float y, float* outSin, float* outCos)
 	*outCos = sincosf_<1>(y);
 }
 
+// Signs of sinf(y) and cosf(y) as glibc returns them (bit 31 of the results), without the polynomials: the quadrant n and
+// the sign of the reduced argument decide them (an odd polynomial has its argument's sign, the cosine polynomial is positive
+// on [-pi/4, pi/4], table [1] negates it).  Valid for 0 <= y < 120; used where only +-0 products of the values matter.
+RLM_FN void sincosf_signs(float y, bool* sinNeg, bool* cosNeg)
+{
+	const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p+0;
+	const uint32_t top = (asuint(y) >> 20) & 0x7ff;
+	if (top < ((asuint(0x1p-12f) >> 20) & 0x7ff)) { *sinNeg = (asuint(y) >> 31) != 0; *cosNeg = false; return; }
+	double x = (double)y;
+	double r = x * hpi_inv;
+	int n = ((int32_t)r + 0x800000) >> 24;
+	x = fma_(-(double)n, hpi, x);
+	const bool xsNeg = (asuint64(x * sincosf_sign(n)) >> 63) != 0;
+	const bool tab1 = (n & 2) != 0;
+	*sinNeg = (n & 1) ? tab1 : xsNeg;
+	*cosNeg = (n & 1) ? xsNeg : tab1;
+}
+
 // ---------------------------------------------------------------------------------------
 // fdlibm-derived float routines (glibc sysdeps/ieee754/flt-32/e_acosf.c, e_asinf.c,
 // s_atanf.c, e_atan2f.c, s_tanf.c + k_tanf.c + e_rem_pio2f.c); float arithmetic, no FMA.

@@ -35,6 +35,7 @@ __device__ __forceinline__ float exp_(float x)  { return expf(x); }
 __device__ __forceinline__ float log_(float x)  { return logf(x); }
 __device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
 __device__ __forceinline__ void sincos_(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+__device__ __forceinline__ void sincos_signs_(float x, bool* sn, bool* cn) { *sn = sinf(x) < 0.0f || (sinf(x) == 0.0f && signbit(sinf(x))); *cn = signbit(cosf(x)); }
 #else
 // Real calls, not inlined: the megakernel evaluates ~40 transcendentals per bounce at ~20 call sites;
 // inlined, k_trace was 72 KB of code against a 64 KB instruction cache shared by two CUs.
@@ -56,6 +57,8 @@ RL_MATH_CALL float pow_(float x, float y) { return rlm::powf_(x, y); }
 // sinf(x) and cosf(x) of one argument share their range reduction (each result is the separate call's)
 RL_MATH_CALL float2 sincos2_(float x) { float s, c; rlm::sincosf_both(x, &s, &c); return make_float2(s, c); }
 __device__ __forceinline__ void sincos_(float x, float* s, float* c) { const float2 r = sincos2_(x); *s = r.x; *c = r.y; }
+// sign bits of sinf(x), cosf(x) for 0 <= x < 120 without evaluating them
+__device__ __forceinline__ void sincos_signs_(float x, bool* sn, bool* cn) { rlm::sincosf_signs(x, sn, cn); }
 #endif
 __device__ __forceinline__ float fmod1_(float x) { return fmodf(x, 1.0f); }
 

@@ -711,7 +711,19 @@ __device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 in
 // Camera::GetCameraRay (reference render/camera.h:44-53)
 __device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rng& g, V3& o, V3& d, float& rayTime)
 {
-	V3 rd = k.lensRadius * RandomInUnitDisk(g);
+	V3 rd;
+	if (k.lensRadius == 0.0f) {
+		// Pinhole: lensRadius * RandomInUnitDisk() is a vector of zeros.  Only their SIGNS can still matter (a +-0 offset decides
+		// the sign of an exactly-zero direction component), and those follow from the signs of cos/sin of the lens angle, which
+		// do not need the polynomials.  The two draws are consumed as always (reference core/random.cc:42-50).
+		(void)Next(g);
+		const float u2 = Next(g);
+		const float theta = 2.0f * 3.14159265358979323846f * u2;
+		bool sn, cn; rtm::sincos_signs_(theta, &sn, &cn);
+		rd = k.lensRadius * v3(cn ? -1.0f : 1.0f, sn ? -1.0f : 1.0f, 0.0f);
+	} else {
+		rd = k.lensRadius * RandomInUnitDisk(g);
+	}
 	V3 cu = ld3(k.u), cv = ld3(k.v);
 	V3 offset = (cu * rd.x) + (cv * rd.y);
 	float captureTime = k.beginTime + k.timePeriod * Next(g);

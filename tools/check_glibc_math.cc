@@ -51,6 +51,12 @@ int main(int argc, char** argv)
 	if (want("logf")) bad += sweep1("logf", rlm::logf_, logf);
 	if (want("sinf")) bad += sweep1("sinf", rlm::sinf_, sinf);
 	if (want("cosf")) bad += sweep1("cosf", rlm::cosf_, cosf);
+	if (want("signs")) {   // sincosf_signs vs the sign bits of sinf / cosf on [0, 120)
+		bad += sweep1("sincosf_signs.sin", [](float x) { bool a, b; rlm::sincosf_signs(x, &a, &b); return a ? -1.0f : 1.0f; },
+		              [](float x) { return (rlm::asuint(sinf(x)) >> 31) ? -1.0f : 1.0f; }, 0, 0x42f00000ull);
+		bad += sweep1("sincosf_signs.cos", [](float x) { bool a, b; rlm::sincosf_signs(x, &a, &b); return b ? -1.0f : 1.0f; },
+		              [](float x) { return (rlm::asuint(cosf(x)) >> 31) ? -1.0f : 1.0f; }, 0, 0x42f00000ull);
+	}
 	if (want("sincos")) {
 		bad += sweep1("sincosf_both.sin", [](float x) { float s, c; rlm::sincosf_both(x, &s, &c); return s; }, sinf);
 		bad += sweep1("sincosf_both.cos", [](float x) { float s, c; rlm::sincosf_both(x, &s, &c); return c; }, cosf);
