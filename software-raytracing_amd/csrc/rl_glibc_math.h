@@ -8,7 +8,7 @@
 // that wants the reference's pixels needs the same roundings, not merely < 1 ulp.
 //
 // Tables are glibc's published constants (__exp2f_data, __logf_data, __powf_log2_data,
-// __sincosf_table, __inv_pio4).  tools/check_glibc_math.c verifies every function here
+// __sincosf_table, __inv_pio4).  tools/check_glibc_math.cc verifies every function here
 // against the host libm over the full float domain (or the stated sub-domain).
 //
 // Everything is plain C arithmetic on IEEE binary32/binary64 + fma: identical on x86-64
@@ -20,11 +20,8 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define RLM_FN __host__ __device__ static inline
-#define RLM_CONST static __constant__
-#define RLM_TAB(name) name##_dev
 #else
 #define RLM_FN static inline
-#define RLM_TAB(name) name
 #endif
 
 namespace rlm {

@@ -1,0 +1,15 @@
+// Sanitizer harness only (tools/asan_host_check.sh): stands in for csrc/rl_render.hip so that the HOST side of the
+// library (ABI, OBJ/MTL loader, BVH builder, codecs, registries) can be built with g++ -fsanitize=address,undefined
+// and run through tests/test_host_logic.py.  Never part of libraylib.so.
+#include "rl_host.h"
+namespace rl {
+bool DeviceAvailable() { return false; }
+bool DeviceRender(Scene&, const RenderRequest&, RaylibAMDStats&) { return false; }
+bool DeviceClosestHit(Scene&, const float*, int32_t, float, void*) { return false; }
+bool DevicePostProcess(Image&) { return false; }
+void* DeviceImagePixels(Image&) { return nullptr; }
+void DeviceFreePixels(void*) {}
+bool DeviceEvalMath(int, const float*, const float*, int, float*) { return false; }
+void DeviceReleaseScene(DeviceScene*) {}
+void DeviceShutdown() {}
+}
