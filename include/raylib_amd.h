@@ -97,6 +97,15 @@ RAYLIB_API SceneElementHandle RaylibAMD_CreateTriangle(const float v0[3], const 
 	const float n0[3], const float n1[3], const float n2[3], const float uv[6], MaterialHandle material);
 RAYLIB_API int32_t RaylibAMD_DestroySceneElement(SceneElementHandle element);
 
+/* Test hooks: one function of the hot path on an array of inputs, evaluated by the device code the megakernel uses.
+ *   EvalScatter   : Material::Scatter + ScatteringPdf + Emitted for scene material `material`; record i uses the stream
+ *                   (seed, i, 0).  in: 16 floats (ray o, d, time; hit t, p, n, paramU, paramV); out: 16 floats (scattered?,
+ *                   reflectance, direction, origin, pdf, scatteringPdf, emitted, draws) -- layouts of oracle/ref_glue.cc.
+ *   EvalCameraRays: Camera::GetCameraRay(u, v), stream (seed, i, 0); out 7 floats (o, d, time).
+ *   EvalTexture   : Texture2D::Sample of scene texture `texture`; out 4 floats. */
+RAYLIB_API int32_t RaylibAMD_EvalScatter(SceneHandle scene, int32_t material, const float* records, int32_t n, uint64_t seed, float* out);
+RAYLIB_API int32_t RaylibAMD_EvalCameraRays(CameraHandle camera, const float* uv, int32_t n, uint64_t seed, float* out);
+RAYLIB_API int32_t RaylibAMD_EvalTexture(SceneHandle scene, int32_t texture, int32_t bSRGB, const float* uv, int32_t n, float* out);
 /* Test hook: out[i] = f(x[i] [, y[i]]) evaluated by the DEVICE math the megakernel uses (csrc/rl_math.h).
  * fn: 0 sinf, 1 cosf, 2 tanf, 3 acosf, 4 asinf, 5 atan2f(x,y), 6 expf, 7 logf, 8 powf(x,y), 9/10 sincos (sin / cos
  * part), 11 sqrtf, 12 x / y, 13 fmodf(x, 1).  y may be NULL for one-argument functions. */

@@ -406,6 +406,26 @@ int32_t RaylibAMD_DestroySceneElement(SceneElementHandle h)
 	return 0;
 }
 
+int32_t RaylibAMD_EvalScatter(SceneHandle sh, int32_t material, const float* records, int32_t n, uint64_t seed, float* out)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized || !records || !out || material < 0 || material >= (int32_t)s->materials.size()) return 0;
+	return DeviceEvalHook(0, s, nullptr, material, 0, records, n, seed, out) ? 1 : 0;
+}
+int32_t RaylibAMD_EvalCameraRays(CameraHandle ch, const float* uv, int32_t n, uint64_t seed, float* out)
+{
+	Camera* c = (Camera*)ch;
+	if (!c || !uv || !out) return 0;
+	const DCamera d = c->ToDevice();
+	return DeviceEvalHook(1, nullptr, &d, 0, 0, uv, n, seed, out) ? 1 : 0;
+}
+int32_t RaylibAMD_EvalTexture(SceneHandle sh, int32_t texture, int32_t bSRGB, const float* uv, int32_t n, float* out)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized || !uv || !out || texture < 0 || texture >= (int32_t)s->textures.size()) return 0;
+	return DeviceEvalHook(2, s, nullptr, texture, bSRGB, uv, n, 0, out) ? 1 : 0;
+}
+
 int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int32_t n, float* out)
 {
 	if (!x || !out) return 0;

@@ -186,6 +186,7 @@ bool DevicePostProcess(Image& img);          // Image2D::PostProcess on the devi
 void* DeviceImagePixels(Image& img);          // (re)allocates img.devPixels for width*height float4; nullptr when no device
 void DeviceFreePixels(void* p);
 bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out);
+bool DeviceEvalHook(int kind, Scene* sc, const DCamera* cam, int a, int b, const float* in, int n, uint64_t seed, float* out);
 void DeviceReleaseScene(DeviceScene* dev);
 void DeviceShutdown();
 

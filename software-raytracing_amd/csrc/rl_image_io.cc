@@ -9,9 +9,11 @@
 // JPEG is not decoded (returns null, like a failed FreeImage load: image.cc:161-165).
 #include "rl_host.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 #include <zlib.h>
+#include <string>
 
 namespace rl {
 
@@ -130,6 +132,55 @@ Image* LoadPNG(const std::vector<uint8_t>& d)
 	return FromBytesRGBA(w, h, px);
 }
 
+// Radiance .hdr (RGBE), the usual container of sky panoramas.  The reference reads it through FreeImage and
+// ConvertToRGBAF (render/image.cc:168-193): float RGB = mantissa * 2^(e - 136) (no +0.5 bias), alpha 1, file rows top to bottom.
+// [parity unpinned: FreeImage is absent; the decode is restated from the format's definition]
+Image* LoadHDR(const std::vector<uint8_t>& d)
+{
+	if (d.size() < 11 || (memcmp(d.data(), "#?RADIANCE", 10) != 0 && memcmp(d.data(), "#?RGBE", 6) != 0)) return nullptr;
+	size_t p = 0;
+	auto line = [&](std::string& out) { out.clear(); while (p < d.size() && d[p] != '\n') out.push_back((char)d[p++]); if (p < d.size()) ++p; return p <= d.size(); };
+	std::string ln;
+	bool formatOk = false;
+	while (line(ln)) {
+		if (ln.empty()) break;
+		if (ln.find("FORMAT=32-bit_rle_rgbe") != std::string::npos) formatOk = true;
+	}
+	if (!formatOk || !line(ln)) return nullptr;
+	int w = 0, h = 0;
+	if (sscanf(ln.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) return nullptr;
+	std::vector<uint8_t> row((size_t)w * 4);
+	Image* img = new Image;
+	img->width = (uint32_t)w; img->height = (uint32_t)h;
+	img->rgba.resize((size_t)w * h * 4);
+	for (int y = 0; y < h; ++y) {
+		if (p + 4 > d.size()) { delete img; return nullptr; }
+		if (w >= 8 && w < 32768 && d[p] == 2 && d[p + 1] == 2 && ((d[p + 2] << 8) | d[p + 3]) == w) {
+			p += 4;   // new-style RLE: the four channels of the scanline one after the other
+			for (int ch = 0; ch < 4; ++ch) {
+				int x = 0;
+				while (x < w) {
+					if (p >= d.size()) { delete img; return nullptr; }
+					int cnt = d[p++];
+					if (cnt > 128) { cnt -= 128; if (p >= d.size() || x + cnt > w) { delete img; return nullptr; } uint8_t v = d[p++]; while (cnt--) row[4 * (x++) + ch] = v; }
+					else { if (cnt == 0 || p + cnt > d.size() || x + cnt > w) { delete img; return nullptr; } while (cnt--) row[4 * (x++) + ch] = d[p++]; }
+				}
+			}
+		} else {
+			if (p + (size_t)w * 4 > d.size()) { delete img; return nullptr; }
+			memcpy(row.data(), &d[p], (size_t)w * 4); p += (size_t)w * 4;   // flat scanline
+		}
+		for (int x = 0; x < w; ++x) {
+			float* o = &img->rgba[((size_t)y * w + x) * 4];
+			const uint8_t e = row[4 * x + 3];
+			if (e) { const float f = ldexpf(1.0f, (int)e - (128 + 8)); o[0] = row[4 * x] * f; o[1] = row[4 * x + 1] * f; o[2] = row[4 * x + 2] * f; }
+			else o[0] = o[1] = o[2] = 0.0f;
+			o[3] = 1.0f;
+		}
+	}
+	return img;
+}
+
 // reference render/image.h:62-69: (uint32)(c * 255.0f) & 0xff, no clamping
 inline uint8_t ToByte(float c) { return (uint8_t)((uint32_t)(c * 255.0f) & 0xff); }
 
@@ -208,7 +259,8 @@ Image* LoadImageFile(const char* path)
 	if (!ReadFile(path, d)) return nullptr;
 	if (Image* i = LoadPNG(d)) return i;
 	if (Image* i = LoadBMP(d)) return i;
-	Log("LoadImage: unsupported image format: %s (BMP and 8-bit PNG are decoded)", path);
+	if (Image* i = LoadHDR(d)) return i;
+	Log("LoadImage: unsupported image format: %s (BMP, 8-bit PNG and Radiance HDR are decoded)", path);
 	return nullptr;
 }
 

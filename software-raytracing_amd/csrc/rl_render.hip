@@ -1110,6 +1110,64 @@ k_pp_map(float4* __restrict__ px, size_t n, const unsigned int* __restrict__ whi
 	px[i] = p;
 }
 
+// Test hooks: single functions of the hot path evaluated on arrays, so that tests can pin them one by one against
+// the reference's outputs (Material::Scatter / ScatteringPdf / Emitted, Camera::GetCameraRay, Texture2D::Sample).
+// Record layouts are those of oracle/ref_glue.cc (ref_scatter, ref_camera_rays, ref_texture_sample).
+__global__ void __launch_bounds__(RL_BLOCK)
+k_eval_scatter(const DSceneView S, int material, const float* __restrict__ in, int n, unsigned long long seed, float* __restrict__ out)
+{
+	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
+	const float* a = in + 16 * i;
+	const V3 d = ld3(a + 3);
+	Surf s;
+	s.t = a[7]; s.p = ld3(a + 8); s.n = ld3(a + 11); s.U = a[14]; s.V = a[15];
+	{
+		V3 T = (fabsf(s.n.x) > 0.9f) ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+		V3 B = normalize(cross(T, s.n));
+		T = normalize(cross(s.n, B));
+		s.tangent = T; s.bitangent = B;
+	}
+	const Mat m = LoadMat(S, material);
+	Rng g; g.s = raylib_rng_begin(seed, (uint32_t)i, 0);
+	V3 refl = v3s(0.0f), outD = v3s(0.0f);
+	float pdf = 0.0f, sp = 0.0f;
+	const bool b = Scatter(S, m, d, s, g, c, refl, outD, pdf, sp);
+	const V3 e = Emitted(S, m, s, c);
+	float* o = out + 16 * i;
+	o[0] = b ? 1.0f : 0.0f;
+	o[1] = refl.x; o[2] = refl.y; o[3] = refl.z;
+	// the reference leaves the scattered ray default-constructed (0) when a material does not fill it
+	const bool wrote = (m.type != MAT_DIFFUSE_LIGHT);
+	o[4] = wrote ? outD.x : 0.0f; o[5] = wrote ? outD.y : 0.0f; o[6] = wrote ? outD.z : 0.0f;
+	o[7] = wrote ? s.p.x : 0.0f; o[8] = wrote ? s.p.y : 0.0f; o[9] = wrote ? s.p.z : 0.0f;
+	o[10] = pdf; o[11] = b ? sp : 0.0f;
+	o[12] = e.x; o[13] = e.y; o[14] = e.z;
+	o[15] = (m.type == MAT_LAMBERTIAN || m.type == MAT_METAL || m.type == MAT_MICROFACET) ? 2.0f : (m.type == MAT_DIELECTRIC ? 1.0f : 0.0f);
+}
+
+__global__ void __launch_bounds__(RL_BLOCK)
+k_eval_camera(const DCamera cam, const float* __restrict__ uv, int n, unsigned long long seed, float* __restrict__ out)
+{
+	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	Rng g; g.s = raylib_rng_begin(seed, (uint32_t)i, 0);
+	V3 o, d; float t;
+	CameraRay(cam, uv[2 * i], uv[2 * i + 1], g, o, d, t);
+	float* r = out + 7 * i;
+	r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = t;
+}
+
+__global__ void __launch_bounds__(RL_BLOCK)
+k_eval_texture(const DSceneView S, int tex, int srgb, const float* __restrict__ uv, int n, float* __restrict__ out)
+{
+	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const float4 p = TexFetch(S.textures, S.texels, tex, srgb != 0, uv[2 * i], uv[2 * i + 1]);
+	out[4 * i] = p.x; out[4 * i + 1] = p.y; out[4 * i + 2] = p.z; out[4 * i + 3] = p.w;
+}
+
 // Test hook: evaluate one device math routine on an array (tests compare with the host libm bit for bit).
 __global__ void __launch_bounds__(RL_BLOCK)
 k_eval_math(int fn, const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ out)
@@ -1454,6 +1512,29 @@ bool DeviceClosestHit(Scene& sc, const float* rays, int32_t n, float tMin, void*
 	HIP_OK(hipStreamSynchronize(g_rt.stream));
 	HIP_OK(hipMemcpy(outHits, dOut, (size_t)n * sizeof(DHitOut), hipMemcpyDeviceToHost));
 	(void)hipFree(dRays); (void)hipFree(dOut);
+	return true;
+}
+
+// kind 0: scatter (in 16 / out 16 floats per record, a = material), 1: camera rays (in 2 / out 7), 2: texture (in 2 / out 4, a = texture, b = sRGB)
+bool DeviceEvalHook(int kind, Scene* sc, const DCamera* cam, int a, int b, const float* in, int n, uint64_t seed, float* out)
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	if (!EnsureRuntime()) return false;
+	HIP_OK(hipSetDevice(g_rt.device));
+	if (sc && !UploadScene(*sc)) return false;
+	if (n <= 0) return true;
+	const int inW = kind == 0 ? 16 : 2, outW = kind == 0 ? 16 : (kind == 1 ? 7 : 4);
+	float *din = nullptr, *dout = nullptr;
+	HIP_OK(hipMalloc(&din, (size_t)n * inW * 4)); HIP_OK(hipMalloc(&dout, (size_t)n * outW * 4));
+	HIP_OK(hipMemcpy(din, in, (size_t)n * inW * 4, hipMemcpyHostToDevice));
+	const dim3 grid(((uint32_t)n + RL_BLOCK - 1) / RL_BLOCK), block(RL_BLOCK);
+	if (kind == 0) hipLaunchKernelGGL(k_eval_scatter, grid, block, 0, g_rt.stream, sc->device->view, a, din, n, (unsigned long long)seed, dout);
+	else if (kind == 1) hipLaunchKernelGGL(k_eval_camera, grid, block, 0, g_rt.stream, *cam, din, n, (unsigned long long)seed, dout);
+	else hipLaunchKernelGGL(k_eval_texture, grid, block, 0, g_rt.stream, sc->device->view, a, b, din, n, dout);
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipStreamSynchronize(g_rt.stream));
+	HIP_OK(hipMemcpy(out, dout, (size_t)n * outW * 4, hipMemcpyDeviceToHost));
+	(void)hipFree(din); (void)hipFree(dout);
 	return true;
 }
 

@@ -94,6 +94,9 @@ _EXPORTS = {
     "RaylibAMD_CreateCube": (C.c_void_p, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float), C.c_void_p]),
     "RaylibAMD_CreateTriangle": (C.c_void_p, [C.POINTER(C.c_float)] * 7 + [C.c_void_p]),
     "RaylibAMD_DestroySceneElement": (C.c_int32, [C.c_void_p]),
+    "RaylibAMD_EvalScatter": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_uint64, C.POINTER(C.c_float)]),
+    "RaylibAMD_EvalCameraRays": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_uint64, C.POINTER(C.c_float)]),
+    "RaylibAMD_EvalTexture": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "RaylibAMD_EvalDeviceMath": (C.c_int32, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "RaylibAMD_ClosestHit": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]),
     "RaylibAMD_SceneNumTriangles": (C.c_int32, [C.c_void_p]),

@@ -151,6 +151,44 @@ def test_procedural_scene_through_the_abi(gpu_lib):
     ses.close()
 
 
+@pytest.mark.parametrize("name", list(helpers.CASES))
+def test_scatter_per_material_vs_reference_goldens(name, sessions, gpu_lib):
+    """Material::Scatter / ScatteringPdf / Emitted of every material of every scene, record by record, bit for bit
+    (reference render/material.cc:195-431 run by the real reference build, fixtures scatter_mat*)."""
+    g = golden(name)
+    ses = sessions[name]
+    rec = np.ascontiguousarray(g["scatter_in"], np.float32)
+    nm = gpu_lib.RaylibAMD_SceneNumMaterials(ses.scene)
+    for mi in range(nm):
+        out = np.zeros((len(rec), 16), np.float32)
+        assert gpu_lib.RaylibAMD_EvalScatter(ses.scene, mi, rec.ctypes.data_as(C.POINTER(C.c_float)), len(rec), 1,
+                                             out.ctypes.data_as(C.POINTER(C.c_float))) == 1
+        want = g["scatter_mat%d" % mi]
+        same = (bits(out) == bits(want)) | (np.isnan(out) & np.isnan(want))
+        assert same.all(), "%s material %d: fields %s differ in %d records" % (name, mi, sorted(set(np.nonzero(~same)[1])), (~same).any(1).sum())
+
+
+def test_camera_and_texture_functions_vs_reference_goldens(gpu_lib, sessions):
+    k = np.load(os.path.join(helpers.GOLDEN, "kat.npz"))
+    lib = gpu_lib
+    for (origin, look, fov, aspect, ap, focal, t0, t1, key) in (((0.3, 1.2, 4), (0, 0.9, -1), 50.0, 1.5, 0.1, 3.0, 0.0, 2.0, "cam_rays"),
+                                                                 ((0, 5, 0), (0, 0, 0), 60.0, 1.0, 0.0, 1.0, 0.0, 0.0, "cam2_rays")):
+        cam = lib.Raylib_CreateCamera()
+        lib.Raylib_CameraSetPosition(cam, *[float(x) for x in origin]); lib.Raylib_CameraSetLookAt(cam, *[float(x) for x in look])
+        lib.Raylib_CameraSetPerspective(cam, fov, aspect); lib.Raylib_CameraSetLens(cam, ap, focal); lib.Raylib_CameraSetMotion(cam, t0, t1)
+        uv = np.ascontiguousarray(k["cam_uv"], np.float32)
+        out = np.zeros((len(uv), 7), np.float32)
+        assert lib.RaylibAMD_EvalCameraRays(cam, uv.ctypes.data_as(C.POINTER(C.c_float)), len(uv), 3, out.ctypes.data_as(C.POINTER(C.c_float))) == 1
+        assert np.array_equal(bits(out), bits(k[key])), key
+        lib.Raylib_DestroyCamera(cam)
+    ses = sessions["cutout_sky"]          # texture 0 = leaf.png decoded by the library
+    uv = np.ascontiguousarray(k["tex_uv"], np.float32)
+    for srgb, key in ((0, "tex_linear"), (1, "tex_srgb")):
+        out = np.zeros((len(uv), 4), np.float32)
+        assert lib.RaylibAMD_EvalTexture(ses.scene, 0, srgb, uv.ctypes.data_as(C.POINTER(C.c_float)), len(uv), out.ctypes.data_as(C.POINTER(C.c_float))) == 1
+        assert np.array_equal(bits(out), bits(k[key])), key
+
+
 def test_soup_closest_hit_10k(gpu_lib, workdir):
     from raylib_amd import binding
     g = golden("soup")

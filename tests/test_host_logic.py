@@ -181,6 +181,42 @@ def test_image_codecs_roundtrip(lib, workdir):
     lib.Raylib_DestroyImage(ih)
 
 
+def test_radiance_hdr_decode(lib, workdir):
+    """Radiance RGBE (sky panoramas): flat and new-style RLE scanlines decode to mantissa * 2^(e-136), alpha 1, row 0 = top."""
+    rng = np.random.RandomState(9)
+    w, h = 16, 5
+    rgbe = rng.randint(1, 256, (h, w, 4)).astype(np.uint8)
+    rgbe[..., 3] = rng.randint(120, 140, (h, w))
+    rgbe[0, 0] = (0, 0, 0, 0)
+    want = np.zeros((h, w, 4), np.float32)
+    f = np.ldexp(np.float32(1.0), rgbe[..., 3].astype(np.int32) - 136).astype(np.float32)
+    for c in range(3):
+        want[..., c] = np.where(rgbe[..., 3] > 0, rgbe[..., c].astype(np.float32) * f, 0)
+    want[..., 3] = 1.0
+    header = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    flat = header + rgbe.tobytes()
+    rle = bytearray(header)
+    for y in range(h):
+        rle += bytes([2, 2, w >> 8, w & 255])
+        for ch in range(4):
+            row = rgbe[y, :, ch]
+            rle += bytes([8]) + row[:8].tobytes() + bytes([128 + 8, row[8]])    # 8 literals, then a run of 8
+            rgbe[y, 8:, ch] = row[8]
+    f = np.ldexp(np.float32(1.0), rgbe[..., 3].astype(np.int32) - 136).astype(np.float32)
+    want_rle = want.copy()
+    for c in range(3):
+        want_rle[..., c] = np.where(rgbe[..., 3] > 0, rgbe[..., c].astype(np.float32) * f, 0)
+    for name, blob, expect in (("flat.hdr", flat, want), ("rle.hdr", bytes(rle), want_rle)):
+        path = os.path.join(str(workdir), name)
+        open(path, "wb").write(blob)
+        ih = lib.Raylib_LoadImage(path.encode())
+        assert ih, name
+        got = np.zeros((h, w, 4), np.float32)
+        lib.RaylibAMD_DumpImageRGBA(ih, got.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(got, expect), name
+        lib.Raylib_DestroyImage(ih)
+
+
 def test_postprocess_matches_oracle(lib, oracle):
     rng = np.random.RandomState(4)
     rgba = np.zeros((9, 11, 4), np.float32)

@@ -1,0 +1,36 @@
+"""configs[3]-sized run on one GPU: colonnade (167 k triangles, sun), 1080p, 256 spp; the slice one of 8 ranks would
+render (cells r::8) is timed too, and parity windows are checked against the oracle."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers
+from helpers import ffi, bits, scenes, objflat
+from raylib_amd import binding, tiling
+lib = binding.load(); assert lib.Raylib_Initialize() == 1
+lib.RaylibAMD_SetSeed(1)
+tmp = os.environ.get("TMPDIR", "/tmp")
+orc = ffi.load_oracle()
+cam = scenes.CONFIG_CAMERAS["sponza"]
+t = time.time(); obj, n = scenes.colonnade(os.path.join(tmp, "colonnade.obj"), tess=12); print("gen %d tris %.1fs" % (n, time.time() - t), flush=True)
+t = time.time(); ses = binding.SceneSession(lib, obj, cam["origin"], cam["look_at"], cam["fov"], 1920 / 1080, sun=cam["sun"], sun_dir=cam["sun_dir"]); print("load+bvh %.1fs" % (time.time() - t), flush=True)
+W, H, SPP = 1920, 1080, 256
+img = ses.render(W, H, SPP); s = ses.stats()
+print("full frame: trace %.1f ms (%d launches) Mrays/s %.0f rays/sample %.2f nodes/ray %.1f depth %d" % (s.traceKernelMs, s.traceLaunches, s.rays / s.traceKernelMs / 1e3, s.rays / s.cameraSamples, s.nodesVisited / s.rays, s.bvhDepth), flush=True)
+full_ms = s.kernelMs
+slices = []
+for r in range(8):
+    buf = ses.render_cells(W, H, SPP, r, 8); st = ses.stats(); slices.append((st.kernelMs, buf))
+print("8-rank slices: kernel ms per rank", ["%.1f" % k for k, _ in slices], "-> max %.1f ms vs full %.1f ms: projected strong scaling x%.2f (excl. gather)" % (
+    max(k for k, _ in slices), full_ms, full_ms / max(k for k, _ in slices)))
+print("tile union bit-identical:", np.array_equal(bits(tiling.assemble(W, H, 8, [b for _, b in slices])), bits(img)))
+flat = objflat.load_obj(obj, orc, sun_illuminance=cam["sun"], sun_direction=cam["sun_dir"]); scene = orc.scene_create(flat, 1)
+ocam = ffi.make_camera(cam["origin"], cam["look_at"], cam["fov"], W / H)
+st = ffi.make_settings(W, H, SPP)
+tot = eq = 0
+for (x0, y0) in ((952, 536), (300, 700), (1500, 400), (1200, 900)):
+    want = orc.render_region(scene, ocam, st, x0, y0, 8, 8, seed=1)
+    got = img[y0:y0 + 8, x0:x0 + 8]
+    e = (bits(got[..., :3]) == bits(want[..., :3])).all(-1); tot += 64; eq += e.sum()
+    print("window", x0, y0, "bit-equal %d/64 mean %.4f" % (e.sum(), want[..., :3].mean()), flush=True)
+print("TOTAL bit-equal", eq, "/", tot)

@@ -10,6 +10,7 @@ bool DevicePostProcess(Image&) { return false; }
 void* DeviceImagePixels(Image&) { return nullptr; }
 void DeviceFreePixels(void*) {}
 bool DeviceEvalMath(int, const float*, const float*, int, float*) { return false; }
+bool DeviceEvalHook(int, Scene*, const DCamera*, int, int, const float*, int, uint64_t, float*) { return false; }
 void DeviceReleaseScene(DeviceScene*) {}
 void DeviceShutdown() {}
 }
