@@ -70,7 +70,27 @@ __device__ __forceinline__ bool isZero(V3 a) { return a.x == 0.0f && a.y == 0.0f
 
 #define RL_PI 3.14159265359f   /* BRDF::PI, reference render/brdf.h:8 */
 
-struct Counters { uint32_t rays, nodes, tris, shaded, texels, samples, trips; };
+#ifdef RL_DIAG_STAMPS
+#define RL_DIAG_BIND(c) { (c).diag = nullptr; (c).tLast = 0; (c).tAcc[0] = (c).tAcc[1] = (c).tAcc[2] = (c).tAcc[3] = 0; }
+#else
+#define RL_DIAG_BIND(c)
+#endif
+struct Counters {
+	uint32_t rays, nodes, tris, shaded, texels, samples, trips;
+#ifdef RL_DIAG_STAMPS
+	unsigned long long* diag;   // diagnostic build: the global counter array (slots CNT_COUNT + k)
+	unsigned long long tLast, tAcc[4];
+#endif
+};
+#ifdef RL_DIAG_STAMPS
+#define RL_CSTAMP_BEGIN(c) { __builtin_amdgcn_sched_barrier(0); (c).tLast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define RL_CSTAMP(c, k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (c).tAcc[k] += now_ - (c).tLast; (c).tLast = now_; __builtin_amdgcn_sched_barrier(0); }
+#define RL_WLSTEP(c, kw, kl) { const unsigned long long em_ = __ballot(1); if ((c).diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) { atomicAdd(&(c).diag[CNT_COUNT + kw], 1ull); atomicAdd(&(c).diag[CNT_COUNT + kl], (unsigned long long)__popcll(em_)); } }
+#else
+#define RL_WLSTEP(c, kw, kl)
+#define RL_CSTAMP_BEGIN(c)
+#define RL_CSTAMP(c, k)
+#endif
 
 // ---------------------------------------------------------------------------
 // RNG (include/raylib_amd_rng.h); draws in the reference's program order.
@@ -275,6 +295,13 @@ __device__ __noinline__ float2 CubeHit(const DCube* cubes, int index, V3 o, V3 d
 	return make_float2(NAN, 0.0f);
 }
 
+// diagnostic build only: count wave-level steps (first active lane adds 1) next to the lane-level counters
+#ifdef RL_DIAG_STAMPS
+#define RL_WSTEP(k) { const unsigned long long em_ = __ballot(1); if (c.diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) atomicAdd(&c.diag[CNT_COUNT + k], 1ull); }
+#else
+#define RL_WSTEP(k)
+#endif
+
 // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (cheap steps:
 // one 64-byte record, two slab tests), THEN the wave intersects leaves together.  With a single
 // "if inner else leaf" loop a wave pays node + leaf cost on every trip as soon as one lane is at a leaf, and
@@ -293,9 +320,7 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 	for (;;) {
 		// ---- descend: inner nodes until this lane holds a leaf or has nothing left ----
 		while (cur >= 0 && cur != DONE) {
-#ifdef RL_DIAG_WSTEPS
-			{ const unsigned long long em = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em) - 1u) c.texels++; }   // diagnostic: wave-level node steps (reported as texFetches)
-#endif
+			RL_WSTEP(4);
 			const float4* np = (const float4*)(S.nodes + cur);
 			const float4 q0 = np[0], q1 = np[1], q2 = np[2];
 			const int4 k = ((const int4*)np)[3];
@@ -319,6 +344,7 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 		if (cur == DONE) break;
 		// ---- leaf: <= 4 triangles stored back to back, or one analytic primitive ----
 		{
+			RL_WSTEP(6);
 			const uint32_t code = (uint32_t)~cur;
 			const int first = (int)(code >> 6);
 			const int count = (int)(code & 7u) + 1;
@@ -326,6 +352,7 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 			const uint32_t kind = (code >> 4) & 3u;
 			if (!PRIMS || kind == 0u) {
 				for (int i = 0; i < count; ++i) {
+					RL_WSTEP(5);
 					const Tri T = LoadTri(S, first + i);
 					c.tris++;
 					// reference geom/triangle.cc:22-27
@@ -466,7 +493,7 @@ __device__ __forceinline__ float CosPhi(V3 w) { float s = SinThetaL(w); return (
 __device__ __forceinline__ float SinPhi(V3 w) { float s = SinThetaL(w); return (s == 0) ? 0 : Clampf(w.y / s, -1, 1); }
 
 // reference render/material.cc:83-165
-__device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y)
+__device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y, Counters& cn)
 {
 	const float Pi = RL_PI;
 	if ((double)cosThetaI > .9999) {
@@ -492,6 +519,7 @@ __device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slo
 
 	int it = 0;
 	while (++it < 10) {
+		RL_WLSTEP(cn, 16, 17);
 		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
 		float invErf = ErfInv(b);
 		float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * rtm::exp_(-invErf * invErf)) - sample_x;
@@ -504,11 +532,11 @@ __device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slo
 	*slope_y = ErfInv(2.0f * fmaxf(U2, (float)1e-6f) - 1.0f);
 }
 // reference render/material.cc:166-190
-__device__ V3 BeckmannSample(V3 wi, float alpha_x, float alpha_y, float U1, float U2)
+__device__ V3 BeckmannSample(V3 wi, float alpha_x, float alpha_y, float U1, float U2, Counters& cn)
 {
 	V3 wiStretched = normalize(v3(alpha_x * wi.x, alpha_y * wi.y, wi.z));
 	float slope_x, slope_y;
-	BeckmannSample11(wiStretched.z, U1, U2, &slope_x, &slope_y);
+	BeckmannSample11(wiStretched.z, U1, U2, &slope_x, &slope_y, cn);
 	float tmp = CosPhi(wiStretched) * slope_x - SinPhi(wiStretched) * slope_y;
 	slope_y = SinPhi(wiStretched) * slope_x + CosPhi(wiStretched) * slope_y;
 	slope_x = tmp;
@@ -662,6 +690,8 @@ __device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 in
 			return true;
 		}
 		default: {               // MicrofacetMaterial, material.cc:290-340,352-376,417-431
+			RL_CSTAMP_BEGIN(c);
+			RL_WLSTEP(c, 18, 19);
 			V3 baseColor = GetAlbedo(S, m, s.U, s.V, c);
 			float roughness = GetRoughness(S, m, s.U, s.V, c);
 			float metallic = m.metallic;
@@ -672,7 +702,9 @@ __device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 in
 			float u0 = Next(g);
 			float u1 = Next(g);
 			bool bFlip = Wo.z < 0.0f;
-			V3 Wh = BeckmannSample(bFlip ? -Wo : Wo, roughness, roughness, u0, u1);
+			RL_CSTAMP(c, 0);
+			V3 Wh = BeckmannSample(bFlip ? -Wo : Wo, roughness, roughness, u0, u1, c);
+			RL_CSTAMP(c, 1);
 			if (bFlip) Wh = -Wh;
 			V3 Wi = reflect(-Wo, Wh);
 			float NdotWi = absDot(N, Wi);
@@ -702,6 +734,7 @@ __device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 in
 			float D = DistributionBeckmann(N, wh, roughness);
 			sp = D * absDot(wh, N);
 			pdf = sp / (4.0f * dot(Wo, Wh));
+			RL_CSTAMP(c, 2);
 			return true;
 		}
 	}
@@ -800,7 +833,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t numSlots = P.numLocalCells * 64u;
 
-	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);
 	Rng g; g.s.state = 0;
 	V3 o = v3s(0.0f), d = v3s(0.0f);
 	float rayTime = 0.0f;
@@ -815,6 +848,18 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	// per wave and bounce was exactly that rate: the kernel ran at the atomic's speed.)
 	uint32_t chunkNext = 0, chunkEnd = 0;
 	bool globalDone = false;
+#ifdef RL_DIAG_STAMPS
+	// diagnostic build only: shader-clock time per phase (refill | traverse | shade | fold), summed per wave
+	unsigned long long stampAcc[4] = { 0, 0, 0, 0 }, subAcc[4] = { 0, 0, 0, 0 };
+	c.diag = counters;
+	unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+	#define RL_SUBSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); subAcc[k] += now_ - subLast; subLast = now_; __builtin_amdgcn_sched_barrier(0); }
+	unsigned long long subLast = 0;
+	#define RL_STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[k] += now_ - stampLast; stampLast = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+	#define RL_STAMP(k)
+	#define RL_SUBSTAMP(k)
+#endif
 
 	for (;;) {
 		// ---- refill idle lanes: wave64 ballot + prefix rank ----
@@ -883,37 +928,47 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 
 		// ---- one bounce for every active lane (TraceScene, reference render/renderer.cc:114-208) ----
 		if (lane == 0) c.trips++;
+		RL_STAMP(0);
+		HitRec h; h.tri = -1;
+		const bool doTrace = active && depth < P.maxPathLength;   // renderer.cc:120-123 otherwise
+		bool hit = false;
+		if (doTrace) hit = Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
+		RL_STAMP(1);
 		if (active) {
 			bool done = false;
 			V3 L = v3s(0.0f);
-			if (depth >= P.maxPathLength) {
-				done = true;                                   // renderer.cc:120-123
-			} else {
-				HitRec h;
-				if (Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c)) {
-					Surf s;
-					const Mat m = LoadMat(S, BuildSurface<PRIMS>(S, o, d, h, s, true, c));
-					V3 refl = v3s(0.0f), outD = v3s(0.0f);
-					float pdf = 0.0f, sp = 0.0f;
-					const bool scattered = Scatter(S, m, d, s, g, c, refl, outD, pdf, sp);
-					const V3 E = Emitted(S, m, s, c);
-					if (scattered && pdf > 0.0f) {
-						// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
-						float4* st = (float4*)pathStack + ((size_t)depth * P.stackStride + gtid) * 2u;
-						st[0] = make_float4(refl.x, refl.y, refl.z, sp);
-						st[1] = make_float4(pdf, E.x, E.y, E.z);
-						o = s.p; d = outD;
-						depth++;
-						if (depth >= P.maxPathLength) done = true;   // the next TraceScene returns 0 at once (renderer.cc:120-123); L stays 0
-					} else {
-						L = v3s(0.0f) + E;                        // radiance(0) += Emitted, renderer.cc:137,151
-						done = true;
-					}
+			if (!doTrace) {
+				done = true;
+			} else if (hit) {
+				Surf s;
+#ifdef RL_DIAG_STAMPS
+				subLast = __builtin_amdgcn_s_memtime();
+#endif
+				const Mat m = LoadMat(S, BuildSurface<PRIMS>(S, o, d, h, s, true, c));
+				RL_SUBSTAMP(0);
+				V3 refl = v3s(0.0f), outD = v3s(0.0f);
+				float pdf = 0.0f, sp = 0.0f;
+				const bool scattered = Scatter(S, m, d, s, g, c, refl, outD, pdf, sp);
+				RL_SUBSTAMP(1);
+				const V3 E = Emitted(S, m, s, c);
+				if (scattered && pdf > 0.0f) {
+					// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
+					float4* st = (float4*)pathStack + ((size_t)depth * P.stackStride + gtid) * 2u;
+					st[0] = make_float4(refl.x, refl.y, refl.z, sp);
+					st[1] = make_float4(pdf, E.x, E.y, E.z);
+					o = s.p; d = outD;
+					depth++;
+					if (depth >= P.maxPathLength) done = true;   // the next TraceScene returns 0 at once (renderer.cc:120-123); L stays 0
 				} else {
-					L = MissShader<STACK, PRIMS>(S, R, o, d, rayTime, P.rayTMin, stk, c);
+					L = v3s(0.0f) + E;                        // radiance(0) += Emitted, renderer.cc:137,151
 					done = true;
 				}
+				RL_SUBSTAMP(2);
+			} else {
+				L = MissShader<STACK, PRIMS>(S, R, o, d, rayTime, P.rayTMin, stk, c);
+				done = true;
 			}
+			RL_STAMP(2);
 			if (done) {
 				// fold back to the camera: radiance = (0 + refl*Li*sp/pdf) + E at every vertex
 				for (int k = depth - 1; k >= 0; --k) {
@@ -931,8 +986,12 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				active = false;
 			}
 		}
+		RL_STAMP(3);
 	}
 
+#ifdef RL_DIAG_STAMPS
+	if (lane == 0) for (int k = 0; k < 4; ++k) { atomicAdd(&counters[CNT_COUNT + k], stampAcc[k]); atomicAdd(&counters[CNT_COUNT + 8 + k], subAcc[k]); atomicAdd(&counters[CNT_COUNT + 12 + k], c.tAcc[k]); }
+#endif
 	// ---- counters: wave reduction, one atomic per wave and counter ----
 	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples, c.trips };
 	for (int k = 0; k < CNT_COUNT; ++k) {
@@ -984,7 +1043,7 @@ k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsig
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t numSlots = P.numLocalCells * 64u;
 	const uint32_t slot = blockIdx.x * RL_BLOCK + threadIdx.x;
-	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);
 	bool valid = false;
 	uint32_t x = 0, y = 0;
 	if (slot < numSlots) {
@@ -1056,7 +1115,7 @@ k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float t
 	int* stk = s_stack + threadIdx.x;
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;
-	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);
 	const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
 	HitRec h;
 	DHitOut r; memset(&r, 0, sizeof(r)); r.material = -1;
@@ -1118,7 +1177,7 @@ k_eval_scatter(const DSceneView S, int material, const float* __restrict__ in, i
 {
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;
-	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);
 	const float* a = in + 16 * i;
 	const V3 d = ld3(a + 3);
 	Surf s;
@@ -1251,7 +1310,7 @@ bool EnsureRuntime()
 	R.numCUs = prop.multiProcessorCount;
 	HIP_OK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
 	for (int i = 0; i < 4; ++i) HIP_OK(hipEventCreate(&R.ev[i]));
-	HIP_OK(hipMalloc(&R.counters, CNT_COUNT * sizeof(unsigned long long)));
+	HIP_OK(hipMalloc(&R.counters, (CNT_COUNT + 24) * sizeof(unsigned long long)));
 	HIP_OK(hipMalloc(&R.jobCounter, sizeof(unsigned int)));
 	Log("raylib(MI355X): device %d %s (%s), %d CUs", dev, prop.name, prop.gcnArchName, R.numCUs);
 	R.ok = true;
@@ -1390,7 +1449,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	float4* out = (float4*)req.outDevice;
 	if (!out) { if (!Grow(R.image, R.imageBytes, outBytes ? outBytes : 16)) return false; out = R.image; }
 
-	HIP_OK(hipMemsetAsync(R.counters, 0, CNT_COUNT * sizeof(unsigned long long), R.stream));
+	HIP_OK(hipMemsetAsync(R.counters, 0, (CNT_COUNT + 24) * sizeof(unsigned long long), R.stream));
 	float traceMs = 0.0f;
 	uint32_t launches = 0;
 	HIP_OK(hipEventRecord(R.ev[0], R.stream));
@@ -1451,7 +1510,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	float totalMs = 0.0f;
 	HIP_OK(hipEventElapsedTime(&totalMs, R.ev[0], R.ev[1]));
 
-	unsigned long long cnt[CNT_COUNT];
+	unsigned long long cnt[CNT_COUNT + 24];
 	HIP_OK(hipMemcpyAsync(cnt, R.counters, sizeof(cnt), hipMemcpyDeviceToHost, R.stream));
 	if (req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, outBytes, hipMemcpyDeviceToHost, R.stream));
 	HIP_OK(hipStreamSynchronize(R.stream));
@@ -1459,6 +1518,13 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	stats.rays = cnt[CNT_RAYS]; stats.nodesVisited = cnt[CNT_NODES]; stats.trisTested = cnt[CNT_TRIS];
 	stats.shadedHits = cnt[CNT_SHADED]; stats.texFetches = cnt[CNT_TEXELS]; stats.cameraSamples = cnt[CNT_SAMPLES];
 	stats.waveTrips = cnt[CNT_TRIPS];
+	if (getenv("RAYLIB_PRINT_STAMPS")) {
+		const double tot = (double)(cnt[CNT_COUNT] + cnt[CNT_COUNT + 1] + cnt[CNT_COUNT + 2] + cnt[CNT_COUNT + 3]);
+		Log("wave steps: node %llu (lane steps %llu, eff %.3f)  tri %llu (lane %llu, eff %.3f)  leaf rounds %llu  trips %llu", cnt[CNT_COUNT + 4], cnt[CNT_NODES], cnt[CNT_NODES] / (64.0 * cnt[CNT_COUNT + 4] + 1), cnt[CNT_COUNT + 5], cnt[CNT_TRIS], cnt[CNT_TRIS] / (64.0 * cnt[CNT_COUNT + 5] + 1), cnt[CNT_COUNT + 6], cnt[CNT_TRIPS]);
+		if (tot > 0) Log("shade split (of all): surface+material %.3f scatter %.3f emit+store %.3f", cnt[CNT_COUNT + 8] / tot, cnt[CNT_COUNT + 9] / tot, cnt[CNT_COUNT + 10] / tot);
+		if (tot > 0) Log("microfacet split (of all): setup %.3f beckmann sample %.3f brdf+pdf %.3f | newton wave iters %llu lane iters %llu (eff %.3f) | microfacet wave calls %llu lanes %llu (eff %.3f)", cnt[CNT_COUNT + 12] / tot, cnt[CNT_COUNT + 13] / tot, cnt[CNT_COUNT + 14] / tot, cnt[CNT_COUNT + 16], cnt[CNT_COUNT + 17], cnt[CNT_COUNT + 17] / (64.0 * cnt[CNT_COUNT + 16] + 1), cnt[CNT_COUNT + 18], cnt[CNT_COUNT + 19], cnt[CNT_COUNT + 19] / (64.0 * cnt[CNT_COUNT + 18] + 1));
+		if (tot > 0) Log("phase shares (shader clock): refill %.3f traverse %.3f shade %.3f fold %.3f", cnt[CNT_COUNT] / tot, cnt[CNT_COUNT + 1] / tot, cnt[CNT_COUNT + 2] / tot, cnt[CNT_COUNT + 3] / tot);
+	}
 	uint64_t px = 0;
 	for (uint32_t k = 0; k < numLocalCells; ++k) {
 		const uint32_t cell = req.cellFirst + k * stride, cx = cell % cellsX, cy = cell / cellsX;
