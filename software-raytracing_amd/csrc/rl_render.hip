@@ -215,7 +215,7 @@ __device__ __forceinline__ bool AlphaTestCandidate(const DSceneView& S, int tri,
 // same products (bound - o) * invD, same "swap if invD < 0", NaN keeps the old
 // bound).  tMax is widened by 2 ulp so the test stays conservative.
 __device__ __forceinline__ bool Slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                     V3 o, V3 inv, bool nx, bool ny, bool nz, float tMin, float tMax, float& tNear)
+                                     V3 o, V3 inv, bool nx, bool ny, bool nz, float tMin, float tMax, float& tNear, const float widen = 1.0000004f)
 {
 	float tn = tMin, tf = tMax;
 	float a0 = ((nx ? mxx : mnx) - o.x) * inv.x, a1 = ((nx ? mnx : mxx) - o.x) * inv.x;
@@ -225,7 +225,7 @@ __device__ __forceinline__ bool Slab(float mnx, float mny, float mnz, float mxx,
 	float c0 = ((nz ? mxz : mnz) - o.z) * inv.z, c1 = ((nz ? mnz : mxz) - o.z) * inv.z;
 	tn = fmaxf(tn, c0); tf = fminf(tf, c1);
 	tNear = tn;
-	return !(tf * 1.0000004f < tn);
+	return !(tf * widen < tn);
 }
 
 // First traversal step only: true when the ray misses both child boxes of the root node.
@@ -1001,6 +1001,625 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	}
 }
 
+// ---------------------------------------------------------------------------
+// The pool megakernel.  Same job queue, same per-path arithmetic and the same outputs as k_trace, but a wave
+// no longer runs "one ray per lane per trip".  Each wave owns a POOL of 64*K paths:
+//   - the per-ray data the traversal needs (origin, direction, time) and gives back (t, primitive, barycentrics)
+//     sit in LDS, one column per pool slot;
+//   - the rest of a path (RNG state, output index, depth) stays in the registers of the slot's HOME lane
+//     (slot = p*64 + lane), its vertex records in the global path stack.
+// A trip is: refill the free slots (wave64 ballot + prefix ranks, compacted: up to 64 new camera rays are generated
+// by the low lanes and dealt to the free slots through LDS), then ONE traversal phase over the whole pool, then K
+// shading passes.  In the traversal phase a lane takes the next un-traced slot from the pool whenever it has
+// finished its ray ("dynamic fetch"; the ray's home lane is irrelevant), so a wave's traversal time is the
+// SUM of its rays' steps / 64 plus a tail, instead of the MAX over lanes per bounce.  The sun query of the miss
+// shader (renderer.cc:192-197) goes through the pool like any other ray instead of being traced inline by the few
+// lanes that missed.
+enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_TIME, F_T, F_TRI, F_A, F_B, F_COUNT };
+#define Q_CLOSEST  (-1)   /* F_TRI before traversal: closest-hit query; after: missed everything */
+#define Q_SHADOW   (-2)   /* before: occlusion query towards the sun (sky part parked in F_D*); after: not occluded */
+#define Q_EMPTY    (-3)   /* no path in this slot */
+#define Q_OCCLUDED (-4)   /* after a Q_SHADOW query: something is in the way */
+#define Q_PENDING  (-5)   /* a lane is tracing this slot's closest-hit query (it may take more than one trip) */
+#define Q_PENDING_SHADOW (-6)
+#define Q_MISS     (-7)   /* result of a closest-hit query that hit nothing (distinct from Q_CLOSEST: a straggler may deliver it while the next phase is handing out slots) */
+#define Q_CLEAR    (-8)   /* result of a sun query: nothing in the way */
+#define RL_POOL_WIDEN 1.0000007f   /* slab test with v_rcp_f32 reciprocals: 6 ulp instead of Slab()'s 3 */
+#ifndef RL_POOL_CUT
+#define RL_POOL_CUT 12    /* with the pool handed out: shade once no more than this many lanes still traverse */
+#endif
+#ifndef RL_POOL_VOTE
+#define RL_POOL_VOTE 1    /* traversal steps by majority vote (node step | primitive step) instead of while-while rounds */
+#endif
+#ifndef RL_POOL_WNODE
+#define RL_POOL_WNODE 4   /* relative cost of a node step and a primitive step in the vote */
+#define RL_POOL_WLEAF 5
+#endif
+#ifndef RL_POOL_KEEP
+#define RL_POOL_KEEP 40   /* leave the traversal loop to fetch new rays when no more than this many lanes still traverse */
+#endif
+
+__device__ __forceinline__ void WaveLdsSync()
+{
+	// LDS operations of one wave are executed in issue order; this only stops the compiler from moving LDS
+	// accesses of different lanes' data across the point.
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+struct Trav { V3 o, d, inv; float rayTime; bool nx, ny, nz, anyhit; HitRec best; int cur, sp, leafI; };
+
+// One while-while round of Traverse() on a resumable state: descend to the next leaf, intersect it, pop.
+// Returns true when the ray is finished (result in T.best).
+template <int STACK, bool PRIMS>
+__device__ __forceinline__ bool TraverseRound(const DSceneView& S, Trav& T, float tMin, int* stk, Counters& c)
+{
+	const int DONE = 0x7fffffff;
+	int cur = T.cur, sp = T.sp;
+	while (cur >= 0 && cur != DONE) {
+		RL_WSTEP(4);
+		const float4* np = (const float4*)(S.nodes + cur);
+		const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+		const int4 k = ((const int4*)np)[3];
+		c.nodes++;
+		float tl, tr;
+		const float tmx = fminf(T.best.t, FLT_MAX);
+		bool hl = Slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tl);
+		bool hr = Slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tr);
+		hl = hl && (k.x != DNODE_EMPTY);
+		hr = hr && (k.y != DNODE_EMPTY);
+		if (hl && hr) {
+			const bool leftFirst = tl <= tr;
+			const int nearC = leftFirst ? k.x : k.y, farC = leftFirst ? k.y : k.x;
+			if (sp < STACK) { stk[sp * RL_BLOCK] = farC; ++sp; }
+			cur = nearC;
+		} else if (hl) cur = k.x;
+		else if (hr) cur = k.y;
+		else if (sp == 0) cur = DONE;
+		else { --sp; cur = stk[sp * RL_BLOCK]; }
+	}
+	if (cur == DONE) { T.cur = cur; T.sp = sp; return true; }
+	{
+		RL_WSTEP(6);
+		const uint32_t code = (uint32_t)~cur;
+		const int first = (int)(code >> 6);
+		const int count = (int)(code & 7u) + 1;
+		const bool alpha = (code & 8u) != 0;
+		const uint32_t kind = (code >> 4) & 3u;
+		const V3 o = T.o, d = T.d;
+		if (!PRIMS || kind == 0u) {
+			for (int i = 0; i < count; ++i) {
+				RL_WSTEP(5);
+				const Tri TT = LoadTri(S, first + i);
+				c.tris++;
+				// reference geom/triangle.cc:22-27
+				const float t = dot((TT.v0 - o), TT.n) / dot(d, TT.n);
+				if (!(t >= tMin && t <= FLT_MAX && t < T.best.t)) continue;
+				const V3 pp = o + t * d;
+				const V3 w = pp - TT.v0;
+				const float wv = dot(w, TT.v), wu = dot(w, TT.u);
+				const float pa = (TT.uv * wv - TT.vv * wu) / TT.denom;
+				const float pb = (TT.uv * wu - TT.uu * wv) / TT.denom;
+				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
+					if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
+					T.best.t = t; T.best.a = pa; T.best.b = pb; T.best.tri = first + i;
+					if (T.anyhit) { T.cur = DONE; T.sp = 0; return true; }
+				}
+			}
+		} else {
+			c.tris++;
+			float2 r;
+			if (kind == 1u) r = make_float2(SphereHit(S.spheres, first, o, d, tMin, T.best.t), 0.0f);
+			else r = CubeHit(S.cubes, first, o, d, T.rayTime, tMin, T.best.t);
+			if (r.x == r.x) {   // not NaN: a hit
+				T.best.t = r.x; T.best.a = r.y; T.best.b = 0.0f; T.best.tri = (int)((kind << 28) | (uint32_t)first);
+				if (T.anyhit) { T.cur = DONE; T.sp = 0; return true; }
+			}
+		}
+	}
+	if (sp == 0) { T.cur = DONE; T.sp = 0; return true; }
+	--sp;
+	T.cur = stk[sp * RL_BLOCK]; T.sp = sp;
+	return false;
+}
+
+// Single steps on the resumable state, for the vote-driven loop of k_trace_pool: a lane is either at an inner node
+// (cur >= 0), at a leaf (cur < 0, leafI = next primitive of it), or finished (both return true then).
+template <int STACK>
+__device__ __forceinline__ bool PopOrFinish(Trav& T, int* stk)
+{
+	if (T.sp == 0) return true;
+	--T.sp;
+	T.cur = stk[T.sp * RL_BLOCK];
+	T.leafI = 0;
+	return false;
+}
+template <int STACK>
+__device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMin, int* stk, Counters& c)
+{
+	RL_WSTEP(4);
+	const float4* np = (const float4*)(S.nodes + T.cur);
+	const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+	const int4 k = ((const int4*)np)[3];
+	c.nodes++;
+	float tl, tr;
+	const float tmx = fminf(T.best.t, FLT_MAX);
+	bool hl = Slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tl, RL_POOL_WIDEN);
+	bool hr = Slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tr, RL_POOL_WIDEN);
+	hl = hl && (k.x != DNODE_EMPTY);
+	hr = hr && (k.y != DNODE_EMPTY);
+	T.leafI = 0;
+	if (hl && hr) {
+		const bool leftFirst = tl <= tr;
+		const int nearC = leftFirst ? k.x : k.y, farC = leftFirst ? k.y : k.x;
+		if (T.sp < STACK) { stk[T.sp * RL_BLOCK] = farC; ++T.sp; }
+		T.cur = nearC;
+		return false;
+	}
+	if (hl) { T.cur = k.x; return false; }
+	if (hr) { T.cur = k.y; return false; }
+	return PopOrFinish<STACK>(T, stk);
+}
+template <int STACK, bool PRIMS>
+__device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMin, int* stk, Counters& c)
+{
+	RL_WSTEP(5);
+	const uint32_t code = (uint32_t)~T.cur;
+	const int first = (int)(code >> 6);
+	const int count = (int)(code & 7u) + 1;
+	const bool alpha = (code & 8u) != 0;
+	const uint32_t kind = (code >> 4) & 3u;
+	const V3 o = T.o, d = T.d;
+	c.tris++;
+	if (!PRIMS || kind == 0u) {
+		const int i = first + T.leafI;
+		const Tri TT = LoadTri(S, i);
+		// reference geom/triangle.cc:22-27
+		const float t = dot((TT.v0 - o), TT.n) / dot(d, TT.n);
+		if (t >= tMin && t <= FLT_MAX && t < T.best.t) {
+			const V3 pp = o + t * d;
+			const V3 w = pp - TT.v0;
+			const float wv = dot(w, TT.v), wu = dot(w, TT.u);
+			const float pa = (TT.uv * wv - TT.vv * wu) / TT.denom;
+			const float pb = (TT.uv * wu - TT.uu * wv) / TT.denom;
+			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
+				if (!alpha || AlphaTestCandidate(S, i, pa, pb, c)) {
+					T.best.t = t; T.best.a = pa; T.best.b = pb; T.best.tri = i;
+					if (T.anyhit) return true;
+				}
+			}
+		}
+	} else {
+		float2 r;
+		if (kind == 1u) r = make_float2(SphereHit(S.spheres, first, o, d, tMin, T.best.t), 0.0f);
+		else r = CubeHit(S.cubes, first, o, d, T.rayTime, tMin, T.best.t);
+		if (r.x == r.x) {   // not NaN: a hit
+			T.best.t = r.x; T.best.a = r.y; T.best.b = 0.0f; T.best.tri = (int)((kind << 28) | (uint32_t)first);
+			if (T.anyhit) return true;
+		}
+	}
+	if (++T.leafI < count) return false;
+	return PopOrFinish<STACK>(T, stk);
+}
+
+// sky part of the miss shader (reference render/renderer.cc:155-181)
+__device__ __forceinline__ V3 MissSky(const DSceneView& S, const SkyRot& R, V3 d, Counters& c)
+{
+	V3 missResult = v3s(0.0f);
+	if (S.skyTexture >= 0) {
+		V3 dir = normalize(d);
+		V3 D = v3(dot(ld3(R.m0), dir), dot(ld3(R.m1), dir), dot(ld3(R.m2), dir));
+		float u = rtm::atan2_(D.z, D.x), v = rtm::asin_(D.y);
+		u *= 0.1591f; v *= 0.3183f;
+		u += 0.5f; v += 0.5f;
+		const DTexture T = S.textures[S.skyTexture];
+		int x = (int)(u * (float)(uint32_t)(T.width - 1));
+		int y = (int)(v * (float)(uint32_t)(T.height - 1));
+		float4 px = ((const float4*)S.texels)[T.offset + (uint32_t)(y * T.width + x)];
+		c.texels++;
+		missResult = missResult + v3(px.x, px.y, px.z);
+	}
+	return missResult;
+}
+
+// Radiance folded from the last vertex back to the camera: radiance = (0 + refl*Li*sp/pdf) + E at every vertex,
+// in the reference's operation order (renderer.cc:139-151).
+__device__ __forceinline__ V3 FoldPath(const float* __restrict__ pathStack, uint32_t stackStride, uint32_t home, int depth, V3 L)
+{
+	for (int k = depth - 1; k >= 0; --k) {
+		const float4* rec = (const float4*)pathStack + ((size_t)k * stackStride + home) * 2u;
+		const float4 r0 = rec[0], r1 = rec[1];
+		const V3 refl = v3(r0.x, r0.y, r0.z);
+		const float sp = r0.w, pdf = r1.x;
+		const V3 E = v3(r1.y, r1.z, r1.w);
+		V3 radiance = v3s(0.0f);
+		radiance = radiance + refl * L * sp / pdf;
+		radiance = radiance + E;
+		L = radiance;
+	}
+	return L;
+}
+
+template <int STACK, int K> struct PoolOcc {
+	static constexpr int kLdsPerBlock = STACK * RL_BLOCK * 4 + (RL_BLOCK / 64) * (F_COUNT * 64 * K * 4 + 64 * K);
+	static constexpr int kFit = (160 * 1024) / kLdsPerBlock;
+	static constexpr int kBlocks = kFit < 1 ? 1 : (kFit > 4 ? 4 : kFit);
+};
+
+// v_rcp_f32 (1 ulp) is enough for the slab test's 1/d: Slab() is only asked to be conservative, and PoolSlab widens by
+// 6 ulp instead of Slab()'s 2.  0 -> inf and the sign of a zero survive, as with the division.
+__device__ __forceinline__ float FastRcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+template <int STACK, bool PRIMS, int K>
+__global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<STACK, K>::kBlocks))
+k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
+             float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
+{
+	constexpr int PP = 64 * K;
+	__shared__ int s_stack[STACK * RL_BLOCK];
+	__shared__ float s_pool[RL_BLOCK / 64][F_COUNT][PP];
+	__shared__ unsigned char s_free[RL_BLOCK / 64][PP];
+	int* stk = s_stack + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	float (*pool)[PP] = s_pool[wave];
+	unsigned char* freeList = s_free[wave];
+	const uint32_t numSlots = P.numLocalCells * 64u;
+	const unsigned long long laneLt = (1ull << lane) - 1ull;
+	// path-stack column of home slot p: consecutive lanes -> consecutive columns
+	const uint32_t homeBase = blockIdx.x * (RL_BLOCK * K) + threadIdx.x;
+
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);
+	// home-lane registers of slot p*64 + lane
+	unsigned long long stRng[K];
+	uint32_t stOut[K];
+	int stDepth[K];
+	bool stActive[K];
+	#pragma unroll
+	for (int p = 0; p < K; ++p) { stRng[p] = 0; stOut[p] = 0; stDepth[p] = 0; stActive[p] = false; pool[F_TRI][p * 64 + lane] = __int_as_float(Q_EMPTY); }
+	uint32_t chunkNext = 0, chunkEnd = 0;
+	bool globalDone = false, exhausted = false;   // wave-uniform
+	// traversal state of the ray this lane is tracing; survives trips (a straggler keeps going while the rest of the pool is shaded)
+	bool busy = false;
+	int mySlot = 0;
+	Trav T;
+	T.o = T.d = T.inv = v3s(0.0f); T.rayTime = 0.0f; T.nx = T.ny = T.nz = T.anyhit = false;
+	T.best.t = INFINITY; T.best.a = T.best.b = 0.0f; T.best.tri = -1; T.cur = 0; T.sp = 0; T.leafI = 0;
+#ifdef RL_DIAG_STAMPS
+	unsigned long long stampAcc[4] = { 0, 0, 0, 0 };
+	c.diag = counters;
+	unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+	#define RL_PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[k] += now_ - stampLast; stampLast = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+	#define RL_PSTAMP(k)
+#endif
+
+#ifdef RL_POOL_WATCHDOG
+	uint32_t wdSteps = 0, wdTrips = 0; bool wdAbort = false;
+#endif
+	for (;;) {
+#ifdef RL_POOL_WATCHDOG
+		if (++wdTrips > 20000u || __ballot(wdAbort) != 0ull) {
+			uint32_t nAct = 0, nEmpty = 0, nQ = 0, nH = 0, nPend = 0, nRes = 0;
+			for (int p = 0; p < K; ++p) {
+				const int q = __float_as_int(pool[F_TRI][p * 64 + (int)lane]);
+				nAct += (uint32_t)__popcll(__ballot(stActive[p]));
+				nEmpty += (uint32_t)__popcll(__ballot(stActive[p] && q == Q_EMPTY));
+				nQ += (uint32_t)__popcll(__ballot(stActive[p] && (q == Q_CLOSEST || q == Q_SHADOW)));
+				nH += (uint32_t)__popcll(__ballot(stActive[p] && q >= 0));
+				nPend += (uint32_t)__popcll(__ballot(stActive[p] && (q == Q_PENDING || q == Q_PENDING_SHADOW)));
+				nRes += (uint32_t)__popcll(__ballot(stActive[p] && (q == Q_MISS || q == Q_CLEAR || q == Q_OCCLUDED)));
+			}
+			if (lane == 0) {
+				atomicAdd(&counters[CNT_COUNT + 21], 1ull);
+				atomicAdd(&counters[CNT_COUNT + 4], (unsigned long long)nAct); atomicAdd(&counters[CNT_COUNT + 5], (unsigned long long)nEmpty);
+				atomicAdd(&counters[CNT_COUNT + 6], (unsigned long long)nQ); atomicAdd(&counters[CNT_COUNT + 7], (unsigned long long)nH);
+				atomicAdd(&counters[CNT_COUNT + 8], (unsigned long long)nPend); atomicAdd(&counters[CNT_COUNT + 9], (unsigned long long)nRes);
+				atomicAdd(&counters[CNT_COUNT + 10], (unsigned long long)(exhausted ? 1 : 0)); atomicAdd(&counters[CNT_COUNT + 11], (unsigned long long)__popcll(__ballot(busy)));
+			}
+			break;
+		}
+#endif
+		// ---- refill: deal new camera samples to the free slots (wave64 ballot + prefix ranks) ----
+		if (!exhausted) {
+			uint32_t pos[K];
+			uint32_t nFree = 0;
+			#pragma unroll
+			for (int p = 0; p < K; ++p) {
+				const bool fr = !stActive[p];
+				const unsigned long long m = __ballot(fr);
+				pos[p] = fr ? nFree + (uint32_t)__popcll(m & laneLt) : 0xffffffffu;
+				if (fr) freeList[pos[p]] = (unsigned char)(p * 64 + (int)lane);
+				nFree += (uint32_t)__popcll(m);
+			}
+			WaveLdsSync();
+			uint32_t filled = 0;
+			for (int round = 0; round < RL_REFILL_ROUNDS && filled < nFree; ++round) {
+				if (chunkNext >= chunkEnd && !globalDone) {
+					uint32_t base = 0;
+					if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
+					base = __shfl(base, 0);
+					if (base >= P.numJobs) globalDone = true;
+					else { chunkNext = base; chunkEnd = min(base + P.jobChunk, P.numJobs); }
+				}
+				const uint32_t avail = chunkEnd - chunkNext;
+				if (avail == 0) { exhausted = true; break; }
+				const uint32_t take = min(min(64u, nFree - filled), avail);
+				bool alive = false;
+				V3 o = v3s(0.0f), d = v3s(0.0f);
+				float rayTime = 0.0f;
+				Rng g; g.s.state = 0;
+				uint32_t outIndex = 0;
+				if (lane < take) {
+					const JobPixel j = DecodeJob(P, chunkNext + lane);
+					if (j.valid) {
+						// GenerateCell body, reference render/renderer.cc:232-239
+						const uint32_t sidx = P.sampleBegin + j.sample;
+						g.s = raylib_rng_begin_mixed(P.seedMixed, j.y * P.width + j.x, sidx);
+						const float imageWidth = (float)P.width, imageHeight = (float)P.height;
+						float u = (float)j.x / imageWidth;
+						float v = (float)j.y / imageHeight;
+						if (sidx != 0) {
+							u += (Next(g) - 0.5f) * 2.0f / imageWidth;
+							v += (Next(g) - 0.5f) * 2.0f / imageHeight;
+						}
+						CameraRay(P.camera, u, v, g, o, d, rayTime);
+						outIndex = j.sample * numSlots + j.slot;
+						alive = true;
+						c.samples++;
+						if (P.maxPathLength <= 0) {
+							samples[outIndex] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);   // renderer.cc:120-123
+							alive = false;
+						} else if (RootMiss(S, o, d, P.rayTMin)) {
+							// cannot hit anything: sky lookup plus (with a sun) one occlusion query that may be decided at the root too
+							const bool sunQuick = !S.hasSun || RootMiss(S, o, -ld3(S.sunDirection), P.rayTMin);
+							if (sunQuick) {
+								c.rays++; c.nodes++;
+								V3 L = MissSky(S, R, d, c);
+								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
+								samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+								alive = false;
+							}
+						}
+					}
+				}
+				chunkNext += take;
+				const unsigned long long am = __ballot(alive);
+				const uint32_t n = (uint32_t)__popcll(am);
+				if (n == 0) continue;
+				if (alive) {
+					// the r-th surviving ray goes to the (filled + r)-th free slot; the fields a traversal fills in later carry
+					// the RNG state and the output index to the slot's home lane
+					const int f = (int)freeList[filled + (uint32_t)__popcll(am & laneLt)];
+					pool[F_OX][f] = o.x; pool[F_OY][f] = o.y; pool[F_OZ][f] = o.z;
+					pool[F_DX][f] = d.x; pool[F_DY][f] = d.y; pool[F_DZ][f] = d.z;
+					pool[F_TIME][f] = rayTime;
+					pool[F_TRI][f] = __int_as_float(Q_CLOSEST);
+					pool[F_T][f] = __int_as_float((int)(uint32_t)(g.s.state & 0xffffffffull));
+					pool[F_A][f] = __int_as_float((int)(uint32_t)(g.s.state >> 32));
+					pool[F_B][f] = __int_as_float((int)outIndex);
+				}
+				WaveLdsSync();
+				#pragma unroll
+				for (int p = 0; p < K; ++p) {
+					if (pos[p] >= filled && pos[p] < filled + n) {
+						const int slot = p * 64 + (int)lane;
+						stRng[p] = (unsigned long long)(uint32_t)__float_as_int(pool[F_T][slot]) | ((unsigned long long)(uint32_t)__float_as_int(pool[F_A][slot]) << 32);
+						stOut[p] = (uint32_t)__float_as_int(pool[F_B][slot]);
+						stDepth[p] = 0;
+						stActive[p] = true;
+					}
+				}
+				filled += n;
+			}
+		}
+		bool anyActive = false;
+		#pragma unroll
+		for (int p = 0; p < K; ++p) anyActive = anyActive || stActive[p];
+		if (__ballot(anyActive) == 0ull) {
+			if (exhausted) break;
+			continue;
+		}
+		if (lane == 0) c.trips++;
+		RL_PSTAMP(0);
+
+		// ---- traversal phase: every waiting query of the pool; a lane takes the next slot whenever its ray is finished ----
+		{
+			WaveLdsSync();
+			uint32_t nextSlot = 0;
+			uint32_t finished = 0;      // rays completed in this phase (wave-uniform)
+			for (;;) {
+				if (nextSlot < (uint32_t)PP) {
+					const unsigned long long idle = __ballot(!busy);
+					const uint32_t slot = nextSlot + (uint32_t)__popcll(idle & laneLt);
+					if (!busy && slot < (uint32_t)PP) {
+						const int q = __float_as_int(pool[F_TRI][slot]);
+						if (q == Q_CLOSEST || q == Q_SHADOW) {
+							T.o = v3(pool[F_OX][slot], pool[F_OY][slot], pool[F_OZ][slot]);
+							T.anyhit = (q == Q_SHADOW);
+							T.d = T.anyhit ? -ld3(S.sunDirection) : v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
+							T.rayTime = pool[F_TIME][slot];
+							T.inv = v3(FastRcp(T.d.x), FastRcp(T.d.y), FastRcp(T.d.z));
+							T.nx = T.inv.x < 0.0f; T.ny = T.inv.y < 0.0f; T.nz = T.inv.z < 0.0f;
+							T.best.t = INFINITY; T.best.tri = -1; T.best.a = 0.0f; T.best.b = 0.0f;
+							T.cur = 0; T.sp = 0; T.leafI = 0;
+							mySlot = (int)slot;
+							busy = true;
+							pool[F_TRI][slot] = __int_as_float(T.anyhit ? Q_PENDING_SHADOW : Q_PENDING);
+							c.rays++;
+						}
+					}
+					nextSlot += (uint32_t)__popcll(idle);
+				}
+				const int nBusy = (int)__popcll(__ballot(busy));
+				if (nBusy == 0) {
+					if (nextSlot >= (uint32_t)PP) break;
+					continue;
+				}
+				// all queries handed out and only a few long rays left: shade what is there, the stragglers go on next trip
+				if (nextSlot >= (uint32_t)PP && nBusy <= RL_POOL_CUT && finished > 0) break;
+				// one step for the larger (cost-weighted) party, lanes at inner nodes or lanes at leaves, until enough lanes
+				// have finished to make a fetch worth it
+				int nb;
+				do {
+					const bool atNode = busy && T.cur >= 0, atLeaf = busy && T.cur < 0;
+					const int nN = (int)__popcll(__ballot(atNode)), nL = (int)__popcll(__ballot(atLeaf));
+					bool fin = false;
+					if (nN * RL_POOL_WNODE >= nL * RL_POOL_WLEAF) { if (atNode) fin = NodeStep<STACK>(S, T, P.rayTMin, stk, c); }
+					else { if (atLeaf) fin = LeafStep<STACK, PRIMS>(S, T, P.rayTMin, stk, c); }
+					if (fin) {
+						const bool hit = T.best.tri >= 0;
+						int q = T.best.tri;
+						if (T.anyhit) q = hit ? Q_OCCLUDED : Q_CLEAR;
+						else if (!hit) q = Q_MISS;
+						pool[F_T][mySlot] = T.best.t; pool[F_TRI][mySlot] = __int_as_float(q);
+						pool[F_A][mySlot] = T.best.a; pool[F_B][mySlot] = T.best.b;
+						busy = false;
+					}
+#ifdef RL_POOL_WATCHDOG
+					if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); busy = false; wdAbort = true; }
+#endif
+					const unsigned long long bm = __ballot(busy);
+					nb = (int)__popcll(bm);
+					finished += (uint32_t)__popcll(__ballot(fin));
+				} while (nb > (nextSlot < (uint32_t)PP ? RL_POOL_KEEP : (finished > 0 ? RL_POOL_CUT : 0)));
+			}
+			WaveLdsSync();
+		}
+		RL_PSTAMP(1);
+
+		// ---- shading (TraceScene after the accel->Hit call, reference render/renderer.cc:129-208) ----
+		// (1) the cheap outcomes are finished by the slot's home lane: a miss runs the sky lookup and (with a sun) turns
+		//     into an occlusion query, a returned occlusion query ends the path.  Hits are only LISTED.
+		uint32_t nHit = 0, nQuery = 0;
+		uint32_t hitIdx[K];
+		#pragma unroll
+		for (int p = 0; p < K; ++p) {
+			const int slot = p * 64 + (int)lane;
+			const int q = __float_as_int(pool[F_TRI][slot]);
+			const bool isHit = stActive[p] && q >= 0;
+			bool isQuery = stActive[p] && (q == Q_CLOSEST || q == Q_SHADOW || q == Q_PENDING || q == Q_PENDING_SHADOW);
+			if (stActive[p] && (q == Q_MISS || q == Q_CLEAR || q == Q_OCCLUDED)) {
+				const V3 d = v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
+				bool done = true;
+				V3 L;
+				if (q == Q_MISS) {
+					L = MissSky(S, R, d, c);
+					if (S.hasSun) {
+						// the sky part waits in the direction fields (the sun query brings its own direction)
+						pool[F_DX][slot] = L.x; pool[F_DY][slot] = L.y; pool[F_DZ][slot] = L.z;
+						pool[F_TRI][slot] = __int_as_float(Q_SHADOW);
+						done = false; isQuery = true;
+					}
+				} else {
+					L = d;
+					if (q == Q_CLEAR) L = L + ld3(S.sunIlluminance);
+				}
+				if (done) {
+					L = FoldPath(pathStack, P.stackStride, homeBase + (uint32_t)p * RL_BLOCK, stDepth[p], L);
+					samples[stOut[p]] = make_float4(L.x, L.y, L.z, 1.0f);
+					stActive[p] = false;
+					pool[F_TRI][slot] = __int_as_float(Q_EMPTY);
+				}
+			}
+			const unsigned long long hm = __ballot(isHit);
+			hitIdx[p] = isHit ? nHit + (uint32_t)__popcll(hm & laneLt) : 0xffffffffu;
+			if (isHit) freeList[hitIdx[p]] = (unsigned char)slot;
+			nHit += (uint32_t)__popcll(hm);
+			nQuery += (uint32_t)__popcll(__ballot(isQuery));
+		}
+		WaveLdsSync();
+		// (2) hits are shaded 64 at a time by whichever lane: the expensive material code always runs with a full wave.
+		//     A remainder below 64 waits in its slots for the next trip's hits (unless nothing else is going on).
+		//     The path registers come from the home lane by ds_bpermute and return through the slot's hit fields.
+		uint32_t shadedEnd = 0;
+		for (;;) {
+			if (shadedEnd >= nHit) break;
+			if (nHit - shadedEnd < 64u && !(exhausted && nQuery == 0)) break;
+#ifdef RL_POOL_WATCHDOG
+			if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); wdAbort = true; break; }
+#endif
+			const uint32_t idx = shadedEnd + lane;
+			const bool on = idx < nHit;
+			const int slot = on ? (int)freeList[idx] : 0;
+			const int h = slot & 63, pp = slot >> 6;
+			uint32_t rngLo = 0, rngHi = 0, outIndex = 0; int depth = 0;
+			#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				const uint32_t a0 = (uint32_t)__shfl((int)(uint32_t)(stRng[k] & 0xffffffffull), h);
+				const uint32_t a1 = (uint32_t)__shfl((int)(uint32_t)(stRng[k] >> 32), h);
+				const uint32_t a2 = (uint32_t)__shfl((int)stOut[k], h);
+				const int a3 = __shfl(stDepth[k], h);
+				if (pp == k) { rngLo = a0; rngHi = a1; outIndex = a2; depth = a3; }
+			}
+			uint32_t cont = 0;
+			if (on) {
+				const V3 o = v3(pool[F_OX][slot], pool[F_OY][slot], pool[F_OZ][slot]);
+				const V3 d = v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
+				HitRec hr; hr.t = pool[F_T][slot]; hr.tri = __float_as_int(pool[F_TRI][slot]); hr.a = pool[F_A][slot]; hr.b = pool[F_B][slot];
+				const uint32_t home = blockIdx.x * (RL_BLOCK * K) + (uint32_t)pp * RL_BLOCK + wave * 64u + (uint32_t)h;
+				Rng g; g.s.state = (unsigned long long)rngLo | ((unsigned long long)rngHi << 32);
+				Surf sf;
+				const Mat m = LoadMat(S, BuildSurface<PRIMS>(S, o, d, hr, sf, true, c));
+				V3 refl = v3s(0.0f), outD = v3s(0.0f);
+				float pdf = 0.0f, sp = 0.0f;
+				const bool scattered = Scatter(S, m, d, sf, g, c, refl, outD, pdf, sp);
+				const V3 E = Emitted(S, m, sf, c);
+				bool done = false;
+				V3 L = v3s(0.0f);
+				if (scattered && pdf > 0.0f) {
+					float4* rec = (float4*)pathStack + ((size_t)depth * P.stackStride + home) * 2u;
+					rec[0] = make_float4(refl.x, refl.y, refl.z, sp);
+					rec[1] = make_float4(pdf, E.x, E.y, E.z);
+					depth++;
+					if (depth >= P.maxPathLength) done = true;   // the next TraceScene returns 0 at once (renderer.cc:120-123)
+					else {
+						pool[F_OX][slot] = sf.p.x; pool[F_OY][slot] = sf.p.y; pool[F_OZ][slot] = sf.p.z;
+						pool[F_DX][slot] = outD.x; pool[F_DY][slot] = outD.y; pool[F_DZ][slot] = outD.z;
+						pool[F_TRI][slot] = __int_as_float(Q_CLOSEST);
+						cont = 1;
+					}
+				} else {
+					L = v3s(0.0f) + E;                            // radiance(0) += Emitted, renderer.cc:137,151
+					done = true;
+				}
+				if (done) {
+					L = FoldPath(pathStack, P.stackStride, home, depth, L);
+					samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+					pool[F_TRI][slot] = __int_as_float(Q_EMPTY);
+				}
+				// back to the home lane: RNG state and depth (negative = the path has ended)
+				pool[F_T][slot] = __int_as_float((int)(uint32_t)(g.s.state & 0xffffffffull));
+				pool[F_A][slot] = __int_as_float((int)(uint32_t)(g.s.state >> 32));
+				pool[F_B][slot] = __int_as_float(done ? -1 : depth);
+			}
+			nQuery += (uint32_t)__popcll(__ballot(cont != 0));
+			shadedEnd += 64u;
+		}
+		WaveLdsSync();
+		// (3) the home lanes take their registers back
+		#pragma unroll
+		for (int p = 0; p < K; ++p) {
+			if (hitIdx[p] < shadedEnd) {
+				const int slot = p * 64 + (int)lane;
+				stRng[p] = (unsigned long long)(uint32_t)__float_as_int(pool[F_T][slot]) | ((unsigned long long)(uint32_t)__float_as_int(pool[F_A][slot]) << 32);
+				const int dd = __float_as_int(pool[F_B][slot]);
+				if (dd < 0) stActive[p] = false; else stDepth[p] = dd;
+			}
+		}
+		RL_PSTAMP(2);
+	}
+
+#ifdef RL_DIAG_STAMPS
+	if (lane == 0) for (int k = 0; k < 4; ++k) { atomicAdd(&counters[CNT_COUNT + k], stampAcc[k]); atomicAdd(&counters[CNT_COUNT + 12 + k], c.tAcc[k]); }
+#endif
+	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples, c.trips };
+	for (int k = 0; k < CNT_COUNT; ++k) {
+		unsigned long long v = vals[k];
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+		if (lane == 0 && v) atomicAdd(&counters[k], v);
+	}
+}
+
 // Sequential per-pixel sum of this batch's samples, then (last batch) the mean.
 // reference render/renderer.cc:244-248 + core/vec3.h:214-220 (operator/= multiplies by 1/SPP)
 __global__ void __launch_bounds__(RL_BLOCK)
@@ -1422,6 +2041,21 @@ bool UploadScene(Scene& sc)
 	return true;
 }
 
+typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot, float4*, float*, unsigned long long*, unsigned int*);
+
+// poolK = 0: k_trace (one path per lane); poolK = K: k_trace_pool with 64*K paths per wave
+template <int STACK, bool PRIMS>
+TraceKernel SelectTraceKernel(int& poolK)
+{
+	if constexpr (STACK <= 32 && !PRIMS) {
+		if (poolK == 2) return k_trace_pool<STACK, PRIMS, 2>;
+		if (poolK == 3) return k_trace_pool<STACK, PRIMS, 3>;
+		if (poolK == 4) return k_trace_pool<STACK, PRIMS, 4>;
+	}
+	poolK = 0;
+	return k_trace<STACK, PRIMS>;
+}
+
 template <int STACK, bool PRIMS>
 bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 {
@@ -1466,8 +2100,12 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		if (const char* e = getenv("RAYLIB_SAMPLE_BATCH")) { int v = atoi(e); if (v > 0) batch = std::min<uint32_t>((uint32_t)v, SPP); }
 		if (!Grow(R.samples, R.samplesBytes, perSample * batch)) return false;
 		if (batch < SPP && !Grow(R.accum, R.accumBytes, perSample)) return false;
+		int poolK = 0;
+		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
+		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK);
+		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
 		int blocksPerCU = 0;
-		HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, (k_trace<STACK, PRIMS>), RL_BLOCK, 0));
+		HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, traceKernel, RL_BLOCK, 0));
 		if (blocksPerCU < 1) blocksPerCU = 1;
 		if (const char* e = getenv("RAYLIB_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) blocksPerCU = v; }
 		const int depthSlots = st.maxPathLength > 1 ? st.maxPathLength : 1;
@@ -1478,9 +2116,9 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 			const uint64_t jobs64 = (uint64_t)numLocalCells * cnt * 64u;
 			if (jobs64 > 0xFFFFFF00ull) { Log("Raylib_Render: job count overflow"); return false; }
 			P.numJobs = (uint32_t)jobs64;
-			uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)R.numCUs * blocksPerCU, (jobs64 + RL_BLOCK - 1) / RL_BLOCK);
+			uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)R.numCUs * blocksPerCU, (jobs64 + RL_BLOCK * pathsPerThread - 1) / (RL_BLOCK * pathsPerThread));
 			if (blocks < 1) blocks = 1;
-			P.stackStride = blocks * RL_BLOCK;
+			P.stackStride = blocks * RL_BLOCK * pathsPerThread;
 			{   // jobs per global atomic: ~1/8 of a wave's share, a multiple of 64 (one cell at one sample), 64..1024
 				const uint64_t waves = (uint64_t)blocks * (RL_BLOCK / 64);
 				uint64_t chunk = (jobs64 / (waves * 8)) & ~63ull;
@@ -1490,7 +2128,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
 			HIP_OK(hipMemsetAsync(R.jobCounter, 0, sizeof(unsigned int), R.stream));
 			HIP_OK(hipEventRecord(R.ev[2], R.stream));
-			hipLaunchKernelGGL((k_trace<STACK, PRIMS>), dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
+			hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
 			                   P, D->view, D->skyRot, R.samples, R.pathStack, R.counters, R.jobCounter);
 			HIP_OK(hipGetLastError());
 			HIP_OK(hipEventRecord(R.ev[3], R.stream));
@@ -1553,7 +2191,8 @@ bool DeviceRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	if (!UploadScene(sc)) return false;
 	bool ok;
 	const bool prims = !sc.spheres.empty() || !sc.cubes.empty();
-	if (sc.bvh.depth <= 32) ok = prims ? LaunchRender<32, true>(sc, req, stats) : LaunchRender<32, false>(sc, req, stats);
+	if (sc.bvh.depth <= 16 && !prims) ok = LaunchRender<16, false>(sc, req, stats);
+	else if (sc.bvh.depth <= 32) ok = prims ? LaunchRender<32, true>(sc, req, stats) : LaunchRender<32, false>(sc, req, stats);
 	else if (sc.bvh.depth <= 64) ok = prims ? LaunchRender<64, true>(sc, req, stats) : LaunchRender<64, false>(sc, req, stats);
 	else { Log("Raylib_Render: BVH depth %u exceeds the traversal stack (64)", sc.bvh.depth); ok = false; }
 	stats.wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
