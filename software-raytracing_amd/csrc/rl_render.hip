@@ -1015,7 +1015,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 // SUM of its rays' steps / 64 plus a tail, instead of the MAX over lanes per bounce.  The sun query of the miss
 // shader (renderer.cc:192-197) goes through the pool like any other ray instead of being traced inline by the few
 // lanes that missed.
-enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_TIME, F_T, F_TRI, F_A, F_B, F_COUNT };
+enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_COUNT };   // F_TIME only exists in scenes with moving primitives (PRIMS)
 #define Q_CLOSEST  (-1)   /* F_TRI before traversal: closest-hit query; after: missed everything */
 #define Q_SHADOW   (-2)   /* before: occlusion query towards the sun (sky part parked in F_D*); after: not occluded */
 #define Q_EMPTY    (-3)   /* no path in this slot */
@@ -1026,7 +1026,7 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_TIME, F_T, F_TRI, F_A, F_B, F_C
 #define Q_CLEAR    (-8)   /* result of a sun query: nothing in the way */
 #define RL_POOL_WIDEN 1.0000007f   /* slab test with v_rcp_f32 reciprocals: 6 ulp instead of Slab()'s 3 */
 #ifndef RL_POOL_CUT
-#define RL_POOL_CUT 12    /* with the pool handed out: shade once no more than this many lanes still traverse */
+#define RL_POOL_CUT 40    /* with the pool handed out: shade once no more than this many lanes still traverse */
 #endif
 #ifndef RL_POOL_VOTE
 #define RL_POOL_VOTE 1    /* traversal steps by majority vote (node step | primitive step) instead of while-while rounds */
@@ -1036,7 +1036,7 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_TIME, F_T, F_TRI, F_A, F_B, F_C
 #define RL_POOL_WLEAF 5
 #endif
 #ifndef RL_POOL_KEEP
-#define RL_POOL_KEEP 40   /* leave the traversal loop to fetch new rays when no more than this many lanes still traverse */
+#define RL_POOL_KEEP 52   /* leave the traversal loop to fetch new rays when no more than this many lanes still traverse */
 #endif
 
 __device__ __forceinline__ void WaveLdsSync()
@@ -1240,8 +1240,9 @@ __device__ __forceinline__ V3 FoldPath(const float* __restrict__ pathStack, uint
 	return L;
 }
 
-template <int STACK, int K> struct PoolOcc {
-	static constexpr int kLdsPerBlock = STACK * RL_BLOCK * 4 + (RL_BLOCK / 64) * (F_COUNT * 64 * K * 4 + 64 * K);
+template <int STACK, bool PRIMS, int K> struct PoolOcc {
+	static constexpr int kFields = PRIMS ? F_COUNT : F_COUNT - 1;
+	static constexpr int kLdsPerBlock = STACK * RL_BLOCK * 4 + (RL_BLOCK / 64) * (kFields * 64 * K * 4 + 64 * K);
 	static constexpr int kFit = (160 * 1024) / kLdsPerBlock;
 	static constexpr int kBlocks = kFit < 1 ? 1 : (kFit > 4 ? 4 : kFit);
 };
@@ -1251,13 +1252,13 @@ template <int STACK, int K> struct PoolOcc {
 __device__ __forceinline__ float FastRcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 template <int STACK, bool PRIMS, int K>
-__global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<STACK, K>::kBlocks))
+__global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<STACK, PRIMS, K>::kBlocks))
 k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
              float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
 	constexpr int PP = 64 * K;
 	__shared__ int s_stack[STACK * RL_BLOCK];
-	__shared__ float s_pool[RL_BLOCK / 64][F_COUNT][PP];
+	__shared__ float s_pool[RL_BLOCK / 64][PoolOcc<STACK, PRIMS, K>::kFields][PP];
 	__shared__ unsigned char s_free[RL_BLOCK / 64][PP];
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1392,7 +1393,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 					const int f = (int)freeList[filled + (uint32_t)__popcll(am & laneLt)];
 					pool[F_OX][f] = o.x; pool[F_OY][f] = o.y; pool[F_OZ][f] = o.z;
 					pool[F_DX][f] = d.x; pool[F_DY][f] = d.y; pool[F_DZ][f] = d.z;
-					pool[F_TIME][f] = rayTime;
+					if (PRIMS) pool[F_TIME][f] = rayTime;
 					pool[F_TRI][f] = __int_as_float(Q_CLOSEST);
 					pool[F_T][f] = __int_as_float((int)(uint32_t)(g.s.state & 0xffffffffull));
 					pool[F_A][f] = __int_as_float((int)(uint32_t)(g.s.state >> 32));
@@ -1437,7 +1438,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 							T.o = v3(pool[F_OX][slot], pool[F_OY][slot], pool[F_OZ][slot]);
 							T.anyhit = (q == Q_SHADOW);
 							T.d = T.anyhit ? -ld3(S.sunDirection) : v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
-							T.rayTime = pool[F_TIME][slot];
+							T.rayTime = PRIMS ? pool[F_TIME][slot] : 0.0f;
 							T.inv = v3(FastRcp(T.d.x), FastRcp(T.d.y), FastRcp(T.d.z));
 							T.nx = T.inv.x < 0.0f; T.ny = T.inv.y < 0.0f; T.nz = T.inv.z < 0.0f;
 							T.best.t = INFINITY; T.best.tri = -1; T.best.a = 0.0f; T.best.b = 0.0f;
@@ -2100,7 +2101,10 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		if (const char* e = getenv("RAYLIB_SAMPLE_BATCH")) { int v = atoi(e); if (v > 0) batch = std::min<uint32_t>((uint32_t)v, SPP); }
 		if (!Grow(R.samples, R.samplesBytes, perSample * batch)) return false;
 		if (batch < SPP && !Grow(R.accum, R.accumBytes, perSample)) return false;
-		int poolK = 0;
+		// Scheduling of the megakernel: scenes whose BVH needs the 32-entry stack are traversal-bound and run the pool
+		// schedule (k_trace_pool, 128 paths per wave); the Cornell class (tens of triangles, shading-bound) runs one
+		// path per lane (k_trace).  RAYLIB_POOL=0|2|3|4 overrides.
+		int poolK = (STACK > 16 && STACK <= 32 && !PRIMS) ? 2 : 0;
 		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
 		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK);
 		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;

@@ -349,3 +349,75 @@ def test_full_size_tile_union(full_size, gpu_lib):
     world = 8
     bufs = [ses.render_cells(1920, 1080, 64, r, world) for r in range(world)]
     assert np.array_equal(bits(tiling.assemble(1920, 1080, world, bufs)), bits(img))
+
+
+# ---- the pool schedule of the megakernel (k_trace_pool) -------------------------------------
+# Scenes whose BVH is deeper than 16 run it by default; RAYLIB_POOL=K forces it (K = 2, 3, 4 -> 128, 192, 256 paths
+# per wave) and RAYLIB_POOL=0 forces the one-path-per-lane schedule.  Every schedule must produce the same bits.
+
+@pytest.mark.parametrize("pool", ["2", "3", "4"])
+@pytest.mark.parametrize("name", list(helpers.CASES))
+def test_pool_schedule_vs_reference_goldens(name, pool, sessions, gpu_lib, oracle, workdir, monkeypatch):
+    monkeypatch.setenv("RAYLIB_POOL", pool)
+    g = golden(name)
+    ses = sessions[name]
+    c = helpers.CASES[name]
+    _, _, flat = helpers.flat_for_case(name, workdir, oracle)
+    ties = tie_mask(oracle, flat, ffi.make_camera(c["origin"], c["look_at"], c["fov"], c["aspect"]), 64, 64)
+    for spp in (1, 4, 16):
+        img = ses.render(64, 64, spp)
+        assert_same_outside_ties(img, g["mode0_spp%d" % spp], ties, "%s spp %d pool %s" % (name, spp, pool))
+    monkeypatch.setenv("RAYLIB_POOL", "0")
+    base = ses.render(64, 64, 16)
+    st0 = ses.stats().as_dict()
+    monkeypatch.setenv("RAYLIB_POOL", pool)
+    img = ses.render(64, 64, 16)
+    st1 = ses.stats().as_dict()
+    assert np.array_equal(bits(img), bits(base))           # ties included: the closest hit does not depend on the schedule
+    for k in ("rays", "shadedHits", "cameraSamples", "texFetches"):
+        assert st0[k] == st1[k], k                          # same queries, same shading events
+
+
+@pytest.fixture(scope="module")
+def mid_scene(gpu_lib, workdir):
+    """Tessellated room with displaced triangles (about 21 k triangles, sun): BVH deeper than 16 -> pool schedule by default."""
+    from raylib_amd import binding
+    d = os.path.join(str(workdir), "mid"); os.makedirs(d, exist_ok=True)
+    obj, n = helpers.scenes.cornell(os.path.join(d, "mid.obj"), tess=24, displace_fraction=0.2)
+    ses = binding.SceneSession(gpu_lib, obj, (0, 1, 5), (0, 1, -1), 60.0, 96 / 64, sun=(20, 20, 20), sun_dir=(-1.0, -1.0, 0.0))
+    yield ses, obj, n
+    ses.close()
+
+
+def test_pool_schedule_is_default_on_deep_bvh_and_bit_identical(mid_scene, gpu_lib, oracle, monkeypatch):
+    ses, obj, n = mid_scene
+    img = ses.render(96, 64, 8, max_path=6)
+    st = ses.stats().as_dict()
+    assert st["bvhDepth"] > 16 and st["numTriangles"] == n
+    monkeypatch.setenv("RAYLIB_POOL", "0")
+    base = ses.render(96, 64, 8, max_path=6)
+    st0 = ses.stats().as_dict()
+    assert np.array_equal(bits(img), bits(base))
+    assert st["rays"] == st0["rays"] and st["shadedHits"] == st0["shadedHits"]
+    assert st["waveTrips"] != st0["waveTrips"]              # it really was another schedule
+    for k in ("3", "4"):
+        monkeypatch.setenv("RAYLIB_POOL", k)
+        assert np.array_equal(bits(ses.render(96, 64, 8, max_path=6)), bits(base))
+    monkeypatch.delenv("RAYLIB_POOL")
+    # windows recomputed by the CPU oracle with the same pixel keys
+    flat = helpers.objflat.load_obj(obj, oracle, texture_loader=helpers.texture_loader, sun_illuminance=(20, 20, 20), sun_direction=(-1.0, -1.0, 0.0))
+    scene = oracle.scene_create(flat, 1)
+    cam = ffi.make_camera((0, 1, 5), (0, 1, -1), 60.0, 96 / 64)
+    stg = ffi.make_settings(96, 64, 8, max_path=6)
+    for (x0, y0) in ((40, 24), (0, 0), (80, 48)):
+        want = oracle.render_region(scene, cam, stg, x0, y0, 16, 16, seed=1)
+        got = img[y0:y0 + 16, x0:x0 + 16]
+        assert l2(got, want) < L2_TOL
+        assert frac_bit_equal(got, want) > 0.99, "window %d,%d" % (x0, y0)
+
+
+def test_full_size_pool_schedule_bit_identical(full_size, monkeypatch):
+    """BASELINE size: the whole 1080p/64spp frame under the pool schedule equals the default schedule bit for bit."""
+    ses, img, _ = full_size
+    monkeypatch.setenv("RAYLIB_POOL", "2")
+    assert np.array_equal(bits(ses.render(1920, 1080, 64)), bits(img))
