@@ -206,7 +206,7 @@ def main():
                        "rays_per_step": total_rays / args.steps, "camera_samples_per_step": total_samples / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace", "avg_launch_ms": avg_launch_ms, "launches": acc["launches"],
+                         "kernel": "k_trace" if stats.pathsPerWave <= 64 else "k_trace_pool", "paths_per_wave": int(stats.pathsPerWave), "avg_launch_ms": avg_launch_ms, "launches": acc["launches"],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "rank 0's launches; algorithmic bytes = 64 B x (BVH nodes + triangle records + shading records) + 16 B x (texels + pixels)"},
         }

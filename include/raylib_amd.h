@@ -40,6 +40,8 @@ typedef struct RaylibAMDStats {
 	uint32_t numTriangles;
 	uint32_t bvhDepth;
 	uint64_t waveTrips;       /* bounce-loop trips summed over waves: rays / (64 * waveTrips) = share of lane slots that traced a ray */
+	uint32_t pathsPerWave;    /* schedule of the megakernel: 64 = k_trace (one path per lane), 128/192/256 = k_trace_pool */
+	uint32_t reserved0;
 } RaylibAMDStats;
 
 /* Seed of the per-(pixel, sample) streams of include/raylib_amd_rng.h. */

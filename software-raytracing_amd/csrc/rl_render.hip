@@ -228,6 +228,10 @@ __device__ __forceinline__ bool Slab(float mnx, float mny, float mnz, float mxx,
 	return !(tf * widen < tn);
 }
 
+// v_rcp_f32 (1 ulp) is enough for the slab test's 1/d when the test is widened to 6 ulp (RL_POOL_WIDEN) instead of 3:
+// Slab() is only asked to be conservative.  0 -> inf and the sign of a zero survive, as with the division.
+__device__ __forceinline__ float FastRcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // First traversal step only: true when the ray misses both child boxes of the root node.
 __device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float tMin)
 {
@@ -1247,10 +1251,6 @@ template <int STACK, bool PRIMS, int K> struct PoolOcc {
 	static constexpr int kBlocks = kFit < 1 ? 1 : (kFit > 4 ? 4 : kFit);
 };
 
-// v_rcp_f32 (1 ulp) is enough for the slab test's 1/d: Slab() is only asked to be conservative, and PoolSlab widens by
-// 6 ulp instead of Slab()'s 2.  0 -> inf and the sign of a zero survive, as with the division.
-__device__ __forceinline__ float FastRcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
 template <int STACK, bool PRIMS, int K>
 __global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<STACK, PRIMS, K>::kBlocks))
 k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
@@ -2085,6 +2085,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	if (!out) { if (!Grow(R.image, R.imageBytes, outBytes ? outBytes : 16)) return false; out = R.image; }
 
 	HIP_OK(hipMemsetAsync(R.counters, 0, (CNT_COUNT + 24) * sizeof(unsigned long long), R.stream));
+	uint32_t schedulePaths = 1;
 	float traceMs = 0.0f;
 	uint32_t launches = 0;
 	HIP_OK(hipEventRecord(R.ev[0], R.stream));
@@ -2108,6 +2109,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
 		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK);
 		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
+		schedulePaths = pathsPerThread;
 		int blocksPerCU = 0;
 		HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, traceKernel, RL_BLOCK, 0));
 		if (blocksPerCU < 1) blocksPerCU = 1;
@@ -2160,6 +2162,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	stats.rays = cnt[CNT_RAYS]; stats.nodesVisited = cnt[CNT_NODES]; stats.trisTested = cnt[CNT_TRIS];
 	stats.shadedHits = cnt[CNT_SHADED]; stats.texFetches = cnt[CNT_TEXELS]; stats.cameraSamples = cnt[CNT_SAMPLES];
 	stats.waveTrips = cnt[CNT_TRIPS];
+	stats.pathsPerWave = 64u * schedulePaths; stats.reserved0 = 0;
 	if (getenv("RAYLIB_PRINT_STAMPS")) {
 		const double tot = (double)(cnt[CNT_COUNT] + cnt[CNT_COUNT + 1] + cnt[CNT_COUNT + 2] + cnt[CNT_COUNT + 3]);
 		Log("wave steps: node %llu (lane steps %llu, eff %.3f)  tri %llu (lane %llu, eff %.3f)  leaf rounds %llu  trips %llu", cnt[CNT_COUNT + 4], cnt[CNT_NODES], cnt[CNT_NODES] / (64.0 * cnt[CNT_COUNT + 4] + 1), cnt[CNT_COUNT + 5], cnt[CNT_TRIS], cnt[CNT_TRIS] / (64.0 * cnt[CNT_COUNT + 5] + 1), cnt[CNT_COUNT + 6], cnt[CNT_TRIPS]);
