@@ -127,6 +127,9 @@ RAYLIB_API void    RaylibAMD_SceneGetSun(SceneHandle scene, float outIlluminance
 /* BVH shape: nodes (64 B each), depth, and a host-side validity check (every triangle
  * inside its leaf's box, every child box inside its parent's).  Returns 1 if valid. */
 RAYLIB_API int32_t RaylibAMD_SceneBVHInfo(SceneHandle scene, uint32_t* outNodes, uint32_t* outDepth, float* outSahCost);
+/* FNV-1a of the flat BVH (node records + leaf order): the multi-threaded build (RAYLIB_BUILD_THREADS, default = host
+ * threads, <= 32) must give the tree of the single-threaded one. */
+RAYLIB_API uint64_t RaylibAMD_SceneBVHHash(SceneHandle scene);
 /* Camera derived state: 19 floats origin(3) lensRadius top_left(3) horizontal(3) vertical(3) u(3) v(3)
  * (reference render/camera.h:55-78). */
 RAYLIB_API void    RaylibAMD_CameraExport(CameraHandle camera, float out[19]);

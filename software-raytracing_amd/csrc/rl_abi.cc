@@ -473,6 +473,16 @@ int32_t RaylibAMD_SceneBVHInfo(SceneHandle sh, uint32_t* nodes, uint32_t* depth,
 	if (sah) *sah = s->bvh.sahCost;
 	return ValidateBVH(s->bvh, s->triangles) ? 1 : 0;
 }
+uint64_t RaylibAMD_SceneBVHHash(SceneHandle sh)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized) return 0;
+	uint64_t h = 1469598103934665603ull;   // FNV-1a over the node records and the leaf order
+	auto feed = [&h](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+	feed(s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(DNode));
+	feed(s->bvh.triOrder.data(), s->bvh.triOrder.size() * sizeof(uint32_t));
+	return h;
+}
 void RaylibAMD_CameraExport(CameraHandle h, float out[19])
 {
 	Camera* c = (Camera*)h;

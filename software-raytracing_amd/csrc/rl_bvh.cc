@@ -12,8 +12,12 @@
 #include "rl_host.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
+#include <thread>
 
 namespace rl {
 namespace {
@@ -41,87 +45,181 @@ constexpr int kBins = 16;
 constexpr uint32_t kMaxLeaf = 4;
 constexpr float kCostTraverse = 1.0f, kCostTri = 1.0f;
 
-struct Builder {
+// Work shared by the build threads.  The tree is the one a single thread would build, whatever the thread count:
+// bin boxes and counts are min/max/integer sums (order-free), the partition is the serial std::partition on the same
+// input order, sub-trees below a size threshold are built as independent tasks on disjoint ranges of `order`, and the
+// final node array is re-emitted in the serial build's pre-order.
+struct Shared {
 	std::vector<uint8_t> kind;      // per primitive: PRIM_TRIANGLE / PRIM_SPHERE / PRIM_CUBE
 	std::vector<Box> triBox;
 	std::vector<f3> centroid;
 	std::vector<uint32_t> order;
+	unsigned threads = 1;
+	uint32_t taskSize = 0;          // ranges of at most this many primitives become tasks (0: no tasks)
+};
+
+struct Task { uint32_t b, e, depth; };
+
+struct Ctx {
 	std::vector<TmpNode> tmp;
 	uint32_t maxDepth = 0;
+	std::vector<Task>* tasks = nullptr;   // only the top-level context spawns tasks
+};
 
-	// a leaf is either <= kMaxLeaf triangles or exactly one analytic primitive
-	bool leafAllowed(uint32_t b, uint32_t e) const {
-		if (e - b == 1) return true;
-		if (e - b > kMaxLeaf) return false;
-		for (uint32_t i = b; i < e; ++i) if (kind[order[i]] != PRIM_TRIANGLE) return false;
-		return true;
+struct BinSet {
+	Box box[3][kBins]; uint32_t count[3][kBins];
+	void reset() { for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { box[a][k].reset(); count[a][k] = 0; } }
+	void merge(const BinSet& o) { for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { box[a][k].grow(o.box[a][k]); count[a][k] += o.count[a][k]; } }
+};
+
+constexpr uint32_t kParallelRange = 1u << 17;   // ranges at least this long are scanned by all threads
+
+template <typename F>
+void ParallelChunks(unsigned threads, uint32_t b, uint32_t e, F&& fn)
+{
+	const uint32_t n = e - b;
+	if (threads <= 1 || n < kParallelRange) { fn(b, e, 0u); return; }
+	std::vector<std::thread> pool;
+	const uint32_t per = (n + threads - 1) / threads;
+	for (unsigned t = 1; t < threads; ++t) {
+		const uint32_t cb = b + std::min(n, t * per), ce = b + std::min(n, (t + 1) * per);
+		if (cb < ce) pool.emplace_back([&fn, cb, ce, t]() { fn(cb, ce, t); });
 	}
+	fn(b, b + std::min(n, per), 0u);
+	for (std::thread& th : pool) th.join();
+}
 
-	int32_t build(uint32_t b, uint32_t e, uint32_t depth) {
-		TmpNode node;
-		node.box.reset();
-		Box cb; cb.reset();
-		for (uint32_t i = b; i < e; ++i) { node.box.grow(triBox[order[i]]); cb.grow(centroid[order[i]]); }
-		const uint32_t n = e - b;
-		int32_t self = (int32_t)tmp.size();
-		tmp.push_back(node);
+// a leaf is either <= kMaxLeaf triangles or exactly one analytic primitive
+bool leafAllowed(const Shared& S, uint32_t b, uint32_t e)
+{
+	if (e - b == 1) return true;
+	if (e - b > kMaxLeaf) return false;
+	for (uint32_t i = b; i < e; ++i) if (S.kind[S.order[i]] != PRIM_TRIANGLE) return false;
+	return true;
+}
 
-		auto makeLeaf = [&]() {
-			tmp[self].first = b; tmp[self].count = n;
-			if (depth > maxDepth) maxDepth = depth;
-			return self;
-		};
-		if (n <= 1) return makeLeaf();
-
-		// best binned split over the three axes
-		float bestCost = FLT_MAX; int bestAxis = -1; int bestBin = -1;
-		const float parentArea = std::max(node.box.halfArea(), 1e-30f);
-		for (int a = 0; a < 3; ++a) {
-			float lo = axisOf(cb.mn, a), hi = axisOf(cb.mx, a);
-			if (!(hi > lo)) continue;
-			Box binBox[kBins]; uint32_t binCount[kBins];
-			for (int k = 0; k < kBins; ++k) { binBox[k].reset(); binCount[k] = 0; }
-			const float scale = (float)kBins / (hi - lo);
-			for (uint32_t i = b; i < e; ++i) {
-				int k = (int)((axisOf(centroid[order[i]], a) - lo) * scale);
-				k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-				binBox[k].grow(triBox[order[i]]); binCount[k]++;
-			}
-			float rightArea[kBins]; uint32_t rightCount[kBins];
-			Box acc; acc.reset(); uint32_t cnt = 0;
-			for (int k = kBins - 1; k >= 1; --k) { acc.grow(binBox[k]); cnt += binCount[k]; rightArea[k] = acc.halfArea(); rightCount[k] = cnt; }
-			acc.reset(); cnt = 0;
-			for (int k = 0; k < kBins - 1; ++k) {
-				acc.grow(binBox[k]); cnt += binCount[k];
-				if (cnt == 0 || rightCount[k + 1] == 0) continue;
-				float cost = kCostTraverse + kCostTri * (acc.halfArea() * cnt + rightArea[k + 1] * rightCount[k + 1]) / parentArea;
-				if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
-			}
-		}
-
-		uint32_t mid;
-		if (bestAxis < 0) {
-			// all centroids coincide: split by index
-			if (leafAllowed(b, e)) return makeLeaf();
-			mid = b + n / 2;
-		} else {
-			if (leafAllowed(b, e) && bestCost >= kCostTri * n) return makeLeaf();
-			float lo = axisOf(cb.mn, bestAxis), hi = axisOf(cb.mx, bestAxis);
-			const float scale = (float)kBins / (hi - lo);
-			auto it = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t t) {
-				int k = (int)((axisOf(centroid[t], bestAxis) - lo) * scale);
-				k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-				return k <= bestBin;
-			});
-			mid = (uint32_t)(it - order.begin());
-			if (mid == b || mid == e) mid = b + n / 2;
-		}
-		int32_t l = build(b, mid, depth + 1);
-		int32_t r = build(mid, e, depth + 1);
-		tmp[self].left = l; tmp[self].right = r;
+int32_t build(Shared& S, Ctx& C, uint32_t b, uint32_t e, uint32_t depth)
+{
+	const uint32_t n = e - b;
+	const int32_t self = (int32_t)C.tmp.size();
+	C.tmp.push_back(TmpNode());
+	if (C.tasks && n <= S.taskSize && n > 1) {
+		// built later by a worker; the placeholder keeps this node's place in the pre-order
+		C.tmp[self].left = -2 - (int32_t)C.tasks->size();
+		C.tasks->push_back({ b, e, depth });
 		return self;
 	}
-};
+	const unsigned threads = C.tasks ? S.threads : 1u;
+
+	// long ranges of the top levels are scanned by all threads (per-thread partial results, merged in thread order:
+	// min / max / integer sums, so the merge order does not matter)
+	const bool wide = threads > 1 && n >= kParallelRange;
+
+	// bounds of the boxes and of the centroids
+	Box nodeBox, cb;
+	if (!wide) {
+		nodeBox.reset(); cb.reset();
+		for (uint32_t i = b; i < e; ++i) { nodeBox.grow(S.triBox[S.order[i]]); cb.grow(S.centroid[S.order[i]]); }
+	} else {
+		std::vector<Box> nb(threads), cbs(threads);
+		for (unsigned t = 0; t < threads; ++t) { nb[t].reset(); cbs[t].reset(); }
+		ParallelChunks(threads, b, e, [&](uint32_t lo, uint32_t hi, unsigned t) {
+			Box x, y; x.reset(); y.reset();
+			for (uint32_t i = lo; i < hi; ++i) { x.grow(S.triBox[S.order[i]]); y.grow(S.centroid[S.order[i]]); }
+			nb[t] = x; cbs[t] = y;
+		});
+		nodeBox = nb[0]; cb = cbs[0];
+		for (unsigned t = 1; t < threads; ++t) { nodeBox.grow(nb[t]); cb.grow(cbs[t]); }
+	}
+	C.tmp[self].box = nodeBox;
+
+	auto makeLeaf = [&]() {
+		C.tmp[self].first = b; C.tmp[self].count = n;
+		if (depth > C.maxDepth) C.maxDepth = depth;
+		return self;
+	};
+	if (n <= 1) return makeLeaf();
+
+	// binned SAH over the three axes, one pass over the range
+	float lo[3], scale[3]; bool live[3];
+	for (int a = 0; a < 3; ++a) {
+		lo[a] = axisOf(cb.mn, a); const float hi = axisOf(cb.mx, a);
+		live[a] = hi > lo[a];
+		scale[a] = live[a] ? (float)kBins / (hi - lo[a]) : 0.0f;
+	}
+	BinSet bins; bins.reset();
+	auto scan = [&](BinSet& bs, uint32_t cbeg, uint32_t cend) {
+		for (uint32_t i = cbeg; i < cend; ++i) {
+			const uint32_t p = S.order[i];
+			const f3& c = S.centroid[p]; const Box& bx = S.triBox[p];
+			for (int a = 0; a < 3; ++a) {
+				if (!live[a]) continue;
+				int k = (int)((axisOf(c, a) - lo[a]) * scale[a]);
+				k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+				bs.box[a][k].grow(bx); bs.count[a][k]++;
+			}
+		}
+	};
+	if (!wide) scan(bins, b, e);
+	else {
+		std::vector<BinSet> sets(threads);
+		for (BinSet& bs : sets) bs.reset();
+		ParallelChunks(threads, b, e, [&](uint32_t cbeg, uint32_t cend, unsigned t) { scan(sets[t], cbeg, cend); });
+		for (unsigned t = 0; t < threads; ++t) bins.merge(sets[t]);
+	}
+
+	float bestCost = FLT_MAX; int bestAxis = -1; int bestBin = -1;
+	const float parentArea = std::max(nodeBox.halfArea(), 1e-30f);
+	for (int a = 0; a < 3; ++a) {
+		if (!live[a]) continue;
+		float rightArea[kBins]; uint32_t rightCount[kBins];
+		Box acc; acc.reset(); uint32_t cnt = 0;
+		for (int k = kBins - 1; k >= 1; --k) { acc.grow(bins.box[a][k]); cnt += bins.count[a][k]; rightArea[k] = acc.halfArea(); rightCount[k] = cnt; }
+		acc.reset(); cnt = 0;
+		for (int k = 0; k < kBins - 1; ++k) {
+			acc.grow(bins.box[a][k]); cnt += bins.count[a][k];
+			if (cnt == 0 || rightCount[k + 1] == 0) continue;
+			float cost = kCostTraverse + kCostTri * (acc.halfArea() * cnt + rightArea[k + 1] * rightCount[k + 1]) / parentArea;
+			if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
+		}
+	}
+
+	uint32_t mid;
+	if (bestAxis < 0) {
+		// all centroids coincide: split by index
+		if (leafAllowed(S, b, e)) return makeLeaf();
+		mid = b + n / 2;
+	} else {
+		if (leafAllowed(S, b, e) && bestCost >= kCostTri * n) return makeLeaf();
+		const float l0 = lo[bestAxis], sc = scale[bestAxis];
+		auto it = std::partition(S.order.begin() + b, S.order.begin() + e, [&](uint32_t t) {
+			int k = (int)((axisOf(S.centroid[t], bestAxis) - l0) * sc);
+			k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+			return k <= bestBin;
+		});
+		mid = (uint32_t)(it - S.order.begin());
+		if (mid == b || mid == e) mid = b + n / 2;
+	}
+	const int32_t l = build(S, C, b, mid, depth + 1);
+	const int32_t r = build(S, C, mid, e, depth + 1);
+	C.tmp[self].left = l; C.tmp[self].right = r;
+	return self;
+}
+
+// pre-order copy of (top tree + task sub-trees) into one array: the order a single-threaded build pushes nodes in
+int32_t Splice(const std::vector<Ctx>& sub, const std::vector<std::pair<uint32_t, int32_t>>& where, const Ctx& src, int32_t idx, std::vector<TmpNode>& dst)
+{
+	const TmpNode& n = src.tmp[idx];
+	if (n.left <= -2) { const auto& w = where[(size_t)(-2 - n.left)]; return Splice(sub, where, sub[w.first], w.second, dst); }
+	const int32_t self = (int32_t)dst.size();
+	dst.push_back(n);
+	if (n.left >= 0) {
+		const int32_t l = Splice(sub, where, src, n.left, dst);
+		const int32_t r = Splice(sub, where, src, n.right, dst);
+		dst[self].left = l; dst[self].right = r;
+	}
+	return self;
+}
 
 inline void storeBox(float* mn, float* mx, const Box& b) {
 	mn[0] = b.mn.x; mn[1] = b.mn.y; mn[2] = b.mn.z;
@@ -145,7 +243,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		return;
 	}
 
-	Builder B;
+	Shared B;
 	B.kind.resize(n); B.triBox.resize(n); B.centroid.resize(n); B.order.resize(n);
 	for (uint32_t i = 0; i < n; ++i) {
 		Box b; b.mn = prims[i].mn; b.mx = prims[i].mx;
@@ -154,12 +252,58 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		B.centroid[i] = F3(0.5f * (b.mn.x + b.mx.x), 0.5f * (b.mn.y + b.mx.y), 0.5f * (b.mn.z + b.mx.z));
 		B.order[i] = i;
 	}
-	B.tmp.reserve(2 * (size_t)n);
-	int32_t root = B.build(0, n, 0);
+	// threads: RAYLIB_BUILD_THREADS, else the host's (capped at 32); small scenes build on the calling thread
+	unsigned threads = std::thread::hardware_concurrency();
+	if (const char* e = getenv("RAYLIB_BUILD_THREADS")) { int v = atoi(e); if (v > 0) threads = (unsigned)v; }
+	threads = std::max(1u, std::min(32u, threads));
+	if (n < (1u << 16)) threads = 1;
+	B.threads = threads;
+	B.taskSize = threads > 1 ? std::max<uint32_t>(4096u, n / (threads * 16u)) : 0u;
+
+	const auto tb0 = std::chrono::steady_clock::now();
+	Ctx top;
+	std::vector<Task> tasks;
+	if (threads > 1) top.tasks = &tasks;
+	top.tmp.reserve(threads > 1 ? 4096 : 2 * (size_t)n);
+	const int32_t topRoot = build(B, top, 0, n, 0);
+	const auto tb1 = std::chrono::steady_clock::now();
+	// every worker appends the sub-trees of the tasks it takes to its own arena (one growing vector per thread: a
+	// vector per task meant one mmap/munmap pair per task, and the threads queued on the kernel's mm lock)
+	std::vector<Ctx> sub(threads);
+	std::vector<std::pair<uint32_t, int32_t>> where(tasks.size());   // task -> (arena, root index in it)
+	if (!tasks.empty()) {
+		std::atomic<size_t> nextTask{ 0 };
+		auto worker = [&](unsigned me) {
+			sub[me].tmp.reserve((size_t)n / threads);
+			for (;;) {
+				const size_t t = nextTask.fetch_add(1);
+				if (t >= tasks.size()) return;
+				const int32_t r = build(B, sub[me], tasks[t].b, tasks[t].e, tasks[t].depth);
+				where[t] = { me, r };
+			}
+		};
+		std::vector<std::thread> pool;
+		for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+		worker(0u);
+		for (std::thread& th : pool) th.join();
+	}
+	const auto tb2 = std::chrono::steady_clock::now();
+	uint32_t maxDepth = top.maxDepth;
+	for (const Ctx& c : sub) maxDepth = std::max(maxDepth, c.maxDepth);
+	std::vector<TmpNode> merged;
+	int32_t root = topRoot;
+	if (!tasks.empty()) {
+		merged.reserve(2 * (size_t)n);
+		root = Splice(sub, where, top, topRoot, merged);
+		top.tmp.clear(); top.tmp.shrink_to_fit();
+		for (Ctx& c : sub) { c.tmp.clear(); c.tmp.shrink_to_fit(); }
+	} else {
+		merged.swap(top.tmp);
+	}
 
 	// Leaf references.  Triangle leaves index the triangle arrays in leaf order (out.triOrder lists the
 	// original triangle index of every slot); an analytic primitive's leaf carries its index in its own array.
-	const std::vector<TmpNode>& T = B.tmp;
+	const std::vector<TmpNode>& T = merged;
 	std::vector<int32_t> leafCode(T.size(), 0);
 	for (size_t t = 0; t < T.size(); ++t) {
 		if (T[t].left >= 0) continue;
@@ -206,7 +350,9 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		nd.right = (R.left < 0) ? leafCode[T[t].right] : emitIndex[T[t].right];
 		out.nodes[emitIndex[t]] = nd;
 	}
-	out.depth = B.maxDepth;   // leaves at depth d => at most d inner nodes above them
+	if (getenv("RAYLIB_BUILD_TIMING")) Log("BVH build: %u threads, %zu tasks; top levels %.3f s, tasks %.3f s, merge + emit %.3f s", threads, tasks.size(),
+		std::chrono::duration<double>(tb1 - tb0).count(), std::chrono::duration<double>(tb2 - tb1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tb2).count());
+	out.depth = maxDepth;     // leaves at depth d => at most d inner nodes above them
 	out.sahCost = (float)sah;
 }
 

@@ -3,6 +3,7 @@
 // re-stated for a flat device scene.
 #include "rl_host.h"
 
+#include <chrono>
 #include <string.h>
 
 namespace rl {
@@ -125,7 +126,9 @@ void Scene::BuildAccel(float t0, float t1)
 		p.kind = PRIM_CUBE; p.index = (uint32_t)i;
 		prims.push_back(p);
 	}
+	const auto tBuild = std::chrono::steady_clock::now();
 	BuildBVH(prims, bvh);
+	const double buildSec = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
 	// leaves that contain a triangle whose material has an albedo texture run the
 	// cut-out test inside traversal (reference geom/triangle.cc:54, material.cc:397-404)
 	std::vector<uint8_t> alpha(triangles.size(), 0);
@@ -144,8 +147,8 @@ void Scene::BuildAccel(float t0, float t1)
 		};
 		for (DNode& n : bvh.nodes) { patch(n.left); patch(n.right); }
 	}
-	Log("Scene finalized: %u triangles, %u BVH nodes, depth %u, SAH cost %.2f",
-	    (unsigned)triangles.size(), (unsigned)bvh.nodes.size(), bvh.depth, bvh.sahCost);
+	Log("Scene finalized: %u triangles, %u BVH nodes, depth %u, SAH cost %.2f (BVH build %.2f s)",
+	    (unsigned)triangles.size(), (unsigned)bvh.nodes.size(), bvh.depth, bvh.sahCost, buildSec);
 }
 
 // Image2D::PostProcess on the host (reference render/image.cc:44-103): max-luminance

@@ -138,6 +138,23 @@ def test_bvh_builder(lib, workdir):
     lib.Raylib_DestroyScene(sc)
 
 
+def test_bvh_build_is_the_same_tree_for_any_thread_count(lib, workdir, monkeypatch):
+    """Above 65536 primitives the build uses every host thread (top levels: parallel binning; sub-trees: tasks);
+    the flat tree must be byte-identical to the single-threaded one (traversal order, hence tie behaviour, depends on it)."""
+    from raylib_amd import binding
+    obj, n = scenes.cornell(os.path.join(str(workdir), "bvh_mt.obj"), tess=64, displace_fraction=0.2)
+    assert n > 65536
+    seen = {}
+    for threads in ("1", "2", "5", "8"):
+        monkeypatch.setenv("RAYLIB_BUILD_THREADS", threads)
+        ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+        nodes, depth, sah = C.c_uint32(), C.c_uint32(), C.c_float()
+        assert lib.RaylibAMD_SceneBVHInfo(ses.scene, C.byref(nodes), C.byref(depth), C.byref(sah)) == 1
+        seen[threads] = (lib.RaylibAMD_SceneBVHHash(ses.scene), nodes.value, depth.value, sah.value)
+        ses.close()
+    assert len(set(seen.values())) == 1, seen
+
+
 def test_transform_rules(lib, workdir):
     """rotate -> scale -> translate on positions, rotation only on normals; ignored after finalize
     (reference raylib.cc:71-90, static_mesh.cc:54-78)."""
