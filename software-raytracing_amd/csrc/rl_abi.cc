@@ -82,7 +82,7 @@ extern "C" {
 // reference raylib.cc:25-51
 int32_t Raylib_Initialize(void)
 {
-	printf("Initialize raylib\n");
+	{ const char* q = getenv("RAYLIB_QUIET"); if (!(q && q[0] == '1')) printf("Initialize raylib\n"); }   // raylib.cc:27 prints this unconditionally
 	LogStart();
 	if (!DeviceAvailable()) {
 		fprintf(stderr, "Raylib_Initialize: no usable HIP device (gfx950) -- this library has no CPU render path\n");
