@@ -94,7 +94,7 @@ int32_t Raylib_Initialize(void)
 
 int32_t Raylib_Terminate(void)
 {
-	printf("Terminate raylib\n");
+	{ const char* q = getenv("RAYLIB_QUIET"); if (!(q && q[0] == '1')) printf("Terminate raylib\n"); }
 	Log("Destroy obj loader");
 	LogStop();
 	return 0;   // the reference returns 0 here despite its header comment (raylib.cc:50)
@@ -506,6 +506,14 @@ void RaylibAMD_DumpImageRGBA(ImageHandle h, float* out)
 	Image* img = (Image*)h;
 	if (!img || !out) return;
 	memcpy(out, img->rgba.data(), img->rgba.size() * sizeof(float));
+}
+int32_t RaylibAMD_ImageSize(ImageHandle h, uint32_t* w, uint32_t* ht)
+{
+	Image* img = (Image*)h;
+	if (!img) return 0;
+	if (w) *w = img->width;
+	if (ht) *ht = img->height;
+	return 1;
 }
 int32_t RaylibAMD_OBJModelSetTexture(OBJModelHandle oh, const char* materialName, int32_t slot, ImageHandle ih)
 {

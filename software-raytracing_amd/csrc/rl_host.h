@@ -180,6 +180,9 @@ struct RenderRequest {
 	float* outHostRGBA;     // may be null; receives what outDevice would (row-major image or the rank's cells)
 };
 bool DeviceAvailable();
+// csrc/rl_jpeg.cc: top-down RGBA8
+bool DecodeJPEG(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
+bool DecodeTGA(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 bool DeviceRender(Scene& scene, const RenderRequest& req, RaylibAMDStats& stats);
 bool DeviceClosestHit(Scene& scene, const float* rays, int32_t n, float tMin, void* outHits);
 bool DevicePostProcess(Image& img);          // Image2D::PostProcess on the device; false when no device

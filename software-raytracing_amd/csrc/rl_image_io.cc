@@ -260,7 +260,14 @@ Image* LoadImageFile(const char* path)
 	if (Image* i = LoadPNG(d)) return i;
 	if (Image* i = LoadBMP(d)) return i;
 	if (Image* i = LoadHDR(d)) return i;
-	Log("LoadImage: unsupported image format: %s (BMP, 8-bit PNG and Radiance HDR are decoded)", path);
+	{
+		uint32_t w = 0, h = 0; std::vector<uint8_t> px;
+		if (DecodeJPEG(d, w, h, px)) return FromBytesRGBA(w, h, px);
+		const size_t len = strlen(path);
+		if (len > 4 && (path[len - 3] == 't' || path[len - 3] == 'T') && (path[len - 2] == 'g' || path[len - 2] == 'G') && (path[len - 1] == 'a' || path[len - 1] == 'A') &&
+		    DecodeTGA(d, w, h, px)) return FromBytesRGBA(w, h, px);   // TGA has no signature: by extension, as FreeImage_GetFIFFromFilename does
+	}
+	Log("LoadImage: unsupported image format: %s (BMP, 8-bit PNG, JPEG (8-bit Huffman), TGA and Radiance HDR are decoded)", path);
 	return nullptr;
 }
 

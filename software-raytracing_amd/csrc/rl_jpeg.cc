@@ -1,0 +1,466 @@
+// JPEG (baseline + progressive Huffman, 8 bit) and TGA decoders for texture / sky ingestion.
+//
+// The reference reads images through FreeImage 3.18 with flags = 0 (reference render/image.cc:159-160).  For JPEG
+// that means FreeImage's "fast" settings: libjpeg's JDCT_IFAST inverse DCT and no fancy up-sampling
+// (PluginJPEG.cpp: without JPEG_ACCURATE, dct_method = JDCT_IFAST and do_fancy_upsampling = FALSE).  The decoder
+// below restates those published libjpeg algorithms -- jidctfst.c (AA&N, 8-bit constants, truncating shifts),
+// jddctmgr.c's IFAST multiplier table, jdsample.c's replication up-sampling, jdcolor.c's fixed-point YCbCr -> RGB --
+// so a texel gets the same 8-bit value.  FreeImage itself is absent here ("parity unpinned" for the codec); the tests
+// pin the decoder against libjpeg-turbo driven the same way (Pillow's draft mode: JDCT_FASTEST, no fancy up-sampling).
+#include "rl_host.h"
+
+#include <stdint.h>
+#include <string.h>
+
+namespace rl {
+namespace {
+
+const uint8_t kZigzag[64] = {
+	0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+	35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+
+// jddctmgr.c: AA&N scale factors, 14 fractional bits, natural order
+const int16_t kAanScales[64] = {
+	16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
+	21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906, 19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
+	16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 12873, 17855, 16819, 15137, 12873, 10114, 6967, 3552,
+	8867, 12299, 11585, 10426, 8867, 6967, 4799, 2446, 4520, 6270, 5906, 5315, 4520, 3552, 2446, 1247 };
+
+struct Huff {
+	bool present = false;
+	// canonical decoding tables (ITU T.81 F.2.2.3)
+	int32_t mincode[17], maxcode[18], valptr[17];
+	uint8_t vals[256];
+	void build(const uint8_t* counts, const uint8_t* symbols, int n)
+	{
+		present = true;
+		memset(vals, 0, sizeof(vals)); memcpy(vals, symbols, (size_t)n);
+		int code = 0, k = 0;
+		for (int l = 1; l <= 16; ++l) {
+			valptr[l] = k; mincode[l] = code;
+			code += counts[l - 1]; k += counts[l - 1];
+			maxcode[l] = counts[l - 1] ? code - 1 : -1;
+			code <<= 1;
+		}
+		maxcode[17] = 0x7fffffff;
+	}
+};
+
+struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int blocksW = 0, blocksH = 0; std::vector<int16_t> coef; int pred = 0; };
+
+struct BitReader {
+	const uint8_t* p; const uint8_t* end;
+	uint32_t acc = 0; int bits = 0;
+	bool hitMarker = false;
+	void reset() { acc = 0; bits = 0; hitMarker = false; }
+	void fill()
+	{
+		while (bits <= 24) {
+			uint32_t b = 0;
+			if (!hitMarker && p < end) {
+				b = *p;
+				if (b == 0xFF) {
+					if (p + 1 < end && p[1] == 0x00) { p += 2; }
+					else { hitMarker = true; b = 0; }          // a marker: feed zeros, leave p on it
+				} else ++p;
+			}
+			acc |= b << (24 - bits);
+			bits += 8;
+		}
+	}
+	int get(int n) { if (n == 0) return 0; fill(); int v = (int)(acc >> (32 - n)); acc <<= n; bits -= n; return v; }
+	int bit() { return get(1); }
+	int decode(const Huff& h)
+	{
+		fill();
+		int code = 0;
+		for (int l = 1; l <= 16; ++l) {
+			code = (code << 1) | (int)(acc >> 31); acc <<= 1; --bits;
+			if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+		}
+		return 0;   // corrupt stream
+	}
+};
+inline int Extend(int v, int s) { return (s && v < (1 << (s - 1))) ? v - (1 << s) + 1 : v; }
+
+// jidctfst.c with the IFAST multipliers of jddctmgr.c; out: 64 samples 0..255
+void IdctIfast(const int16_t* coef, const int32_t* mult, uint8_t* out)
+{
+	const int32_t F1_082 = 277, F1_414 = 362, F1_847 = 473, F2_613 = 669;
+	#define JMUL(v, c) (((v) * (c)) >> 8)
+	int32_t ws[64];
+	for (int c = 0; c < 8; ++c) {
+		const int16_t* in = coef + c; const int32_t* q = mult + c; int32_t* w = ws + c;
+		int32_t tmp0 = in[0] * q[0], tmp1 = in[16] * q[16], tmp2 = in[32] * q[32], tmp3 = in[48] * q[48];
+		int32_t tmp10 = tmp0 + tmp2, tmp11 = tmp0 - tmp2;
+		int32_t tmp13 = tmp1 + tmp3, tmp12 = JMUL(tmp1 - tmp3, F1_414) - tmp13;
+		tmp0 = tmp10 + tmp13; tmp3 = tmp10 - tmp13; tmp1 = tmp11 + tmp12; tmp2 = tmp11 - tmp12;
+		int32_t tmp4 = in[8] * q[8], tmp5 = in[24] * q[24], tmp6 = in[40] * q[40], tmp7 = in[56] * q[56];
+		int32_t z13 = tmp6 + tmp5, z10 = tmp6 - tmp5, z11 = tmp4 + tmp7, z12 = tmp4 - tmp7;
+		tmp7 = z11 + z13; tmp11 = JMUL(z11 - z13, F1_414);
+		int32_t z5 = JMUL(z10 + z12, F1_847);
+		tmp10 = JMUL(z12, F1_082) - z5;
+		tmp12 = JMUL(z10, -F2_613) + z5;
+		tmp6 = tmp12 - tmp7; tmp5 = tmp11 - tmp6; tmp4 = tmp10 + tmp5;
+		w[0] = tmp0 + tmp7; w[56] = tmp0 - tmp7; w[8] = tmp1 + tmp6; w[48] = tmp1 - tmp6;
+		w[16] = tmp2 + tmp5; w[40] = tmp2 - tmp5; w[32] = tmp3 + tmp4; w[24] = tmp3 - tmp4;
+	}
+	auto limit = [](int32_t x) -> uint8_t {
+		// range_limit[(x >> 5) & RANGE_MASK] of the IDCT table (jdmaster.c prepare_range_limit_table), CENTERJSAMPLE folded in
+		const int idx = (x >> 5) & 1023;
+		if (idx < 128) return (uint8_t)(128 + idx);
+		if (idx < 512) return 255;
+		if (idx < 896) return 0;
+		return (uint8_t)(idx - 896);
+	};
+	for (int r = 0; r < 8; ++r) {
+		const int32_t* w = ws + 8 * r; uint8_t* o = out + 8 * r;
+		int32_t tmp10 = w[0] + w[4], tmp11 = w[0] - w[4];
+		int32_t tmp13 = w[2] + w[6], tmp12 = JMUL(w[2] - w[6], F1_414) - tmp13;
+		int32_t tmp0 = tmp10 + tmp13, tmp3 = tmp10 - tmp13, tmp1 = tmp11 + tmp12, tmp2 = tmp11 - tmp12;
+		int32_t z13 = w[5] + w[3], z10 = w[5] - w[3], z11 = w[1] + w[7], z12 = w[1] - w[7];
+		int32_t tmp7 = z11 + z13; tmp11 = JMUL(z11 - z13, F1_414);
+		int32_t z5 = JMUL(z10 + z12, F1_847);
+		tmp10 = JMUL(z12, F1_082) - z5;
+		tmp12 = JMUL(z10, -F2_613) + z5;
+		int32_t tmp6 = tmp12 - tmp7, tmp5 = tmp11 - tmp6, tmp4 = tmp10 + tmp5;
+		o[0] = limit(tmp0 + tmp7); o[7] = limit(tmp0 - tmp7); o[1] = limit(tmp1 + tmp6); o[6] = limit(tmp1 - tmp6);
+		o[2] = limit(tmp2 + tmp5); o[5] = limit(tmp2 - tmp5); o[4] = limit(tmp3 + tmp4); o[3] = limit(tmp3 - tmp4);
+	}
+	#undef JMUL
+}
+
+inline uint8_t Clamp255(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+struct Decoder {
+	const uint8_t* d; size_t n;
+	int width = 0, height = 0, ncomp = 0; bool progressive = false;
+	uint16_t qt[4][64]; bool qtPresent[4] = { false, false, false, false };
+	Huff dc[4], ac[4];
+	Component comp[4];
+	int hmax = 1, vmax = 1, mcuW = 0, mcuH = 0, restart = 0;
+	int adobeTransform = -1;
+	int eobrun = 0;
+
+	bool parse(std::vector<uint8_t>& rgba)
+	{
+		if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return false;
+		size_t p = 2;
+		bool sawFrame = false;
+		while (p + 4 <= n) {
+			if (d[p] != 0xFF) { ++p; continue; }
+			const uint8_t m = d[p + 1];
+			if (m == 0xFF) { ++p; continue; }
+			if (m == 0xD9) break;
+			if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { p += 2; continue; }
+			const size_t len = ((size_t)d[p + 2] << 8) | d[p + 3];
+			if (len < 2 || p + 2 + len > n) return false;
+			const uint8_t* b = d + p + 4; const size_t bl = len - 2;
+			if (m == 0xDB) {                       // DQT
+				size_t k = 0;
+				while (k < bl) {
+					const int pq = b[k] >> 4, tq = b[k] & 15; ++k;
+					if (tq > 3 || k + (pq ? 128 : 64) > bl) return false;
+					for (int i = 0; i < 64; ++i) { qt[tq][kZigzag[i]] = pq ? (uint16_t)((b[k] << 8) | b[k + 1]) : b[k]; k += pq ? 2 : 1; }
+					qtPresent[tq] = true;
+				}
+			} else if (m == 0xC4) {                // DHT
+				size_t k = 0;
+				while (k + 17 <= bl) {
+					const int tc = b[k] >> 4, th = b[k] & 15;
+					int total = 0; for (int i = 0; i < 16; ++i) total += b[k + 1 + i];
+					if (th > 3 || tc > 1 || total > 256 || k + 17 + (size_t)total > bl) return false;
+					(tc ? ac[th] : dc[th]).build(b + k + 1, b + k + 17, total);
+					k += 17 + (size_t)total;
+				}
+			} else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {   // SOF0/1/2
+				if (sawFrame || bl < 6 || b[0] != 8) return false;
+				progressive = (m == 0xC2);
+				height = (b[1] << 8) | b[2]; width = (b[3] << 8) | b[4]; ncomp = b[5];
+				if (!width || !height || (ncomp != 1 && ncomp != 3) || bl < 6 + 3 * (size_t)ncomp) return false;
+				for (int c = 0; c < ncomp; ++c) {
+					comp[c].id = b[6 + 3 * c]; comp[c].h = b[7 + 3 * c] >> 4; comp[c].v = b[7 + 3 * c] & 15; comp[c].tq = b[8 + 3 * c] & 3;
+					if (comp[c].h < 1 || comp[c].h > 4 || comp[c].v < 1 || comp[c].v > 4) return false;
+					hmax = std::max(hmax, comp[c].h); vmax = std::max(vmax, comp[c].v);
+				}
+				if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }   // a single component is never interleaved
+				mcuW = (width + 8 * hmax - 1) / (8 * hmax); mcuH = (height + 8 * vmax - 1) / (8 * vmax);
+				for (int c = 0; c < ncomp; ++c) {
+					comp[c].blocksW = mcuW * comp[c].h; comp[c].blocksH = mcuH * comp[c].v;
+					comp[c].coef.assign((size_t)comp[c].blocksW * comp[c].blocksH * 64, 0);
+				}
+				sawFrame = true;
+			} else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+				return false;                      // lossless / arithmetic / hierarchical
+			} else if (m == 0xDD) {                // DRI
+				if (bl >= 2) restart = (b[0] << 8) | b[1];
+			} else if (m == 0xEE) {                // APP14 "Adobe"
+				if (bl >= 12 && !memcmp(b, "Adobe", 5)) adobeTransform = b[11];
+			} else if (m == 0xDA) {                // SOS
+				if (!sawFrame) return false;
+				size_t consumed = 0;
+				if (!scan(b, bl, d + p + 2 + len, d + n, consumed)) return false;
+				p += 2 + len + consumed;
+				continue;
+			}
+			p += 2 + len;
+		}
+		if (!sawFrame) return false;
+		return finish(rgba);
+	}
+
+	bool scan(const uint8_t* hdr, size_t hl, const uint8_t* data, const uint8_t* end, size_t& consumed)
+	{
+		if (hl < 1) return false;
+		const int ns = hdr[0];
+		if (ns < 1 || ns > ncomp || hl < 1 + 2 * (size_t)ns + 3) return false;
+		int idx[4];
+		for (int i = 0; i < ns; ++i) {
+			int c = -1;
+			for (int k = 0; k < ncomp; ++k) if (comp[k].id == hdr[1 + 2 * i]) c = k;
+			if (c < 0) return false;
+			idx[i] = c; comp[c].td = hdr[2 + 2 * i] >> 4; comp[c].ta = hdr[2 + 2 * i] & 15;
+			if (comp[c].td > 3 || comp[c].ta > 3) return false;
+		}
+		const int Ss = hdr[1 + 2 * ns], Se = hdr[2 + 2 * ns], Ah = hdr[3 + 2 * ns] >> 4, Al = hdr[3 + 2 * ns] & 15;
+		if (progressive) { if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1)) return false; }
+		else if (Ss != 0 || Se != 63) { /* tolerated: baseline ignores them */ }
+		BitReader br; br.p = data; br.end = end;
+		for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+		eobrun = 0;
+		int untilRestart = restart;
+		auto restartCheck = [&]() -> bool {
+			if (!restart) return true;
+			if (--untilRestart > 0) return true;
+			// byte-align, expect RSTn
+			br.reset();
+			while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) {
+				if (br.p[0] == 0xFF && br.p[1] != 0x00 && br.p[1] != 0xFF) return true;   // another marker: the scan is over
+				++br.p;
+			}
+			if (br.p + 1 < br.end) br.p += 2;
+			for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+			eobrun = 0;
+			untilRestart = restart;
+			return true;
+		};
+		if (ns > 1) {
+			// interleaved: one MCU = h x v blocks of every scan component
+			const int total = mcuW * mcuH;
+			for (int m = 0; m < total; ++m) {
+				const int mx = m % mcuW, my = m / mcuW;
+				for (int i = 0; i < ns; ++i) {
+					Component& C = comp[idx[i]];
+					for (int by = 0; by < C.v; ++by) for (int bx = 0; bx < C.h; ++bx) {
+						int16_t* blk = &C.coef[((size_t)(my * C.v + by) * C.blocksW + (mx * C.h + bx)) * 64];
+						if (!block(br, C, blk, Ss, Se, Ah, Al)) return false;
+					}
+				}
+				if (m + 1 < total) restartCheck();
+			}
+		} else {
+			// non-interleaved: the component's own block raster, clipped to the image (T.81 A.2.2)
+			Component& C = comp[idx[0]];
+			const int bw = (int)(((size_t)width * C.h + hmax * 8 - 1) / ((size_t)hmax * 8));
+			const int bh = (int)(((size_t)height * C.v + vmax * 8 - 1) / ((size_t)vmax * 8));
+			const int total = bw * bh;
+			for (int m = 0; m < total; ++m) {
+				int16_t* blk = &C.coef[((size_t)(m / bw) * C.blocksW + (m % bw)) * 64];
+				if (!block(br, C, blk, Ss, Se, Ah, Al)) return false;
+				if (m + 1 < total) restartCheck();
+			}
+		}
+		// leave the parser at the next marker (the bit reader never steps over one)
+		const uint8_t* q = br.p;
+		while (q + 1 < end && !(q[0] == 0xFF && q[1] != 0x00 && !(q[1] >= 0xD0 && q[1] <= 0xD7) && q[1] != 0xFF)) ++q;
+		consumed = (size_t)(q - data);
+		return true;
+	}
+
+	bool block(BitReader& br, Component& C, int16_t* blk, int Ss, int Se, int Ah, int Al)
+	{
+		if (!progressive) {
+			const Huff& hd = dc[C.td]; const Huff& ha = ac[C.ta];
+			if (!hd.present || !ha.present) return false;
+			int s = br.decode(hd);
+			int diff = s ? Extend(br.get(s), s) : 0;
+			C.pred += diff; blk[0] = (int16_t)C.pred;
+			for (int k = 1; k < 64;) {
+				const int rs = br.decode(ha); const int r = rs >> 4; s = rs & 15;
+				if (s == 0) { if (r == 15) { k += 16; continue; } break; }
+				k += r; if (k > 63) break;
+				blk[kZigzag[k]] = (int16_t)Extend(br.get(s), s); ++k;
+			}
+			return true;
+		}
+		if (Ss == 0) {
+			if (Ah == 0) {
+				const Huff& hd = dc[C.td]; if (!hd.present) return false;
+				const int s = br.decode(hd);
+				const int diff = s ? Extend(br.get(s), s) : 0;
+				C.pred += diff; blk[0] = (int16_t)(C.pred * (1 << Al));
+			} else if (br.bit()) blk[0] = (int16_t)(blk[0] | (1 << Al));
+			return true;
+		}
+		const Huff& ha = ac[C.ta]; if (!ha.present) return false;
+		if (Ah == 0) {
+			if (eobrun > 0) { --eobrun; return true; }
+			for (int k = Ss; k <= Se;) {
+				const int rs = br.decode(ha); const int r = rs >> 4, s = rs & 15;
+				if (s == 0) {
+					if (r == 15) { k += 16; continue; }
+					eobrun = (1 << r) - 1; if (r) eobrun += br.get(r);
+					break;
+				}
+				k += r; if (k > 63) break;
+				blk[kZigzag[k]] = (int16_t)(Extend(br.get(s), s) * (1 << Al)); ++k;
+			}
+			return true;
+		}
+		// AC refinement (T.81 G.1.2.3; control flow of libjpeg's decode_mcu_AC_refine)
+		const int p1 = 1 << Al, m1 = -(1 << Al);
+		auto correct = [&](int16_t& cf) { if (br.bit() && (cf & p1) == 0) cf = (int16_t)(cf >= 0 ? cf + p1 : cf + m1); };
+		int k = Ss;
+		if (eobrun == 0) {
+			for (; k <= Se; ++k) {
+				const int rs = br.decode(ha); int r = rs >> 4; const int s = rs & 15;
+				int val = 0;
+				if (s) val = br.bit() ? p1 : m1;
+				else if (r != 15) { eobrun = 1 << r; if (r) eobrun += br.get(r); break; }
+				do {
+					int16_t& cf = blk[kZigzag[k]];
+					if (cf != 0) correct(cf);
+					else if (--r < 0) break;
+					++k;
+				} while (k <= Se);
+				if (val && k <= 63) blk[kZigzag[k]] = (int16_t)val;
+			}
+		}
+		if (eobrun > 0) {
+			for (; k <= Se; ++k) { int16_t& cf = blk[kZigzag[k]]; if (cf != 0) correct(cf); }
+			--eobrun;
+		}
+		return true;
+	}
+
+	bool finish(std::vector<uint8_t>& rgba)
+	{
+		// planes at component resolution
+		std::vector<uint8_t> plane[4];
+		for (int c = 0; c < ncomp; ++c) {
+			Component& C = comp[c];
+			if (!qtPresent[C.tq]) return false;
+			int32_t mult[64];
+			for (int i = 0; i < 64; ++i) mult[i] = (int32_t)(((int32_t)qt[C.tq][i] * (int32_t)kAanScales[i] + (1 << 11)) >> 12);   // DESCALE(q * aan, 14 - 2)
+			const int pw = C.blocksW * 8;
+			plane[c].assign((size_t)pw * C.blocksH * 8, 0);
+			uint8_t px[64];
+			for (int by = 0; by < C.blocksH; ++by) for (int bx = 0; bx < C.blocksW; ++bx) {
+				IdctIfast(&C.coef[((size_t)by * C.blocksW + bx) * 64], mult, px);
+				for (int y = 0; y < 8; ++y) memcpy(&plane[c][(size_t)(by * 8 + y) * pw + bx * 8], px + 8 * y, 8);
+			}
+		}
+		// replication up-sampling (jdsample.c int_upsample / h2v1 / h2v2 without fancy) + jdcolor.c
+		// jdapimin.c default_decompress_parms: Adobe transform 0 or component ids 'R','G','B' mean RGB, else YCbCr
+		const bool rgbIds = ncomp == 3 && comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B';
+		const bool ycc = ncomp == 3 && (adobeTransform >= 0 ? adobeTransform != 0 : !rgbIds);
+		int crR[256], cbB[256], crG[256], cbG[256];
+		for (int i = 0; i < 256; ++i) {
+			const int x = i - 128;
+			crR[i] = (int)((91881 * x + 32768) >> 16);      // FIX(1.40200)
+			cbB[i] = (int)((116130 * x + 32768) >> 16);     // FIX(1.77200)
+			crG[i] = -46802 * x;                             // FIX(0.71414)
+			cbG[i] = -22554 * x + 32768;                     // FIX(0.34414) + ONE_HALF
+		}
+		rgba.resize((size_t)width * height * 4);
+		for (int y = 0; y < height; ++y) for (int x = 0; x < width; ++x) {
+			int v[3] = { 0, 0, 0 };
+			for (int c = 0; c < ncomp; ++c) {
+				const Component& C = comp[c];
+				const int sx = x * C.h / hmax, sy = y * C.v / vmax;
+				v[c] = plane[c][(size_t)sy * (C.blocksW * 8) + sx];
+			}
+			uint8_t* o = &rgba[((size_t)y * width + x) * 4];
+			if (ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)v[0]; }
+			else if (ycc) {
+				o[0] = Clamp255(v[0] + crR[v[2]]);
+				o[1] = Clamp255(v[0] + ((cbG[v[1]] + crG[v[2]]) >> 16));
+				o[2] = Clamp255(v[0] + cbB[v[1]]);
+			} else { o[0] = (uint8_t)v[0]; o[1] = (uint8_t)v[1]; o[2] = (uint8_t)v[2]; }
+			o[3] = 255;
+		}
+		return true;
+	}
+};
+
+} // namespace
+
+bool DecodeJPEG(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba)
+{
+	Decoder D; D.d = d.data(); D.n = d.size();
+	memset(D.qt, 0, sizeof(D.qt));
+	if (!D.parse(rgba)) return false;
+	w = (uint32_t)D.width; h = (uint32_t)D.height;
+	return true;
+}
+
+// Truevision TGA: types 2 / 10 (true colour, raw / RLE) with 24 or 32 bits, 3 / 11 (grey), 1 / 9 (colour-mapped, 24/32-bit
+// palette); origin bit honoured.  FreeImage's ConvertTo32Bits keeps a 32-bit file's alpha and sets 255 otherwise.
+bool DecodeTGA(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba)
+{
+	if (d.size() < 18) return false;
+	const int idLen = d[0], cmapType = d[1], type = d[2];
+	const int cmFirst = d[3] | (d[4] << 8), cmLen = d[5] | (d[6] << 8), cmBits = d[7];
+	w = (uint32_t)(d[12] | (d[13] << 8)); h = (uint32_t)(d[14] | (d[15] << 8));
+	const int bpp = d[16], desc = d[17];
+	if (!w || !h || cmapType > 1) return false;
+	const bool rle = type >= 9;
+	const int base = rle ? type - 8 : type;
+	if (base < 1 || base > 3) return false;
+	if (base == 2 && bpp != 24 && bpp != 32) return false;
+	if (base == 3 && bpp != 8) return false;
+	if (base == 1 && (bpp != 8 || !cmapType || (cmBits != 24 && cmBits != 32))) return false;
+	size_t p = 18 + (size_t)idLen;
+	const size_t cmBytes = cmapType ? (size_t)cmLen * (cmBits / 8) : 0;
+	if (p + cmBytes > d.size()) return false;
+	const uint8_t* cmap = d.data() + p; p += cmBytes;
+	const int bytes = bpp / 8;
+	std::vector<uint8_t> raw((size_t)w * h * bytes);
+	if (!rle) {
+		if (p + raw.size() > d.size()) return false;
+		memcpy(raw.data(), d.data() + p, raw.size());
+	} else {
+		size_t o = 0;
+		while (o < raw.size()) {
+			if (p >= d.size()) return false;
+			const int hdr = d[p++]; const size_t cnt = (size_t)(hdr & 127) + 1;
+			if (hdr & 128) {
+				if (p + bytes > d.size()) return false;
+				for (size_t i = 0; i < cnt && o < raw.size(); ++i) { memcpy(&raw[o], &d[p], (size_t)bytes); o += bytes; }
+				p += bytes;
+			} else {
+				const size_t nb = cnt * bytes;
+				if (p + nb > d.size()) return false;
+				const size_t take = std::min(nb, raw.size() - o);
+				memcpy(&raw[o], &d[p], take); o += take; p += nb;
+			}
+		}
+	}
+	rgba.resize((size_t)w * h * 4);
+	const bool topDown = (desc & 0x20) != 0, rightLeft = (desc & 0x10) != 0;
+	for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) {
+		const uint32_t sy = topDown ? y : h - 1 - y, sx = rightLeft ? w - 1 - x : x;
+		const uint8_t* s = &raw[((size_t)sy * w + sx) * bytes];
+		uint8_t* o = &rgba[((size_t)y * w + x) * 4];
+		if (base == 2) { o[0] = s[2]; o[1] = s[1]; o[2] = s[0]; o[3] = bytes == 4 ? s[3] : 255; }
+		else if (base == 3) { o[0] = o[1] = o[2] = s[0]; o[3] = 255; }
+		else {
+			const int k = (int)s[0] - cmFirst;
+			if (k < 0 || k >= cmLen) { o[0] = o[1] = o[2] = 0; o[3] = 255; }
+			else { const uint8_t* e = cmap + (size_t)k * (cmBits / 8); o[0] = e[2]; o[1] = e[1]; o[2] = e[0]; o[3] = cmBits == 32 ? e[3] : 255; }
+		}
+	}
+	return true;
+}
+
+} // namespace rl

@@ -1029,6 +1029,9 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #define Q_MISS     (-7)   /* result of a closest-hit query that hit nothing (distinct from Q_CLOSEST: a straggler may deliver it while the next phase is handing out slots) */
 #define Q_CLEAR    (-8)   /* result of a sun query: nothing in the way */
 #define RL_POOL_WIDEN 1.0000007f   /* slab test with v_rcp_f32 reciprocals: 6 ulp instead of Slab()'s 3 */
+#ifndef RL_POOL_MAXBLOCKS
+#define RL_POOL_MAXBLOCKS 4   /* workgroups per CU the pool kernel is compiled for (register budget 512 / (4 * blocks) per lane) */
+#endif
 #ifndef RL_POOL_CUT
 #define RL_POOL_CUT 40    /* with the pool handed out: shade once no more than this many lanes still traverse */
 #endif
@@ -1248,7 +1251,7 @@ template <int STACK, bool PRIMS, int K> struct PoolOcc {
 	static constexpr int kFields = PRIMS ? F_COUNT : F_COUNT - 1;
 	static constexpr int kLdsPerBlock = STACK * RL_BLOCK * 4 + (RL_BLOCK / 64) * (kFields * 64 * K * 4 + 64 * K);
 	static constexpr int kFit = (160 * 1024) / kLdsPerBlock;
-	static constexpr int kBlocks = kFit < 1 ? 1 : (kFit > 4 ? 4 : kFit);
+	static constexpr int kBlocks = kFit < 1 ? 1 : (kFit > RL_POOL_MAXBLOCKS ? RL_POOL_MAXBLOCKS : kFit);
 };
 
 template <int STACK, bool PRIMS, int K>
