@@ -507,6 +507,7 @@ void RaylibAMD_DumpImageRGBA(ImageHandle h, float* out)
 	if (!img || !out) return;
 	memcpy(out, img->rgba.data(), img->rgba.size() * sizeof(float));
 }
+float RaylibAMD_ParseFloat(const char* token) { return token ? ParseDecimalFloat(token) : 0.0f; }
 int32_t RaylibAMD_ImageSize(ImageHandle h, uint32_t* w, uint32_t* ht)
 {
 	Image* img = (Image*)h;

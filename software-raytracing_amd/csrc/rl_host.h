@@ -180,6 +180,7 @@ struct RenderRequest {
 	float* outHostRGBA;     // may be null; receives what outDevice would (row-major image or the rank's cells)
 };
 bool DeviceAvailable();
+float ParseDecimalFloat(const char* token);   // csrc/rl_obj_loader.cc: the OBJ parser's number reader (= strtof, with exact fast paths)
 // csrc/rl_jpeg.cc: top-down RGBA8
 bool DecodeJPEG(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 bool DecodeTGA(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);

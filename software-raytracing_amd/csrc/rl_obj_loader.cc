@@ -17,6 +17,8 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <chrono>
+#include <stdint.h>
 #include <string.h>
 #include <map>
 
@@ -140,12 +142,41 @@ HostMaterial MaterialFromMTL(const MtlRecord& r)
 	return m;
 }
 
+// strtof's value for the token [b, e).  Fast paths (Clinger) for plain decimals "digits[.digits]": (1) the digits form an
+// integer m < 2^24 and the scale is 10^k, k <= 10 -- both exact floats, one IEEE division gives the correctly rounded result;
+// (2) m < 2^53, k <= 22 -- the same in double, then a rounding to float that is provably single unless the double lies within
+// an ulp of a float midpoint.  Everything else (exponents, hex, inf/nan, 17+ digits, midpoints) goes to strtof itself.
+float ParseFloat(const char* b, const char* e)
+{
+	static const float kPow10f[11] = { 1e0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f };
+	static const double kPow10d[23] = { 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22 };
+	const char* p = b;
+	bool neg = false;
+	if (p < e && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
+	uint64_t m = 0; int digits = 0, frac = 0; bool ok = p < e;
+	for (; p < e && *p >= '0' && *p <= '9'; ++p) { if (m > 900719925474098ull) { ok = false; break; } m = m * 10u + (uint64_t)(*p - '0'); ++digits; }
+	if (ok && p < e && *p == '.') {
+		++p;
+		for (; p < e && *p >= '0' && *p <= '9'; ++p) { if (m > 900719925474098ull) { ok = false; break; } m = m * 10u + (uint64_t)(*p - '0'); ++digits; ++frac; }
+	}
+	if (!ok || p != e || digits == 0 || frac > 22) return strtof(b, nullptr);
+	if (m < (1ull << 24) && frac <= 10) { const float v = (float)(uint32_t)m / kPow10f[frac]; return neg ? -v : v; }
+	// m < 2^53 and 10^frac are exact doubles: d is the correctly rounded double of the decimal.  Rounding d to float gives the
+	// correctly rounded float unless d sits within one double-ulp of the midpoint of two floats; those go to strtof.
+	const double d = (double)m / kPow10d[frac];
+	if (!(d > 1e-30 && d < 1e30)) return strtof(b, nullptr);
+	uint64_t bits; memcpy(&bits, &d, 8);
+	const uint64_t low = bits & ((1ull << 29) - 1);
+	if (low >= (1ull << 28) - 1 && low <= (1ull << 28) + 1) return strtof(b, nullptr);
+	const float v = (float)d;
+	return neg ? -v : v;
+}
+
 struct Corner { int v, vt, vn; };
 
-bool ParseCorner(const std::string& s, int nV, int nVT, int nVN, Corner& c)
+bool ParseCorner(const char* p, int nV, int nVT, int nVN, Corner& c)
 {
 	c.v = c.vt = c.vn = -1;
-	const char* p = s.c_str();
 	char* end;
 	long a = strtol(p, &end, 10);
 	if (end == p) return false;
@@ -165,11 +196,27 @@ bool ParseCorner(const std::string& s, int nV, int nVT, int nVN, Corner& c)
 
 } // namespace
 
+float ParseDecimalFloat(const char* token) { return ParseFloat(token, token + strlen(token)); }
+
 bool LoadOBJ(const char* path, OBJModel& out)
 {
 	if (path == nullptr) { Log("LoadOBJ: filepath was null"); return false; }
-	std::vector<std::string> lines;
-	if (!ReadLines(path, lines)) { Log("LoadOBJ: cannot open %s", path); return false; }
+	// The whole file in one NUL-terminated buffer, parsed in place: no per-line / per-token allocations (a 10 M-triangle
+	// OBJ is 2.7 GB of text; the string-per-token parser spent 3x the BVH build's time here).  Token rules as before:
+	// whitespace separated, a token starting with '#' ends the line, numbers by strtof / strtol at the token start.
+	const auto tl0 = std::chrono::steady_clock::now();
+	std::vector<char> text;
+	{
+		FILE* fp = fopen(path, "rb");
+		if (!fp) { Log("LoadOBJ: cannot open %s", path); return false; }
+		fseek(fp, 0, SEEK_END); const long sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+		if (sz < 0) { fclose(fp); Log("LoadOBJ: cannot open %s", path); return false; }
+		text.resize((size_t)sz + 1);
+		const size_t got = sz ? fread(text.data(), 1, (size_t)sz, fp) : 0;
+		fclose(fp);
+		text[got] = 0;
+		for (size_t i = 0; i < got; ++i) if (text[i] == 0) text[i] = ' ';   // stray NULs would end the C-string parsing early
+	}
 	const std::string dir = DirOf(path);
 
 	std::vector<float> V, VT, VN;
@@ -180,47 +227,75 @@ bool LoadOBJ(const char* path, OBJModel& out)
 	int curMaterial = -1;
 	int curShape = -1, numShapes = 0;
 	bool shapeHasFaces = false;
+	std::vector<Corner> cs;
 
-	for (const std::string& line : lines) {
-		Tokens tk(line.c_str());
-		if (tk.size() == 0) continue;
-		const std::string& k = tk[0];
-		if (k == "v") { V.push_back(tk.f(1)); V.push_back(tk.f(2)); V.push_back(tk.f(3)); }
-		else if (k == "vt") { VT.push_back(tk.f(1)); VT.push_back(tk.f(2)); }
-		else if (k == "vn") { VN.push_back(tk.f(1)); VN.push_back(tk.f(2)); VN.push_back(tk.f(3)); }
-		else if (k == "o" || k == "g") {
-			// a new shape starts; shapes that end up without faces are dropped
-			if (shapeHasFaces || curShape < 0) { curShape = numShapes++; }
-			shapeHasFaces = false;
-		}
-		else if (k == "usemtl") {
-			auto it = tk.size() > 1 ? mtlIndex.find(tk[1]) : mtlIndex.end();
-			curMaterial = it == mtlIndex.end() ? -1 : it->second;
-		}
-		else if (k == "mtllib") {
-			for (size_t i = 1; i < tk.size(); ++i) {
-				size_t before = mtl.size();
-				ParseMTL(dir + tk[i], mtl);
-				for (size_t j = before; j < mtl.size(); ++j) mtlIndex[mtl[j].name] = (int)j;
+	auto isSpace = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r'; };
+	// next token of the current line: [b, e); false at end of line / comment
+	auto nextToken = [&](const char*& p, const char*& b, const char*& e) -> bool {
+		while (isSpace(*p)) ++p;
+		if (*p == 0 || *p == '\n' || *p == '#') return false;
+		b = p;
+		while (*p && *p != '\n' && !isSpace(*p)) ++p;
+		e = p;
+		return true;
+	};
+	auto number = [&](const char*& p, float dflt) -> float {
+		const char* b; const char* e;
+		if (!nextToken(p, b, e)) return dflt;
+		return ParseFloat(b, e);
+	};
+	auto is = [](const char* b, const char* e, const char* word) { const size_t n = strlen(word); return (size_t)(e - b) == n && memcmp(b, word, n) == 0; };
+
+	const auto tl1 = std::chrono::steady_clock::now();
+	const char* p = text.data();
+	while (*p) {
+		const char* b; const char* e;
+		if (nextToken(p, b, e)) {
+			if (is(b, e, "v")) { const float x = number(p, 0.0f), y = number(p, 0.0f), z = number(p, 0.0f); V.push_back(x); V.push_back(y); V.push_back(z); }
+			else if (is(b, e, "vt")) { const float u = number(p, 0.0f), v = number(p, 0.0f); VT.push_back(u); VT.push_back(v); }
+			else if (is(b, e, "vn")) { const float x = number(p, 0.0f), y = number(p, 0.0f), z = number(p, 0.0f); VN.push_back(x); VN.push_back(y); VN.push_back(z); }
+			else if (is(b, e, "o") || is(b, e, "g")) {
+				// a new shape starts; shapes that end up without faces are dropped
+				if (shapeHasFaces || curShape < 0) { curShape = numShapes++; }
+				shapeHasFaces = false;
+			}
+			else if (is(b, e, "usemtl")) {
+				const char* nb; const char* ne;
+				auto it = nextToken(p, nb, ne) ? mtlIndex.find(std::string(nb, ne)) : mtlIndex.end();
+				curMaterial = it == mtlIndex.end() ? -1 : it->second;
+			}
+			else if (is(b, e, "mtllib")) {
+				const char* nb; const char* ne;
+				while (nextToken(p, nb, ne)) {
+					size_t before = mtl.size();
+					ParseMTL(dir + std::string(nb, ne), mtl);
+					for (size_t j = before; j < mtl.size(); ++j) mtlIndex[mtl[j].name] = (int)j;
+				}
+			}
+			else if (is(b, e, "f")) {
+				if (curShape < 0) { curShape = numShapes++; }
+				cs.clear();
+				bool ok = true;
+				const char* cb; const char* ce;
+				while (nextToken(p, cb, ce)) {
+					Corner c;
+					if (!ParseCorner(cb, (int)V.size() / 3, (int)VT.size() / 2, (int)VN.size() / 3, c)) { ok = false; break; }
+					cs.push_back(c);
+				}
+				if (ok && cs.size() >= 3) {
+					for (size_t j = 1; j + 1 < cs.size(); ++j) {   // triangle fan
+						Face f; f.c[0] = cs[0]; f.c[1] = cs[j]; f.c[2] = cs[j + 1]; f.material = curMaterial; f.shape = curShape;
+						faces.push_back(f);
+					}
+					shapeHasFaces = true;
+				}
 			}
 		}
-		else if (k == "f") {
-			if (curShape < 0) { curShape = numShapes++; }
-			std::vector<Corner> cs;
-			bool ok = true;
-			for (size_t i = 1; i < tk.size(); ++i) {
-				Corner c;
-				if (!ParseCorner(tk[i], (int)V.size() / 3, (int)VT.size() / 2, (int)VN.size() / 3, c)) { ok = false; break; }
-				cs.push_back(c);
-			}
-			if (!ok || cs.size() < 3) continue;
-			for (size_t j = 1; j + 1 < cs.size(); ++j) {   // triangle fan
-				Face f; f.c[0] = cs[0]; f.c[1] = cs[j]; f.c[2] = cs[j + 1]; f.material = curMaterial; f.shape = curShape;
-				faces.push_back(f);
-			}
-			shapeHasFaces = true;
-		}
+		while (*p && *p != '\n') ++p;   // rest of the line
+		if (*p == '\n') ++p;
 	}
+	text.clear(); text.shrink_to_fit();
+	const auto tl2 = std::chrono::steady_clock::now();
 	if (faces.empty()) { Log("LoadOBJ: No shapes found in: %s", path); return false; }
 
 	// compact shape ids (drop empty shapes)
@@ -291,6 +366,8 @@ bool LoadOBJ(const char* path, OBJModel& out)
 	}
 	out.numShapes = nShapes;
 	out.finalized = false;
+	if (getenv("RAYLIB_BUILD_TIMING")) Log("LoadOBJ: read %.2f s, parse %.2f s, materials + triangle assembly %.2f s", std::chrono::duration<double>(tl1 - tl0).count(),
+		std::chrono::duration<double>(tl2 - tl1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tl2).count());
 	Log("LoadOBJ: Load %s", path);
 	Log("\tTotal shapes: %d", nShapes);
 	Log("\tTotal vertices: %d", (int)(V.size() / 3));

@@ -303,3 +303,45 @@ def test_render_without_device_fails_loudly(lib, workdir, capfd):
     assert "FAILED" in capfd.readouterr().err
     assert lib.Raylib_Initialize() == 0
     ses.close()
+
+
+def test_obj_number_reader_is_correctly_rounded(lib):
+    """The OBJ parser reads numbers with exact fast paths in front of strtof (csrc/rl_obj_loader.cc ParseFloat); every value
+    must be the float32 nearest to the decimal (ties to even) -- checked with rational arithmetic, not with another parser."""
+    import random, struct
+    from fractions import Fraction
+
+    def nearest_f32(txt):
+        x = Fraction(txt)
+        if x == 0:
+            return 0.0
+        approx = np.float32(float(x))                       # within one ulp; pick the true nearest among its neighbours
+        cands = {float(approx), float(np.nextafter(approx, np.float32(np.inf))), float(np.nextafter(approx, np.float32(-np.inf)))}
+        best = min(cands, key=lambda c: (abs(Fraction(c) - x), struct.unpack("<I", struct.pack("<f", c))[0] & 1))
+        return best
+
+    rnd = random.Random(11)
+    texts = ["0", "-0", "1", "0.1", "16777216", "16777217", "16777217.000000001", "0.333333343267440796", "1.00000005960464477539",
+             "8388608.5", "8388609.5", "0.000000000116415321826934814453125", "123456789012345.6789", "-2.5", "+7.25", "00012.5000"]
+    for _ in range(20000):
+        digits = rnd.randint(1, 16)
+        m = rnd.randrange(10 ** digits)
+        frac = rnd.randint(0, min(22, digits + 6))
+        t = str(m).rjust(frac + 1, "0")
+        t = (t[:-frac] + "." + t[-frac:]) if frac else t
+        texts.append(("-" if rnd.random() < 0.3 else "") + t)
+    # decimal midpoints of adjacent floats (the double-rounding trap): exact halfway strings
+    for _ in range(300):
+        f = np.float32(rnd.uniform(0.001, 1000.0))
+        g = np.nextafter(f, np.float32(np.inf))
+        mid = (Fraction(float(f)) + Fraction(float(g))) / 2
+        num, den = mid.numerator, mid.denominator            # den is a power of two: finite decimal expansion
+        k = den.bit_length() - 1
+        texts.append(str(Fraction(num * 5 ** k, 10 ** k).numerator).rjust(k + 1, "0")[:-k] + "." + str(num * 5 ** k).rjust(k + 1, "0")[-k:] if k else str(num))
+    bad = []
+    for t in texts:
+        got = lib.RaylibAMD_ParseFloat(t.encode())
+        want = nearest_f32(t.lstrip("+"))
+        if struct.pack("<f", got) != struct.pack("<f", want) and not (got == 0.0 and want == 0.0):
+            bad.append((t, got, want))
+    assert not bad, bad[:5]
