@@ -258,7 +258,9 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 	threads = std::max(1u, std::min(32u, threads));
 	if (n < (1u << 16)) threads = 1;
 	B.threads = threads;
-	B.taskSize = threads > 1 ? std::max<uint32_t>(4096u, n / (threads * 16u)) : 0u;
+	// sub-trees of at most this many primitives are tasks.  Not far below kParallelRange: between the two sizes a range is
+	// binned by ONE thread while the others wait (10 M triangles, 32 threads: 1.3 s of a 2.3 s build went there with n / 16T)
+	B.taskSize = threads > 1 ? std::max<uint32_t>(4096u, std::min<uint32_t>(kParallelRange - 1u, n / (threads * 4u))) : 0u;
 
 	const auto tb0 = std::chrono::steady_clock::now();
 	Ctx top;
