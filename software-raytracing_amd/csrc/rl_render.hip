@@ -1029,14 +1029,13 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #define Q_MISS     (-7)   /* result of a closest-hit query that hit nothing (distinct from Q_CLOSEST: a straggler may deliver it while the next phase is handing out slots) */
 #define Q_CLEAR    (-8)   /* result of a sun query: nothing in the way */
 #define RL_POOL_WIDEN 1.0000007f   /* slab test with v_rcp_f32 reciprocals: 6 ulp instead of Slab()'s 3 */
+#define RL_POOL_SHORT_LSTACK 19   /* LDS entries of the "short" 32-deep stack: 19 KiB + 20.5 KiB pool = 4 workgroups per CU */
+#define RL_POOL_SHORT_MAXDEPTH 24 /* BVH depth up to which the short variant is used (deeper trees overflow too often: measured) */
 #ifndef RL_POOL_MAXBLOCKS
 #define RL_POOL_MAXBLOCKS 4   /* workgroups per CU the pool kernel is compiled for (register budget 512 / (4 * blocks) per lane) */
 #endif
 #ifndef RL_POOL_CUT
 #define RL_POOL_CUT 40    /* with the pool handed out: shade once no more than this many lanes still traverse */
-#endif
-#ifndef RL_POOL_VOTE
-#define RL_POOL_VOTE 1    /* traversal steps by majority vote (node step | primitive step) instead of while-while rounds */
 #endif
 #ifndef RL_POOL_WNODE
 #define RL_POOL_WNODE 4   /* relative cost of a node step and a primitive step in the vote */
@@ -1056,93 +1055,27 @@ __device__ __forceinline__ void WaveLdsSync()
 
 struct Trav { V3 o, d, inv; float rayTime; bool nx, ny, nz, anyhit; HitRec best; int cur, sp, leafI; };
 
-// One while-while round of Traverse() on a resumable state: descend to the next leaf, intersect it, pop.
-// Returns true when the ray is finished (result in T.best).
-template <int STACK, bool PRIMS>
-__device__ __forceinline__ bool TraverseRound(const DSceneView& S, Trav& T, float tMin, int* stk, Counters& c)
-{
-	const int DONE = 0x7fffffff;
-	int cur = T.cur, sp = T.sp;
-	while (cur >= 0 && cur != DONE) {
-		RL_WSTEP(4);
-		const float4* np = (const float4*)(S.nodes + cur);
-		const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-		const int4 k = ((const int4*)np)[3];
-		c.nodes++;
-		float tl, tr;
-		const float tmx = fminf(T.best.t, FLT_MAX);
-		bool hl = Slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tl);
-		bool hr = Slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tr);
-		hl = hl && (k.x != DNODE_EMPTY);
-		hr = hr && (k.y != DNODE_EMPTY);
-		if (hl && hr) {
-			const bool leftFirst = tl <= tr;
-			const int nearC = leftFirst ? k.x : k.y, farC = leftFirst ? k.y : k.x;
-			if (sp < STACK) { stk[sp * RL_BLOCK] = farC; ++sp; }
-			cur = nearC;
-		} else if (hl) cur = k.x;
-		else if (hr) cur = k.y;
-		else if (sp == 0) cur = DONE;
-		else { --sp; cur = stk[sp * RL_BLOCK]; }
-	}
-	if (cur == DONE) { T.cur = cur; T.sp = sp; return true; }
-	{
-		RL_WSTEP(6);
-		const uint32_t code = (uint32_t)~cur;
-		const int first = (int)(code >> 6);
-		const int count = (int)(code & 7u) + 1;
-		const bool alpha = (code & 8u) != 0;
-		const uint32_t kind = (code >> 4) & 3u;
-		const V3 o = T.o, d = T.d;
-		if (!PRIMS || kind == 0u) {
-			for (int i = 0; i < count; ++i) {
-				RL_WSTEP(5);
-				const Tri TT = LoadTri(S, first + i);
-				c.tris++;
-				// reference geom/triangle.cc:22-27
-				const float t = dot((TT.v0 - o), TT.n) / dot(d, TT.n);
-				if (!(t >= tMin && t <= FLT_MAX && t < T.best.t)) continue;
-				const V3 pp = o + t * d;
-				const V3 w = pp - TT.v0;
-				const float wv = dot(w, TT.v), wu = dot(w, TT.u);
-				const float pa = (TT.uv * wv - TT.vv * wu) / TT.denom;
-				const float pb = (TT.uv * wu - TT.uu * wv) / TT.denom;
-				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
-					if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
-					T.best.t = t; T.best.a = pa; T.best.b = pb; T.best.tri = first + i;
-					if (T.anyhit) { T.cur = DONE; T.sp = 0; return true; }
-				}
-			}
-		} else {
-			c.tris++;
-			float2 r;
-			if (kind == 1u) r = make_float2(SphereHit(S.spheres, first, o, d, tMin, T.best.t), 0.0f);
-			else r = CubeHit(S.cubes, first, o, d, T.rayTime, tMin, T.best.t);
-			if (r.x == r.x) {   // not NaN: a hit
-				T.best.t = r.x; T.best.a = r.y; T.best.b = 0.0f; T.best.tri = (int)((kind << 28) | (uint32_t)first);
-				if (T.anyhit) { T.cur = DONE; T.sp = 0; return true; }
-			}
-		}
-	}
-	if (sp == 0) { T.cur = DONE; T.sp = 0; return true; }
-	--sp;
-	T.cur = stk[sp * RL_BLOCK]; T.sp = sp;
-	return false;
-}
-
 // Single steps on the resumable state, for the vote-driven loop of k_trace_pool: a lane is either at an inner node
 // (cur >= 0), at a leaf (cur < 0, leafI = next primitive of it), or finished (both return true then).
-template <int STACK>
-__device__ __forceinline__ bool PopOrFinish(Trav& T, int* stk)
+// LSTACK entries of the traversal stack live in LDS (stk), deeper ones in the lane's private overflow array (scratch):
+// with a 19-entry LDS part a 32-deep stack fits 4 workgroups per CU; trees rarely need the overflow.
+template <int LSTACK, int STACK>
+__device__ __forceinline__ void StackPush(Trav& T, int* stk, int* ovf, int v)
+{
+	if (T.sp < LSTACK) { stk[T.sp * RL_BLOCK] = v; ++T.sp; }
+	else if (LSTACK < STACK && T.sp < STACK) { ovf[T.sp - LSTACK] = v; ++T.sp; }
+}
+template <int LSTACK, int STACK>
+__device__ __forceinline__ bool PopOrFinish(Trav& T, int* stk, int* ovf)
 {
 	if (T.sp == 0) return true;
 	--T.sp;
-	T.cur = stk[T.sp * RL_BLOCK];
+	T.cur = (LSTACK < STACK && T.sp >= LSTACK) ? ovf[T.sp - LSTACK] : stk[T.sp * RL_BLOCK];
 	T.leafI = 0;
 	return false;
 }
-template <int STACK>
-__device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMin, int* stk, Counters& c)
+template <int LSTACK, int STACK>
+__device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c)
 {
 	RL_WSTEP(4);
 	const float4* np = (const float4*)(S.nodes + T.cur);
@@ -1159,16 +1092,16 @@ __device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMi
 	if (hl && hr) {
 		const bool leftFirst = tl <= tr;
 		const int nearC = leftFirst ? k.x : k.y, farC = leftFirst ? k.y : k.x;
-		if (T.sp < STACK) { stk[T.sp * RL_BLOCK] = farC; ++T.sp; }
+		StackPush<LSTACK, STACK>(T, stk, ovf, farC);
 		T.cur = nearC;
 		return false;
 	}
 	if (hl) { T.cur = k.x; return false; }
 	if (hr) { T.cur = k.y; return false; }
-	return PopOrFinish<STACK>(T, stk);
+	return PopOrFinish<LSTACK, STACK>(T, stk, ovf);
 }
-template <int STACK, bool PRIMS>
-__device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMin, int* stk, Counters& c)
+template <int LSTACK, int STACK, bool PRIMS>
+__device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c)
 {
 	RL_WSTEP(5);
 	const uint32_t code = (uint32_t)~T.cur;
@@ -1206,7 +1139,7 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 		}
 	}
 	if (++T.leafI < count) return false;
-	return PopOrFinish<STACK>(T, stk);
+	return PopOrFinish<LSTACK, STACK>(T, stk, ovf);
 }
 
 // sky part of the miss shader (reference render/renderer.cc:155-181)
@@ -1247,21 +1180,25 @@ __device__ __forceinline__ V3 FoldPath(const float* __restrict__ pathStack, uint
 	return L;
 }
 
-template <int STACK, bool PRIMS, int K> struct PoolOcc {
+template <int LSTACK, bool PRIMS, int K> struct PoolOcc {
 	static constexpr int kFields = PRIMS ? F_COUNT : F_COUNT - 1;
-	static constexpr int kLdsPerBlock = STACK * RL_BLOCK * 4 + (RL_BLOCK / 64) * (kFields * 64 * K * 4 + 64 * K);
+	static constexpr int kLdsPerBlock = LSTACK * RL_BLOCK * 4 + (RL_BLOCK / 64) * (kFields * 64 * K * 4 + 64 * K);
 	static constexpr int kFit = (160 * 1024) / kLdsPerBlock;
 	static constexpr int kBlocks = kFit < 1 ? 1 : (kFit > RL_POOL_MAXBLOCKS ? RL_POOL_MAXBLOCKS : kFit);
 };
 
-template <int STACK, bool PRIMS, int K>
-__global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<STACK, PRIMS, K>::kBlocks))
+// STACK: capacity of the traversal stack; LSTACK <= STACK: how much of it lives in LDS (the rest is private overflow)
+template <int STACK, bool PRIMS, int K, int LSTACK = STACK>
+__global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<LSTACK, PRIMS, K>::kBlocks))
 k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
              float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
 	constexpr int PP = 64 * K;
-	__shared__ int s_stack[STACK * RL_BLOCK];
-	__shared__ float s_pool[RL_BLOCK / 64][PoolOcc<STACK, PRIMS, K>::kFields][PP];
+	static_assert(LSTACK <= STACK, "the LDS part cannot exceed the stack");
+	__shared__ int s_stack[LSTACK * RL_BLOCK];
+	int ovfStore[LSTACK < STACK ? STACK - LSTACK : 1];
+	int* ovf = ovfStore;
+	__shared__ float s_pool[RL_BLOCK / 64][PoolOcc<LSTACK, PRIMS, K>::kFields][PP];
 	__shared__ unsigned char s_free[RL_BLOCK / 64][PP];
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1468,8 +1405,8 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 					const bool atNode = busy && T.cur >= 0, atLeaf = busy && T.cur < 0;
 					const int nN = (int)__popcll(__ballot(atNode)), nL = (int)__popcll(__ballot(atLeaf));
 					bool fin = false;
-					if (nN * RL_POOL_WNODE >= nL * RL_POOL_WLEAF) { if (atNode) fin = NodeStep<STACK>(S, T, P.rayTMin, stk, c); }
-					else { if (atLeaf) fin = LeafStep<STACK, PRIMS>(S, T, P.rayTMin, stk, c); }
+					if (nN * RL_POOL_WNODE >= nL * RL_POOL_WLEAF) { if (atNode) fin = NodeStep<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c); }
+					else { if (atLeaf) fin = LeafStep<LSTACK, STACK, PRIMS>(S, T, P.rayTMin, stk, ovf, c); }
 					if (fin) {
 						const bool hit = T.best.tri >= 0;
 						int q = T.best.tri;
@@ -2049,9 +1986,16 @@ typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot,
 
 // poolK = 0: k_trace (one path per lane); poolK = K: k_trace_pool with 64*K paths per wave
 template <int STACK, bool PRIMS>
-TraceKernel SelectTraceKernel(int& poolK)
+TraceKernel SelectTraceKernel(int& poolK, uint32_t bvhDepth, bool& shortStack)
 {
+	shortStack = false;
 	if constexpr (STACK <= 32 && !PRIMS) {
+		if constexpr (STACK == 32) {
+			const char* e = getenv("RAYLIB_POOL_SHORT_STACK");
+			const bool wantShort = e ? atoi(e) != 0 : bvhDepth <= RL_POOL_SHORT_MAXDEPTH;
+			if (poolK == 2 && e && atoi(e) == 4) { shortStack = true; return k_trace_pool<STACK, PRIMS, 2, 4>; }   // tests: nearly every push overflows
+			if (poolK == 2 && wantShort) { shortStack = true; return k_trace_pool<STACK, PRIMS, 2, RL_POOL_SHORT_LSTACK>; }
+		}
 		if (poolK == 2) return k_trace_pool<STACK, PRIMS, 2>;
 		if (poolK == 3) return k_trace_pool<STACK, PRIMS, 3>;
 		if (poolK == 4) return k_trace_pool<STACK, PRIMS, 4>;
@@ -2110,7 +2054,8 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		// path per lane (k_trace).  RAYLIB_POOL=0|2|3|4 overrides.
 		int poolK = (STACK > 16 && STACK <= 32 && !PRIMS) ? 2 : 0;
 		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
-		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK);
+		bool shortStack = false;
+		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, sc.bvh.depth, shortStack);
 		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
 		schedulePaths = pathsPerThread;
 		int blocksPerCU = 0;

@@ -404,6 +404,12 @@ def test_pool_schedule_is_default_on_deep_bvh_and_bit_identical(mid_scene, gpu_l
         monkeypatch.setenv("RAYLIB_POOL", k)
         assert np.array_equal(bits(ses.render(96, 64, 8, max_path=6)), bits(base))
     monkeypatch.delenv("RAYLIB_POOL")
+    # the traversal stack's LDS part: 19 entries (default up to depth 24), all 32, and 4 (test build: the private overflow
+    # array takes nearly every push)
+    for mode in ("0", "1", "4"):
+        monkeypatch.setenv("RAYLIB_POOL_SHORT_STACK", mode)
+        assert np.array_equal(bits(ses.render(96, 64, 8, max_path=6)), bits(base)), mode
+    monkeypatch.delenv("RAYLIB_POOL_SHORT_STACK")
     # windows recomputed by the CPU oracle with the same pixel keys
     flat = helpers.objflat.load_obj(obj, oracle, texture_loader=helpers.texture_loader, sun_illuminance=(20, 20, 20), sun_direction=(-1.0, -1.0, 0.0))
     scene = oracle.scene_create(flat, 1)
