@@ -119,7 +119,10 @@ def main():
     # device buffers: this rank's cells (padded to equal size for the gather) and, on rank 0, the frame
     if distributed:
         pad_floats = max(tiling.padded_cells(w, h, world) * 64 * 4, w * h * 4 if world == 1 else 0)
-        mine = torch.zeros(pad_floats, dtype=torch.float32, device=dev)
+        # two send buffers, used alternately: the gather of frame i (RCCL's stream) may still be reading its buffer while the
+        # library (its own stream) already renders frame i + 1 into the other one
+        mines = [torch.zeros(pad_floats, dtype=torch.float32, device=dev) for _ in range(2)]
+        mine = mines[0]
         gathered = [torch.zeros(pad_floats, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
         frame = torch.zeros(h * w, 4, dtype=torch.float32, device=dev) if rank == 0 else None
         plan = tiling.torch_scatter_plan(w, h, world, dev) if rank == 0 else None
@@ -129,13 +132,25 @@ def main():
     stats = binding.Stats()
     acc = dict(rays=0, trace_ms=0.0, launches=0, bytes=0, nodes=0, tris=0, shaded=0, texels=0, samples=0, kernel_ms=0.0)
 
+    pending = [None, None]
+    frame_no = [0]
+
     def step(record):
-        ok = lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(mine.data_ptr()))
+        out = mine
+        if distributed:
+            k = frame_no[0] & 1
+            frame_no[0] += 1
+            out = mines[k]
+            if pending[k] is not None:
+                pending[k].wait()                             # the gather that read this buffer two frames ago ...
+                torch.cuda.current_stream().synchronize()     # ... is complete before the library's stream overwrites it (returns at once in steady state)
+        ok = lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(out.data_ptr()))
         if ok != 1:
             raise SystemExit("RaylibAMD_RenderDevice failed")
         if distributed:
-            dist.gather(mine, gathered, dst=0)               # one RCCL gather per frame
+            pending[k] = dist.gather(out, gathered, dst=0, async_op=True)   # one RCCL gather per frame
             if rank == 0:
+                pending[k].wait()                             # stream-level: the assembly below is ordered after the gather
                 if world == 1:
                     frame.copy_(gathered[0][: h * w * 4].view(h * w, 4))   # one rank renders the row-major frame directly
                 else:
@@ -174,6 +189,16 @@ def main():
     else:
         total_rays, total_samples = float(acc["rays"]), float(acc["samples"])
 
+    frame_check = None
+    if distributed and rank == 0:
+        # outside the timed region: the frame assembled from the ranks' cells against this rank's own render of the whole frame
+        torch.cuda.synchronize()
+        whole = torch.zeros(h * w * 4, dtype=torch.float32, device=dev)
+        if lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, 0, 1, C.c_void_p(whole.data_ptr())) == 1:
+            same = bool(torch.equal(whole.view(torch.int32), frame.reshape(-1).view(torch.int32)))
+            frame_check = "assembled frame bit-identical to a one-GPU render" if same else "MISMATCH between the assembled frame and a one-GPU render"
+        lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(mines[0].data_ptr()))   # stats of a timed-style call again
+
     if rank == 0:
         launches = max(1, acc["launches"])
         avg_launch_ms = acc["trace_ms"] / launches
@@ -203,7 +228,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "scene_triangles": ntris, "width": w, "height": h, "spp": wl["spp"],
                        "max_path_length": wl["max_path"], "seed": 1, "tiling": "8x8 cells round-robin over %d rank(s)" % world,
-                       "rays_per_step": total_rays / args.steps, "camera_samples_per_step": total_samples / args.steps},
+                       "rays_per_step": total_rays / args.steps, "camera_samples_per_step": total_samples / args.steps,
+                       "frame_check": frame_check},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_trace" if stats.pathsPerWave <= 64 else "k_trace_pool", "paths_per_wave": int(stats.pathsPerWave), "avg_launch_ms": avg_launch_ms, "launches": acc["launches"],
