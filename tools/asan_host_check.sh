@@ -10,4 +10,4 @@ g++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined -fno-omit-frame
 cd "$ROOT"
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
 LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so)" RAYLIB_LIB="$OUT" \
-    python -m pytest tests/test_host_logic.py -x -q
+    python -m pytest tests/test_host_logic.py tests/test_image_codecs.py -x -q
