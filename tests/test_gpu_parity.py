@@ -427,3 +427,29 @@ def test_full_size_pool_schedule_bit_identical(full_size, monkeypatch):
     ses, img, _ = full_size
     monkeypatch.setenv("RAYLIB_POOL", "2")
     assert np.array_equal(bits(ses.render(1920, 1080, 64)), bits(img))
+
+
+def test_configs2_size_scene_all_schedules_agree(gpu_lib, workdir, monkeypatch):
+    """BASELINE configs[2]-size scene (298 k triangles, sun, 1080p; 2 spp to keep the suite short): the default schedule
+    (pool, 19-entry LDS stack), the pool with the whole stack in LDS and the one-path-per-lane kernel give the same bits
+    and the same ray / shading counts.  (Windows of this scene against the CPU oracle: tools/gpu_big.py.)"""
+    from raylib_amd import binding
+    d = os.path.join(str(workdir), "c2"); os.makedirs(d, exist_ok=True)
+    obj, n = helpers.scenes.cornell(os.path.join(d, "c2.obj"), tess=137, displace_fraction=0.2)
+    assert n > 290000
+    cam = helpers.scenes.CONFIG_CAMERAS["breakfast"]
+    ses = binding.SceneSession(gpu_lib, obj, cam["origin"], cam["look_at"], cam["fov"], 1920 / 1080, sun=cam["sun"], sun_dir=cam["sun_dir"])
+    img = ses.render(1920, 1080, 2)
+    st = ses.stats().as_dict()
+    assert st["pathsPerWave"] == 128 and 16 < st["bvhDepth"] <= 24
+    assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
+    for env in (dict(RAYLIB_POOL="0"), dict(RAYLIB_POOL_SHORT_STACK="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = ses.render(1920, 1080, 2)
+        so = ses.stats().as_dict()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(bits(other), bits(img)), env
+        assert so["rays"] == st["rays"] and so["shadedHits"] == st["shadedHits"] and so["cameraSamples"] == st["cameraSamples"], env
+    ses.close()
