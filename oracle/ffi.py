@@ -70,7 +70,8 @@ class FlatSceneDesc(C.Structure):
 
 
 class OracleCounters(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("cameraSamples", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("cameraSamples", C.c_uint64),
+                ("closestHitTies", C.c_uint64)]
 
 
 def make_camera(origin, look_at, fov_y, aspect, aperture=0.0, focal=1.0, t0=0.0, t1=0.0):
@@ -196,7 +197,8 @@ class Checker:
     def counters(self, scene):
         c = OracleCounters()
         self.lib.oracle_get_counters(scene, C.byref(c))
-        return {"rays": c.rays, "nodes_visited": c.nodesVisited, "tris_tested": c.trisTested, "camera_samples": c.cameraSamples}
+        return {"rays": c.rays, "nodes_visited": c.nodesVisited, "tris_tested": c.trisTested, "camera_samples": c.cameraSamples,
+                "closest_hit_ties": c.closestHitTies}
 
     # -- known-answer helpers --------------------------------------------------
     def closest_hit(self, scene, rays, tmin=1e-4):

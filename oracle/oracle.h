@@ -18,6 +18,7 @@ typedef struct OracleCounters {
 	uint64_t nodesVisited;  /* BVHNode::Hit calls whose box test ran (reference bvh.cc:82-84) */
 	uint64_t trisTested;    /* Triangle::Hit calls (reference triangle.cc:18) */
 	uint64_t cameraSamples;
+	uint64_t closestHitTies; /* BVH nodes where both subtrees returned a hit at exactly the same t (answer depends on the tree shape) */
 } OracleCounters;
 
 void*   oracle_scene_create(const FlatSceneDesc* desc, uint64_t buildSeed);

@@ -481,6 +481,7 @@ uint64_t RaylibAMD_SceneBVHHash(SceneHandle sh)
 	auto feed = [&h](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
 	feed(s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(DNode));
 	feed(s->bvh.triOrder.data(), s->bvh.triOrder.size() * sizeof(uint32_t));
+	feed(s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(DNode4));
 	return h;
 }
 void RaylibAMD_CameraExport(CameraHandle h, float out[19])

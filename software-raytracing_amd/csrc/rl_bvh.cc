@@ -231,7 +231,7 @@ inline int32_t leafRef(uint32_t first, uint32_t kind, uint32_t count) { return ~
 
 void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 {
-	out.nodes.clear(); out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
+	out.nodes.clear(); out.nodes4.clear(); out.stackNeed4 = 0; out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
 	const uint32_t n = (uint32_t)prims.size();
 	Box empty; empty.mn = F3(FLT_MAX, FLT_MAX, FLT_MAX); empty.mx = F3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
 
@@ -356,6 +356,55 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		std::chrono::duration<double>(tb1 - tb0).count(), std::chrono::duration<double>(tb2 - tb1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tb2).count());
 	out.depth = maxDepth;     // leaves at depth d => at most d inner nodes above them
 	out.sahCost = (float)sah;
+
+	// ---- the wide tree: collapse to <= 4 children per node ----
+	// Starting from a node's two children, the inner child with the largest surface area is replaced by its own two
+	// children until there are four (or only leaves).  Only for trees the pool schedule will run (deeper than 16, triangles only).
+	bool trianglesOnly = true;
+	for (uint32_t i = 0; i < n && trianglesOnly; ++i) if (prims[i].kind != PRIM_TRIANGLE) trianglesOnly = false;
+	if (maxDepth > 16 && trianglesOnly) {
+		struct Item { int32_t tmp; int32_t slot; uint32_t need; };   // a BVH2 inner node that becomes wide node `slot`
+		std::vector<Item> work;
+		out.nodes4.clear();
+		out.nodes4.reserve(T.size() / 3 + 1);
+		out.nodes4.emplace_back();
+		work.push_back({ root, 0, 0u });
+		uint32_t needMax = 0;
+		while (!work.empty()) {
+			const Item it = work.back(); work.pop_back();
+			int32_t kids[4]; int nk = 0;
+			kids[nk++] = T[it.tmp].left; kids[nk++] = T[it.tmp].right;
+			while (nk < 4) {
+				int best = -1; float bestArea = -1.0f;
+				for (int k = 0; k < nk; ++k) if (T[kids[k]].left >= 0) { const float a = T[kids[k]].box.halfArea(); if (a > bestArea) { bestArea = a; best = k; } }
+				if (best < 0) break;
+				const int32_t open = kids[best];
+				kids[best] = T[open].left; kids[nk++] = T[open].right;
+			}
+			DNode4 nd; memset(&nd, 0, sizeof(nd));
+			const uint32_t need = it.need + (uint32_t)(nk - 1);   // entries this node can leave on the stack while one child is followed
+			if (need > needMax) needMax = need;
+			for (int k = 0; k < 4; ++k) {
+				if (k >= nk) {
+					nd.lo[0][k] = nd.lo[1][k] = nd.lo[2][k] = FLT_MAX; nd.hi[0][k] = nd.hi[1][k] = nd.hi[2][k] = -FLT_MAX;
+					nd.child[k] = DNODE_EMPTY;
+					continue;
+				}
+				const TmpNode& c = T[kids[k]];
+				nd.lo[0][k] = c.box.mn.x; nd.lo[1][k] = c.box.mn.y; nd.lo[2][k] = c.box.mn.z;
+				nd.hi[0][k] = c.box.mx.x; nd.hi[1][k] = c.box.mx.y; nd.hi[2][k] = c.box.mx.z;
+				if (c.left < 0) nd.child[k] = leafCode[kids[k]];
+				else {
+					const int32_t slot = (int32_t)out.nodes4.size();
+					out.nodes4.emplace_back();
+					nd.child[k] = slot;
+					work.push_back({ kids[k], slot, need });
+				}
+			}
+			out.nodes4[it.slot] = nd;
+		}
+		out.stackNeed4 = needMax;
+	} else { out.nodes4.clear(); out.stackNeed4 = 0; }
 }
 
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris)

@@ -24,6 +24,18 @@ struct alignas(64) DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode");
 
+// BVH4 node, 128 B = one L2 line: up to four child boxes, structure of arrays so that a lane reads
+// lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] with 7 x 16-byte loads.  Child references as in DNode.
+// Built by collapsing the BVH2 (rl_bvh.cc); used by the pool schedule on large scenes, where traversal is bound by
+// dependent fetches: half as many of them per ray.
+struct alignas(128) DNode4 {
+	float lo[3][4];
+	float hi[3][4];
+	int32_t child[4];
+	uint32_t pad[4];
+};
+static_assert(sizeof(DNode4) == 128, "DNode4");
+
 // Triangle intersection record, 64 B.  The reference tests ray vs plane, then
 // barycentrics from dot products of edge vectors (geom/triangle.cc:18-58); all
 // ray-independent terms of that formula are precomputed here with the reference's
@@ -87,6 +99,7 @@ struct DCamera {
 
 struct DSceneView {
 	const DNode* nodes;
+	const DNode4* nodes4;      // nullptr unless the scene carries the wide tree
 	const DTriIsect* isect;
 	const DTriShade* shade;
 	const DMaterial* materials;

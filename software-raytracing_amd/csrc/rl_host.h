@@ -101,6 +101,8 @@ struct Camera {
 
 struct BVH {
 	std::vector<DNode> nodes;
+	std::vector<DNode4> nodes4;       // the same tree collapsed to <= 4 children per node (empty for small scenes / analytic primitives)
+	uint32_t stackNeed4 = 0;          // worst-case traversal-stack entries of nodes4 (sum of children - 1 along the deepest path)
 	std::vector<uint32_t> triOrder;   // leaf order -> index into the flat triangle array
 	uint32_t depth = 0;
 	float sahCost = 0.0f;

@@ -361,7 +361,9 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 					c.tris++;
 					// reference geom/triangle.cc:22-27
 					const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
-					if (!(t >= tMin && t <= FLT_MAX && t < best.t)) continue;
+					// closer, or exactly as far with a lower slot: which of two surfaces at the same t wins must not depend on the
+					// order a traversal happens to test them in (the reference's answer there depends on its random tree, SURVEY A)
+					if (!(t >= tMin && t <= FLT_MAX && (t < best.t || (t == best.t && first + i < best.tri)))) continue;
 					const V3 p = o + t * d;
 					const V3 w = p - T.v0;
 					const float wv = dot(w, T.v), wu = dot(w, T.u);
@@ -1100,6 +1102,47 @@ __device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMi
 	if (hr) { T.cur = k.y; return false; }
 	return PopOrFinish<LSTACK, STACK>(T, stk, ovf);
 }
+// One step on the BVH4 (DNode4, 128 B): four slab tests, the hit children ordered by entry distance (5-comparator network),
+// the nearest followed, the others pushed far-to-near.  Counts as two 64-byte node records.
+template <int LSTACK, int STACK>
+__device__ __forceinline__ bool NodeStep4(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c)
+{
+	RL_WSTEP(4);
+	const float4* np = (const float4*)(S.nodes4 + T.cur);
+	const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
+	const int4 ch = ((const int4*)np)[6];
+	c.nodes += 2;
+	const float tmx = fminf(T.best.t, FLT_MAX);
+	// near / far planes per axis by the ray's sign, for the four children at once
+	const float4 nX = T.nx ? hix : lox, fX = T.nx ? lox : hix;
+	const float4 nY = T.ny ? hiy : loy, fY = T.ny ? loy : hiy;
+	const float4 nZ = T.nz ? hiz : loz, fZ = T.nz ? loz : hiz;
+	float t0, t1, t2, t3;
+	#define RL_SLAB4(k, tk) { \
+		float tn = tMin, tf = tmx; \
+		tn = fmaxf(tn, (nX.k - T.o.x) * T.inv.x); tf = fminf(tf, (fX.k - T.o.x) * T.inv.x); \
+		tn = fmaxf(tn, (nY.k - T.o.y) * T.inv.y); tf = fminf(tf, (fY.k - T.o.y) * T.inv.y); \
+		tn = fmaxf(tn, (nZ.k - T.o.z) * T.inv.z); tf = fminf(tf, (fZ.k - T.o.z) * T.inv.z); \
+		tk = (tf * RL_POOL_WIDEN < tn) ? INFINITY : tn; }
+	RL_SLAB4(x, t0) RL_SLAB4(y, t1) RL_SLAB4(z, t2) RL_SLAB4(w, t3)
+	#undef RL_SLAB4
+	int r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
+	if (r0 == DNODE_EMPTY) t0 = INFINITY;
+	if (r1 == DNODE_EMPTY) t1 = INFINITY;
+	if (r2 == DNODE_EMPTY) t2 = INFINITY;
+	if (r3 == DNODE_EMPTY) t3 = INFINITY;
+	#define RL_CSWAP(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; const int rr = sw ? rb : ra; rb = sw ? ra : rb; ra = rr; }
+	RL_CSWAP(t0, r0, t1, r1) RL_CSWAP(t2, r2, t3, r3) RL_CSWAP(t0, r0, t2, r2) RL_CSWAP(t1, r1, t3, r3) RL_CSWAP(t1, r1, t2, r2)
+	#undef RL_CSWAP
+	T.leafI = 0;
+	if (!(t0 < INFINITY)) return PopOrFinish<LSTACK, STACK>(T, stk, ovf);
+	if (t3 < INFINITY) StackPush<LSTACK, STACK>(T, stk, ovf, r3);
+	if (t2 < INFINITY) StackPush<LSTACK, STACK>(T, stk, ovf, r2);
+	if (t1 < INFINITY) StackPush<LSTACK, STACK>(T, stk, ovf, r1);
+	T.cur = r0;
+	return false;
+}
+
 template <int LSTACK, int STACK, bool PRIMS>
 __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c)
 {
@@ -1116,7 +1159,7 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 		const Tri TT = LoadTri(S, i);
 		// reference geom/triangle.cc:22-27
 		const float t = dot((TT.v0 - o), TT.n) / dot(d, TT.n);
-		if (t >= tMin && t <= FLT_MAX && t < T.best.t) {
+		if (t >= tMin && t <= FLT_MAX && (t < T.best.t || (t == T.best.t && i < T.best.tri))) {   // ties: the lower slot, as in Traverse()
 			const V3 pp = o + t * d;
 			const V3 w = pp - TT.v0;
 			const float wv = dot(w, TT.v), wu = dot(w, TT.u);
@@ -1188,7 +1231,8 @@ template <int LSTACK, bool PRIMS, int K> struct PoolOcc {
 };
 
 // STACK: capacity of the traversal stack; LSTACK <= STACK: how much of it lives in LDS (the rest is private overflow)
-template <int STACK, bool PRIMS, int K, int LSTACK = STACK>
+// WIDE: traverse the BVH4 (S.nodes4) instead of the BVH2
+template <int STACK, bool PRIMS, int K, int LSTACK = STACK, bool WIDE = false>
 __global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<LSTACK, PRIMS, K>::kBlocks))
 k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
              float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
@@ -1405,7 +1449,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 					const bool atNode = busy && T.cur >= 0, atLeaf = busy && T.cur < 0;
 					const int nN = (int)__popcll(__ballot(atNode)), nL = (int)__popcll(__ballot(atLeaf));
 					bool fin = false;
-					if (nN * RL_POOL_WNODE >= nL * RL_POOL_WLEAF) { if (atNode) fin = NodeStep<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c); }
+					if (nN * RL_POOL_WNODE >= nL * RL_POOL_WLEAF) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c); }
 					else { if (atLeaf) fin = LeafStep<LSTACK, STACK, PRIMS>(S, T, P.rayTMin, stk, ovf, c); }
 					if (fin) {
 						const bool hit = T.best.tri >= 0;
@@ -1822,6 +1866,7 @@ k_eval_math(int fn, const float* __restrict__ x, const float* __restrict__ y, in
 	Log("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__, __LINE__, #expr); return false; } } while (0)
 
 struct DeviceScene {
+	DNode4* nodes4 = nullptr; uint32_t stackNeed4 = 0;
 	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
 	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
 	DSphere* spheres = nullptr; DCube* cubes = nullptr;
@@ -1940,6 +1985,7 @@ bool UploadScene(Scene& sc)
 		pool.insert(pool.end(), im.rgba.begin(), im.rgba.end());
 	}
 	if (!Upload(D->nodes, sc.bvh.nodes.data(), sc.bvh.nodes.size())) return false;
+	if (!sc.bvh.nodes4.empty()) { if (!Upload(D->nodes4, sc.bvh.nodes4.data(), sc.bvh.nodes4.size())) return false; D->stackNeed4 = sc.bvh.stackNeed4; }
 	if (!Upload(D->isect, isect.data(), n)) return false;
 	if (!Upload(D->shade, shade.data(), n)) return false;
 	if (!Upload(D->materials, mats.data(), mats.size())) return false;
@@ -1962,7 +2008,7 @@ bool UploadScene(Scene& sc)
 	if (!Upload(D->spheres, dsph.data(), dsph.size())) return false;
 	if (!Upload(D->cubes, dcub.data(), dcub.size())) return false;
 	DSceneView& V = D->view;
-	V.nodes = D->nodes; V.isect = D->isect; V.shade = D->shade; V.materials = D->materials;
+	V.nodes = D->nodes; V.nodes4 = D->nodes4; V.isect = D->isect; V.shade = D->shade; V.materials = D->materials;
 	V.textures = D->textures; V.texels = D->texels; V.spheres = D->spheres; V.cubes = D->cubes;
 	V.sunIlluminance[0] = sc.sunIlluminance.x; V.sunIlluminance[1] = sc.sunIlluminance.y; V.sunIlluminance[2] = sc.sunIlluminance.z;
 	V.sunDirection[0] = sc.sunDirection.x; V.sunDirection[1] = sc.sunDirection.y; V.sunDirection[2] = sc.sunDirection.z;
@@ -1986,12 +2032,21 @@ typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot,
 
 // poolK = 0: k_trace (one path per lane); poolK = K: k_trace_pool with 64*K paths per wave
 template <int STACK, bool PRIMS>
-TraceKernel SelectTraceKernel(int& poolK, uint32_t bvhDepth, bool& shortStack)
+TraceKernel SelectTraceKernel(int& poolK, uint32_t bvhDepth, const DeviceScene* D, bool& shortStack, bool& wide)
 {
-	shortStack = false;
+	shortStack = false; wide = false;
 	if constexpr (STACK <= 32 && !PRIMS) {
 		if constexpr (STACK == 32) {
 			const char* e = getenv("RAYLIB_POOL_SHORT_STACK");
+			// the wide tree: default whenever the scene carries one whose worst-case stack fits; RAYLIB_BVH4=0|1 overrides
+			const char* w = getenv("RAYLIB_BVH4");
+			const bool haveWide = D && D->nodes4 != nullptr && D->stackNeed4 <= 64;
+			const bool wantWide = haveWide && (w ? atoi(w) != 0 : true);
+			if (poolK == 2 && wantWide) {
+				wide = true; shortStack = true;
+				if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, true>; }
+				return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, true>;
+			}
 			const bool wantShort = e ? atoi(e) != 0 : bvhDepth <= RL_POOL_SHORT_MAXDEPTH;
 			if (poolK == 2 && e && atoi(e) == 4) { shortStack = true; return k_trace_pool<STACK, PRIMS, 2, 4>; }   // tests: nearly every push overflows
 			if (poolK == 2 && wantShort) { shortStack = true; return k_trace_pool<STACK, PRIMS, 2, RL_POOL_SHORT_LSTACK>; }
@@ -2054,8 +2109,8 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		// path per lane (k_trace).  RAYLIB_POOL=0|2|3|4 overrides.
 		int poolK = (STACK > 16 && STACK <= 32 && !PRIMS) ? 2 : 0;
 		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
-		bool shortStack = false;
-		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, sc.bvh.depth, shortStack);
+		bool shortStack = false, wide = false;
+		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, sc.bvh.depth, D, shortStack, wide);
 		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
 		schedulePaths = pathsPerThread;
 		int blocksPerCU = 0;
@@ -2271,7 +2326,7 @@ void DeviceReleaseScene(DeviceScene* D)
 {
 	if (!D) return;
 	std::lock_guard<std::mutex> lk(g_rt.lock);
-	(void)hipFree(D->nodes); (void)hipFree(D->isect); (void)hipFree(D->shade);
+	(void)hipFree(D->nodes); if (D->nodes4) (void)hipFree(D->nodes4); (void)hipFree(D->isect); (void)hipFree(D->shade);
 	(void)hipFree(D->materials); (void)hipFree(D->textures); (void)hipFree(D->texels); (void)hipFree(D->spheres); (void)hipFree(D->cubes);
 	delete D;
 }

@@ -146,9 +146,11 @@ void Scene::BuildAccel(float t0, float t1)
 			ref = ~(int32_t)code;
 		};
 		for (DNode& n : bvh.nodes) { patch(n.left); patch(n.right); }
+		for (DNode4& n : bvh.nodes4) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 	}
 	Log("Scene finalized: %u triangles, %u BVH nodes, depth %u, SAH cost %.2f (BVH build %.2f s)",
 	    (unsigned)triangles.size(), (unsigned)bvh.nodes.size(), bvh.depth, bvh.sahCost, buildSec);
+	if (!bvh.nodes4.empty()) Log("\twide tree: %u BVH4 nodes, worst-case traversal stack %u entries", (unsigned)bvh.nodes4.size(), bvh.stackNeed4);
 }
 
 // Image2D::PostProcess on the host (reference render/image.cc:44-103): max-luminance

@@ -59,6 +59,24 @@ def frac_bit_equal(a, b):
     return float((bits(a[..., :3]) == bits(b[..., :3])).all(-1).mean())
 
 
+
+def window_mismatches_without_a_tie(oracle, scene, cam, st, img, x0, y0, size):
+    """Compare a window with the oracle; a pixel may differ only if one of its samples met two surfaces at exactly the same t
+    (there the reference's own answer depends on its randomly shaped BVH; the oracle counts such events, the device breaks the tie
+    by the lower triangle slot).  Returns (pixels equal, pixels differing with a tie, pixels differing WITHOUT one)."""
+    want = oracle.render_region(scene, cam, st, x0, y0, size, size, seed=1)
+    got = img[y0:y0 + size, x0:x0 + size]
+    e = (bits(got[..., :3]) == bits(want[..., :3])).all(-1)
+    tied = untied = 0
+    for (py, px) in zip(*np.nonzero(~e)):
+        oracle.render_region(scene, cam, st, x0 + int(px), y0 + int(py), 1, 1, seed=1)
+        if oracle.counters(scene)["closest_hit_ties"] > 0:
+            tied += 1
+        else:
+            untied += 1
+    return int(e.sum()), tied, untied, l2(got, want)
+
+
 def golden(name):
     return np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
 
@@ -310,13 +328,13 @@ def test_full_size_windows_against_oracle(full_size, oracle, workdir):
     scene = oracle.scene_create(flat, 1)
     cam = ffi.make_camera(c["origin"], c["look_at"], 45.0, 1920 / 1080)
     st = ffi.make_settings(1920, 1080, 64)
-    tot, eq = 0, 0
+    tot = eq = tied = 0
     for (x0, y0) in ((952, 536), (700, 300), (1100, 800), (0, 0), (1904, 1064), (860, 200)):
-        want = oracle.render_region(scene, cam, st, x0, y0, 16, 16, seed=1)
-        got = img[y0:y0 + 16, x0:x0 + 16]
-        assert l2(got, want) < L2_TOL, "window %d,%d L2 %.3e" % (x0, y0, l2(got, want))
-        eq += (bits(got[..., :3]) == bits(want[..., :3])).all(-1).sum(); tot += 256
-    assert eq == tot, "%d of %d window pixels bit-equal" % (eq, tot)
+        same, t, untied, err = window_mismatches_without_a_tie(oracle, scene, cam, st, img, x0, y0, 16)
+        assert err < L2_TOL, "window %d,%d L2 %.3e" % (x0, y0, err)
+        assert untied == 0, "window %d,%d: %d pixels differ without a closest-hit tie" % (x0, y0, untied)
+        eq += same; tied += t; tot += 256
+    assert eq + tied == tot and tied <= 2, "%d of %d window pixels bit-equal, %d tie pixels" % (eq, tot, tied)
     assert stats["cameraSamples"] == 1920 * 1080 * 64 and stats["pixels"] == 1920 * 1080
 
 
@@ -416,10 +434,8 @@ def test_pool_schedule_is_default_on_deep_bvh_and_bit_identical(mid_scene, gpu_l
     cam = ffi.make_camera((0, 1, 5), (0, 1, -1), 60.0, 96 / 64)
     stg = ffi.make_settings(96, 64, 8, max_path=6)
     for (x0, y0) in ((40, 24), (0, 0), (80, 48)):
-        want = oracle.render_region(scene, cam, stg, x0, y0, 16, 16, seed=1)
-        got = img[y0:y0 + 16, x0:x0 + 16]
-        assert l2(got, want) < L2_TOL
-        assert frac_bit_equal(got, want) > 0.99, "window %d,%d" % (x0, y0)
+        same, tied, untied, err = window_mismatches_without_a_tie(oracle, scene, cam, stg, img, x0, y0, 16)
+        assert err < L2_TOL and untied == 0 and same + tied == 256 and tied <= 4, (x0, y0, same, tied, untied, err)
 
 
 def test_full_size_pool_schedule_bit_identical(full_size, monkeypatch):
