@@ -1043,6 +1043,10 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #define RL_POOL_WNODE 4   /* relative cost of a node step and a primitive step in the vote */
 #define RL_POOL_WLEAF 5
 #endif
+#ifndef RL_POOL_WNODE4
+#define RL_POOL_WNODE4 4  /* the same for a BVH4 step */
+#define RL_POOL_WLEAF4 5
+#endif
 #ifndef RL_POOL_KEEP
 #define RL_POOL_KEEP 52   /* leave the traversal loop to fetch new rays when no more than this many lanes still traverse */
 #endif
@@ -1449,7 +1453,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 					const bool atNode = busy && T.cur >= 0, atLeaf = busy && T.cur < 0;
 					const int nN = (int)__popcll(__ballot(atNode)), nL = (int)__popcll(__ballot(atLeaf));
 					bool fin = false;
-					if (nN * RL_POOL_WNODE >= nL * RL_POOL_WLEAF) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c); }
+					if (nN * (WIDE ? RL_POOL_WNODE4 : RL_POOL_WNODE) >= nL * (WIDE ? RL_POOL_WLEAF4 : RL_POOL_WLEAF)) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c); }
 					else { if (atLeaf) fin = LeafStep<LSTACK, STACK, PRIMS>(S, T, P.rayTMin, stk, ovf, c); }
 					if (fin) {
 						const bool hit = T.best.tri >= 0;
