@@ -473,6 +473,14 @@ int32_t RaylibAMD_SceneBVHInfo(SceneHandle sh, uint32_t* nodes, uint32_t* depth,
 	if (sah) *sah = s->bvh.sahCost;
 	return ValidateBVH(s->bvh, s->triangles) ? 1 : 0;
 }
+int32_t RaylibAMD_SceneBVH4Info(SceneHandle sh, uint32_t* nodes4, uint32_t* stackNeed)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized || s->bvh.nodes4.empty()) return 0;
+	if (nodes4) *nodes4 = (uint32_t)s->bvh.nodes4.size();
+	if (stackNeed) *stackNeed = s->bvh.stackNeed4;
+	return ValidateBVH4(s->bvh, s->triangles) ? 1 : -1;
+}
 uint64_t RaylibAMD_SceneBVHHash(SceneHandle sh)
 {
 	Scene* s = (Scene*)sh;

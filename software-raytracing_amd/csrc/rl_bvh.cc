@@ -448,4 +448,49 @@ bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris)
 	return true;
 }
 
+// The wide tree must hold every triangle exactly once, inside the box its parent records for it, every child box inside
+// its parent's, and never need more stack than stackNeed4 says.
+bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris)
+{
+	if (bvh.nodes4.empty()) return false;
+	std::vector<uint8_t> seen(tris.size(), 0);
+	struct Item { int32_t ref; f3 mn, mx; uint32_t need; bool haveBox; };
+	std::vector<Item> st;
+	st.push_back({ 0, F3(0, 0, 0), F3(0, 0, 0), 0u, false });
+	auto inside = [](const f3& p, const f3& mn, const f3& mx) {
+		return p.x >= mn.x && p.y >= mn.y && p.z >= mn.z && p.x <= mx.x && p.y <= mx.y && p.z <= mx.z;
+	};
+	while (!st.empty()) {
+		const Item it = st.back(); st.pop_back();
+		if (it.ref < 0) {
+			const uint32_t code = (uint32_t)~it.ref, first = code >> 6, count = (code & 7u) + 1;
+			if (((code >> 4) & 3u) != PRIM_TRIANGLE) return false;
+			for (uint32_t k = 0; k < count; ++k) {
+				if (first + k >= bvh.triOrder.size()) return false;
+				const uint32_t ti = bvh.triOrder[first + k];
+				if (ti >= tris.size() || seen[ti]) return false;
+				seen[ti] = 1;
+				const HostTriangle& t = tris[ti];
+				if (!inside(t.v0, it.mn, it.mx) || !inside(t.v1, it.mn, it.mx) || !inside(t.v2, it.mn, it.mx)) return false;
+			}
+			continue;
+		}
+		if ((size_t)it.ref >= bvh.nodes4.size()) return false;
+		const DNode4& n = bvh.nodes4[it.ref];
+		int nk = 0;
+		for (int k = 0; k < 4; ++k) if (n.child[k] != DNODE_EMPTY) ++nk;
+		if (nk < 2 && !(it.ref == 0 && nk >= 1)) return false;
+		const uint32_t need = it.need + (uint32_t)(nk - 1);
+		if (need > bvh.stackNeed4) return false;
+		for (int k = 0; k < 4; ++k) {
+			if (n.child[k] == DNODE_EMPTY) continue;
+			const f3 mn = F3(n.lo[0][k], n.lo[1][k], n.lo[2][k]), mx = F3(n.hi[0][k], n.hi[1][k], n.hi[2][k]);
+			if (it.haveBox && (!inside(mn, it.mn, it.mx) || !inside(mx, it.mn, it.mx))) return false;
+			st.push_back({ n.child[k], mn, mx, need, true });
+		}
+	}
+	for (uint8_t v : seen) if (!v) return false;
+	return true;
+}
+
 } // namespace rl

@@ -112,6 +112,7 @@ enum PrimKind { PRIM_TRIANGLE = 0, PRIM_SPHERE = 1, PRIM_CUBE = 2 };
 struct PrimRef { f3 mn, mx; uint8_t kind; uint32_t index; };
 void BuildBVH(const std::vector<PrimRef>& prims, BVH& out);
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris);
+bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris);
 
 // Scene elements created through include/raylib_amd.h (the reference's procedural scenes `new` C++ objects in the
 // application instead: src/main.cc:913-984).  A material is owned by the library and shared by reference.

@@ -131,6 +131,7 @@ def test_bvh_builder(lib, workdir):
         assert lib.RaylibAMD_SceneBVHInfo(ses.scene, C.byref(nodes), C.byref(depth), C.byref(sah)) == 1
         assert lib.RaylibAMD_SceneNumTriangles(ses.scene) == n
         assert n / 4 <= nodes.value <= n and depth.value <= 64
+        assert lib.RaylibAMD_SceneBVH4Info(ses.scene, None, None) == (1 if depth.value > 16 else 0)
         ses.close()
     # empty and single-triangle scenes
     sc = lib.Raylib_CreateScene(); lib.Raylib_FinalizeScene(sc)
@@ -150,7 +151,10 @@ def test_bvh_build_is_the_same_tree_for_any_thread_count(lib, workdir, monkeypat
         ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
         nodes, depth, sah = C.c_uint32(), C.c_uint32(), C.c_float()
         assert lib.RaylibAMD_SceneBVHInfo(ses.scene, C.byref(nodes), C.byref(depth), C.byref(sah)) == 1
-        seen[threads] = (lib.RaylibAMD_SceneBVHHash(ses.scene), nodes.value, depth.value, sah.value)
+        n4, need = C.c_uint32(), C.c_uint32()
+        assert lib.RaylibAMD_SceneBVH4Info(ses.scene, C.byref(n4), C.byref(need)) == 1          # the wide tree exists and is valid
+        assert nodes.value / 4 < n4.value < nodes.value and depth.value / 2 <= need.value <= 3 * depth.value
+        seen[threads] = (lib.RaylibAMD_SceneBVHHash(ses.scene), nodes.value, depth.value, sah.value, n4.value, need.value)
         ses.close()
     assert len(set(seen.values())) == 1, seen
 
