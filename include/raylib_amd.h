@@ -127,7 +127,7 @@ RAYLIB_API void    RaylibAMD_SceneGetSun(SceneHandle scene, float outIlluminance
 /* BVH shape: nodes (64 B each), depth, and a host-side validity check (every triangle
  * inside its leaf's box, every child box inside its parent's).  Returns 1 if valid. */
 RAYLIB_API int32_t RaylibAMD_SceneBVHInfo(SceneHandle scene, uint32_t* outNodes, uint32_t* outDepth, float* outSahCost);
-/* The 4-wide collapse of the tree that the pool schedule traverses on large scenes: 0 = the scene has none (BVH not deeper than 16, or
+/* The 4-wide collapse of the tree that the pool schedule traverses on large scenes: 0 = the scene has none (fewer than 8 triangles, or
  * analytic primitives), 1 = present and structurally valid (every triangle once, boxes nested, stack bound holds), -1 = invalid. */
 RAYLIB_API int32_t RaylibAMD_SceneBVH4Info(SceneHandle scene, uint32_t* outNodes4, uint32_t* outWorstCaseStack);
 /* FNV-1a of the flat BVH (node records + leaf order): the multi-threaded build (RAYLIB_BUILD_THREADS, default = host

@@ -359,10 +359,10 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 
 	// ---- the wide tree: collapse to <= 4 children per node ----
 	// Starting from a node's two children, the inner child with the largest surface area is replaced by its own two
-	// children until there are four (or only leaves).  Only for trees the pool schedule will run (deeper than 16, triangles only).
+	// children until there are four (or only leaves).  Only for scenes the pool schedule can run (triangles only, not tiny).
 	bool trianglesOnly = true;
 	for (uint32_t i = 0; i < n && trianglesOnly; ++i) if (prims[i].kind != PRIM_TRIANGLE) trianglesOnly = false;
-	if (maxDepth > 16 && trianglesOnly) {
+	if (n >= 8 && trianglesOnly) {
 		struct Item { int32_t tmp; int32_t slot; uint32_t need; };   // a BVH2 inner node that becomes wide node `slot`
 		std::vector<Item> work;
 		out.nodes4.clear();

@@ -2040,17 +2040,17 @@ TraceKernel SelectTraceKernel(int& poolK, uint32_t bvhDepth, const DeviceScene* 
 {
 	shortStack = false; wide = false;
 	if constexpr (STACK <= 32 && !PRIMS) {
+		const char* e = getenv("RAYLIB_POOL_SHORT_STACK");
+		// the wide tree: default whenever the scene carries one whose worst-case stack fits; RAYLIB_BVH4=0|1 overrides
+		const char* w = getenv("RAYLIB_BVH4");
+		const bool haveWide = D && D->nodes4 != nullptr && D->stackNeed4 <= 64;
+		const bool wantWide = haveWide && (w ? atoi(w) != 0 : true);
+		if (poolK == 2 && wantWide) {
+			wide = true; shortStack = true;
+			if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, true>; }
+			return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, true>;
+		}
 		if constexpr (STACK == 32) {
-			const char* e = getenv("RAYLIB_POOL_SHORT_STACK");
-			// the wide tree: default whenever the scene carries one whose worst-case stack fits; RAYLIB_BVH4=0|1 overrides
-			const char* w = getenv("RAYLIB_BVH4");
-			const bool haveWide = D && D->nodes4 != nullptr && D->stackNeed4 <= 64;
-			const bool wantWide = haveWide && (w ? atoi(w) != 0 : true);
-			if (poolK == 2 && wantWide) {
-				wide = true; shortStack = true;
-				if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, true>; }
-				return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, true>;
-			}
 			const bool wantShort = e ? atoi(e) != 0 : bvhDepth <= RL_POOL_SHORT_MAXDEPTH;
 			if (poolK == 2 && e && atoi(e) == 4) { shortStack = true; return k_trace_pool<STACK, PRIMS, 2, 4>; }   // tests: nearly every push overflows
 			if (poolK == 2 && wantShort) { shortStack = true; return k_trace_pool<STACK, PRIMS, 2, RL_POOL_SHORT_LSTACK>; }
@@ -2111,7 +2111,11 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		// Scheduling of the megakernel: scenes whose BVH needs the 32-entry stack are traversal-bound and run the pool
 		// schedule (k_trace_pool, 128 paths per wave); the Cornell class (tens of triangles, shading-bound) runs one
 		// path per lane (k_trace).  RAYLIB_POOL=0|2|3|4 overrides.
-		int poolK = (STACK > 16 && STACK <= 32 && !PRIMS) ? 2 : 0;
+		// default: the pool schedule for triangle scenes from RAYLIB_POOL_MIN_TRIS triangles on, else k_trace.  Measured crossover
+		// (tools/gpu_crossover.py, tessellated rooms at 1080p x 16 spp, pool time / k_trace time): 36 triangles 1.07, 144: 0.97,
+		// 324: 0.95, 1296: 0.89, 5184: 0.80, 20736: 0.67.
+		uint32_t minTris = 256; if (const char* e = getenv("RAYLIB_POOL_MIN_TRIS")) minTris = (uint32_t)atoi(e);
+		int poolK = (STACK <= 32 && !PRIMS && sc.triangles.size() >= minTris) ? 2 : 0;
 		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
 		bool shortStack = false, wide = false;
 		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, sc.bvh.depth, D, shortStack, wide);

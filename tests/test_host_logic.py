@@ -131,7 +131,7 @@ def test_bvh_builder(lib, workdir):
         assert lib.RaylibAMD_SceneBVHInfo(ses.scene, C.byref(nodes), C.byref(depth), C.byref(sah)) == 1
         assert lib.RaylibAMD_SceneNumTriangles(ses.scene) == n
         assert n / 4 <= nodes.value <= n and depth.value <= 64
-        assert lib.RaylibAMD_SceneBVH4Info(ses.scene, None, None) == (1 if depth.value > 16 else 0)
+        assert lib.RaylibAMD_SceneBVH4Info(ses.scene, None, None) == 1    # triangle scenes of 8+ triangles carry the valid wide tree
         ses.close()
     # empty and single-triangle scenes
     sc = lib.Raylib_CreateScene(); lib.Raylib_FinalizeScene(sc)
