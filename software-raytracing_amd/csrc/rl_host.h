@@ -187,6 +187,7 @@ float ParseDecimalFloat(const char* token);   // csrc/rl_obj_loader.cc: the OBJ 
 // csrc/rl_jpeg.cc: top-down RGBA8
 bool DecodeJPEG(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 bool DecodeTGA(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
+bool EncodeJPEG(uint32_t w, uint32_t h, const uint8_t* rgbTopDown, std::vector<uint8_t>& out);   // baseline, quality 75, 4:2:0
 bool DeviceRender(Scene& scene, const RenderRequest& req, RaylibAMDStats& stats);
 bool DeviceClosestHit(Scene& scene, const float* rays, int32_t n, float tMin, void* outHits);
 bool DevicePostProcess(Image& img);          // Image2D::PostProcess on the device; false when no device

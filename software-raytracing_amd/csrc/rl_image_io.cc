@@ -276,7 +276,17 @@ bool WriteImageFile(const Image& img, const char* path, uint32_t fileType)
 	switch (fileType) {
 		case RAYLIB_IMAGEFILETYPE_Bitmap: return WriteBMP(img, path);
 		case RAYLIB_IMAGEFILETYPE_Png:    return WritePNG(img, path);
-		default: Log("WriteImageToDisk: JPEG encoding is not available"); return false;
+		case RAYLIB_IMAGEFILETYPE_Jpg: {
+			std::vector<uint8_t> rgb((size_t)img.width * img.height * 3), file;
+			for (size_t i = 0; i < (size_t)img.width * img.height; ++i) for (int k = 0; k < 3; ++k) rgb[3 * i + k] = ToByte(img.rgba[4 * i + k]);
+			if (!EncodeJPEG(img.width, img.height, rgb.data(), file)) return false;
+			FILE* f = fopen(path, "wb");
+			if (!f) return false;
+			const bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+			fclose(f);
+			return ok;
+		}
+		default: Log("WriteImageToDisk: unknown file type %u", fileType); return false;
 	}
 }
 

@@ -9,6 +9,7 @@
 // pin the decoder against libjpeg-turbo driven the same way (Pillow's draft mode: JDCT_FASTEST, no fancy up-sampling).
 #include "rl_host.h"
 
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -460,6 +461,131 @@ bool DecodeTGA(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::vec
 			else { const uint8_t* e = cmap + (size_t)k * (cmBits / 8); o[0] = e[2]; o[1] = e[1]; o[2] = e[0]; o[3] = cmBits == 32 ? e[3] : 255; }
 		}
 	}
+	return true;
+}
+
+// ---------------------------------------------------------------------------
+// Baseline JPEG writer for Raylib_WriteImageToDisk(..., RAYLIB_IMAGEFILETYPE_Jpg) -- the console front-end saves its
+// results as .jpg (reference src/main.cc:480-510).  What FreeImage's flags = 0 produce: quality 75, 4:2:0 chroma,
+// the Annex K tables; the exact bytes of a lossy writer are not part of parity (tests: the file decodes, with Pillow and with
+// the decoder above, to within the quantisation error of the source).
+namespace {
+
+const uint8_t kStdLumaQ[64] = {   // ITU T.81 Table K.1, natural order
+	16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+	18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99 };
+const uint8_t kStdChromaQ[64] = { // Table K.2
+	17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+	99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99 };
+// Tables K.3 - K.6: code-length counts and symbols
+const uint8_t kDcLumaBits[16] = { 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0 };
+const uint8_t kDcChromaBits[16] = { 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0 };
+const uint8_t kDcVals[12] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 };
+const uint8_t kAcLumaBits[16] = { 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d };
+const uint8_t kAcLumaVals[162] = {
+	0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08,
+	0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28,
+	0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+	0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89,
+	0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6,
+	0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+	0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa };
+const uint8_t kAcChromaBits[16] = { 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77 };
+const uint8_t kAcChromaVals[162] = {
+	0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91,
+	0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26,
+	0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+	0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87,
+	0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4,
+	0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+	0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa };
+
+struct EncTable { uint16_t code[256]; uint8_t len[256]; };
+void BuildEnc(const uint8_t* bits, const uint8_t* vals, EncTable& t)
+{
+	memset(&t, 0, sizeof(t));
+	int code = 0, k = 0;
+	for (int l = 1; l <= 16; ++l) { for (int i = 0; i < bits[l - 1]; ++i) { t.code[vals[k]] = (uint16_t)code; t.len[vals[k]] = (uint8_t)l; ++code; ++k; } code <<= 1; }
+}
+struct BitWriter {
+	std::vector<uint8_t>& out; uint32_t acc = 0; int n = 0;
+	explicit BitWriter(std::vector<uint8_t>& o) : out(o) {}
+	void put(uint32_t v, int len) { acc = (acc << len) | (v & ((1u << len) - 1u)); n += len; while (n >= 8) { const uint8_t b = (uint8_t)(acc >> (n - 8)); out.push_back(b); if (b == 0xFF) out.push_back(0); n -= 8; } }
+	void flush() { if (n) put(0x7F, 8 - n); }
+};
+void Fdct(const float* in, float* out)
+{
+	static float c[8][8]; static bool init = false;
+	if (!init) { for (int k = 0; k < 8; ++k) for (int x = 0; x < 8; ++x) c[k][x] = (k ? 0.5f : 0.35355339f) * cosf((2 * x + 1) * k * 3.14159265358979f / 16.0f); init = true; }
+	float tmp[64];
+	for (int y = 0; y < 8; ++y) for (int k = 0; k < 8; ++k) { float s = 0; for (int x = 0; x < 8; ++x) s += in[8 * y + x] * c[k][x]; tmp[8 * y + k] = s; }
+	for (int k = 0; k < 8; ++k) for (int x = 0; x < 8; ++x) { float s = 0; for (int y = 0; y < 8; ++y) s += tmp[8 * y + x] * c[k][y]; out[8 * k + x] = s; }
+}
+void EncodeBlock(BitWriter& bw, const float* px, const uint8_t* q, const EncTable& dc, const EncTable& ac, int& pred)
+{
+	float f[64]; Fdct(px, f);
+	int zz[64];
+	for (int i = 0; i < 64; ++i) { const float v = f[kZigzag[i]] / (float)q[kZigzag[i]]; zz[i] = (int)(v < 0 ? v - 0.5f : v + 0.5f); }
+	auto magnitude = [](int v, int& bits) { int a = v < 0 ? -v : v, s = 0; while (a) { ++s; a >>= 1; } bits = v < 0 ? v - 1 : v; return s; };
+	int bits; const int diff = zz[0] - pred; pred = zz[0];
+	int s = magnitude(diff, bits);
+	bw.put(dc.code[s], dc.len[s]); if (s) bw.put((uint32_t)bits, s);
+	int run = 0;
+	for (int k = 1; k < 64; ++k) {
+		if (zz[k] == 0) { ++run; continue; }
+		while (run > 15) { bw.put(ac.code[0xF0], ac.len[0xF0]); run -= 16; }
+		s = magnitude(zz[k], bits);
+		bw.put(ac.code[(run << 4) | s], ac.len[(run << 4) | s]); bw.put((uint32_t)bits, s);
+		run = 0;
+	}
+	if (run) bw.put(ac.code[0], ac.len[0]);
+}
+
+} // namespace
+
+bool EncodeJPEG(uint32_t w, uint32_t h, const uint8_t* rgb /* top-down, 3 bytes per pixel */, std::vector<uint8_t>& out)
+{
+	if (!w || !h || w > 65535 || h > 65535) return false;
+	uint8_t ql[64], qc[64];
+	for (int i = 0; i < 64; ++i) {   // jcparam.c jpeg_quality_scaling(75) = 50, jpeg_add_quant_table with force_baseline
+		int a = (kStdLumaQ[i] * 50 + 50) / 100, b = (kStdChromaQ[i] * 50 + 50) / 100;
+		ql[i] = (uint8_t)(a < 1 ? 1 : (a > 255 ? 255 : a)); qc[i] = (uint8_t)(b < 1 ? 1 : (b > 255 ? 255 : b));
+	}
+	EncTable dcL, dcC, acL, acC;
+	BuildEnc(kDcLumaBits, kDcVals, dcL); BuildEnc(kDcChromaBits, kDcVals, dcC); BuildEnc(kAcLumaBits, kAcLumaVals, acL); BuildEnc(kAcChromaBits, kAcChromaVals, acC);
+	auto marker = [&](uint8_t m, const std::vector<uint8_t>& body) { out.push_back(0xFF); out.push_back(m); const size_t n = body.size() + 2; out.push_back((uint8_t)(n >> 8)); out.push_back((uint8_t)n); out.insert(out.end(), body.begin(), body.end()); };
+	out.clear(); out.push_back(0xFF); out.push_back(0xD8);
+	marker(0xE0, { 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 });
+	for (int t = 0; t < 2; ++t) { std::vector<uint8_t> b; b.push_back((uint8_t)t); for (int i = 0; i < 64; ++i) b.push_back((t ? qc : ql)[kZigzag[i]]); marker(0xDB, b); }
+	marker(0xC0, { 8, (uint8_t)(h >> 8), (uint8_t)h, (uint8_t)(w >> 8), (uint8_t)w, 3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1 });
+	auto dht = [&](uint8_t id, const uint8_t* bits, const uint8_t* vals, int n) { std::vector<uint8_t> b; b.push_back(id); b.insert(b.end(), bits, bits + 16); b.insert(b.end(), vals, vals + n); marker(0xC4, b); };
+	dht(0x00, kDcLumaBits, kDcVals, 12); dht(0x10, kAcLumaBits, kAcLumaVals, 162); dht(0x01, kDcChromaBits, kDcVals, 12); dht(0x11, kAcChromaBits, kAcChromaVals, 162);
+	marker(0xDA, { 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0 });
+	BitWriter bw(out);
+	int predY = 0, predCb = 0, predCr = 0;
+	const uint32_t mw = (w + 15) / 16, mh = (h + 15) / 16;
+	for (uint32_t my = 0; my < mh; ++my) for (uint32_t mx = 0; mx < mw; ++mx) {
+		float Y[16][16], Cb[16][16], Cr[16][16];
+		for (int y = 0; y < 16; ++y) for (int x = 0; x < 16; ++x) {
+			const uint32_t sx = std::min(w - 1, mx * 16 + (uint32_t)x), sy = std::min(h - 1, my * 16 + (uint32_t)y);   // edge replication
+			const uint8_t* p = rgb + ((size_t)sy * w + sx) * 3;
+			const float r = p[0], g = p[1], b = p[2];
+			Y[y][x] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
+			Cb[y][x] = -0.168736f * r - 0.331264f * g + 0.5f * b;
+			Cr[y][x] = 0.5f * r - 0.418688f * g - 0.081312f * b;
+		}
+		float blk[64];
+		for (int by = 0; by < 2; ++by) for (int bx = 0; bx < 2; ++bx) {
+			for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) blk[8 * y + x] = Y[by * 8 + y][bx * 8 + x];
+			EncodeBlock(bw, blk, ql, dcL, acL, predY);
+		}
+		for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) blk[8 * y + x] = 0.25f * (Cb[2 * y][2 * x] + Cb[2 * y][2 * x + 1] + Cb[2 * y + 1][2 * x] + Cb[2 * y + 1][2 * x + 1]);
+		EncodeBlock(bw, blk, qc, dcC, acC, predCb);
+		for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) blk[8 * y + x] = 0.25f * (Cr[2 * y][2 * x] + Cr[2 * y][2 * x + 1] + Cr[2 * y + 1][2 * x] + Cr[2 * y + 1][2 * x + 1]);
+		EncodeBlock(bw, blk, qc, dcC, acC, predCr);
+	}
+	bw.flush();
+	out.push_back(0xFF); out.push_back(0xD9);
 	return true;
 }
 

@@ -97,3 +97,31 @@ def test_unsupported_image_is_refused(lib, workdir):
     path = os.path.join(str(workdir), "junk.jpg")
     open(path, "wb").write(b"\xff\xd8\xff\xe0 not a jpeg at all")
     assert not lib.Raylib_LoadImage(path.encode())
+
+
+def test_jpeg_writer_roundtrip(lib, workdir):
+    """Raylib_WriteImageToDisk(..., Jpg): the console front-end saves its results as .jpg (reference src/main.cc:480-510).
+    A lossy writer's bytes are not part of parity; the file must be a baseline JPEG that Pillow and the library's own
+    decoder read back to within the quantisation error of quality 75 / 4:2:0."""
+    for (w, h) in ((64, 48), (37, 29), (16, 16), (1, 1)):
+        src = np.asarray(_picture(max(w, 8), max(h, 8), seed=w + h), np.uint8)[:h, :w]
+        rgba = np.concatenate([src.astype(np.float32) / np.float32(255.0), np.ones((h, w, 1), np.float32)], -1)
+        rgba = np.ascontiguousarray(rgba)
+        img = lib.RaylibAMD_CreateImageFromData(w, h, rgba.ctypes.data_as(C.POINTER(C.c_float)))
+        path = os.path.join(str(workdir), "w_%d_%d.jpg" % (w, h))
+        assert lib.Raylib_WriteImageToDisk(img, path.encode(), 1) == 1
+        lib.Raylib_DestroyImage(img)
+        pil = Image.open(path)
+        assert pil.format == "JPEG" and pil.size == (w, h)
+        back = np.asarray(pil.convert("RGB"), np.float32)
+        mine = _load_through_abi(lib, path)[..., :3] * 255.0
+        # yardstick: libjpeg's own encoder at the same settings (quality 75, 4:2:0) on the same picture
+        bio = io.BytesIO(); Image.fromarray(src).save(bio, "JPEG", quality=75, subsampling=2)
+        ref = np.asarray(Image.open(io.BytesIO(bio.getvalue())).convert("RGB"), np.float32)
+        ref_mse = float(((ref - src.astype(np.float32)) ** 2).mean())
+        for got, slack in ((back, 1.1), (mine, 1.4)):     # the fast path (replicated chroma) reconstructs edges a little worse
+            mse = float(((got - src.astype(np.float32)) ** 2).mean())
+            assert mse <= slack * ref_mse + 2.0, (w, h, mse, ref_mse)
+        assert os.path.getsize(path) <= 1.25 * len(bio.getvalue()) + 64
+        fast = _turbo_fast_decode(open(path, "rb").read()).astype(np.float32)
+        assert np.array_equal(np.rint(mine), fast)       # the library's decoder on the library's file = libjpeg's fast path, bit for bit
