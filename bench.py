@@ -90,18 +90,24 @@ def main():
     distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    os.environ["RAYLIB_DEVICE"] = str(local_rank)
-
     import torch
     import torch.distributed as dist
     from raylib_amd import binding, scenes, tiling
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_SHARE_GPU=1 (test aid, 1-GPU box): several ranks on the one device, the gather staged through the host over gloo --
+    # RCCL refuses two ranks per device.  It exercises the N > 1 frame assembly, not its speed.
+    share = os.environ.get("BENCH_SHARE_GPU", "0") == "1"
+    device_index = local_rank % torch.cuda.device_count() if share else local_rank
+    os.environ["RAYLIB_DEVICE"] = str(device_index)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     lib = binding.load()
     if lib.Raylib_Initialize() != 1:
@@ -148,9 +154,18 @@ def main():
         if ok != 1:
             raise SystemExit("RaylibAMD_RenderDevice failed")
         if distributed:
-            pending[k] = dist.gather(out, gathered, dst=0, async_op=True)   # one RCCL gather per frame
+            if share:
+                host = out.cpu()
+                host_list = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, host_list, dst=0)
+                if rank == 0:
+                    for dst_t, src_t in zip(gathered, host_list):
+                        dst_t.copy_(src_t)
+            else:
+                pending[k] = dist.gather(out, gathered, dst=0, async_op=True)   # one RCCL gather per frame
             if rank == 0:
-                pending[k].wait()                             # stream-level: the assembly below is ordered after the gather
+                if pending[k] is not None:
+                    pending[k].wait()                         # stream-level: the assembly below is ordered after the gather
                 if world == 1:
                     frame.copy_(gathered[0][: h * w * 4].view(h * w, 4))   # one rank renders the row-major frame directly
                 else:
@@ -180,10 +195,11 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        red_dev = torch.device("cpu") if share else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(acc["rays"]), float(acc["samples"])], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(acc["rays"]), float(acc["samples"])], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
     else:
