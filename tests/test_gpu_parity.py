@@ -428,6 +428,13 @@ def test_pool_schedule_is_default_on_deep_bvh_and_bit_identical(mid_scene, gpu_l
         monkeypatch.setenv("RAYLIB_POOL_SHORT_STACK", mode)
         assert np.array_equal(bits(ses.render(96, 64, 8, max_path=6)), bits(base)), mode
     monkeypatch.delenv("RAYLIB_POOL_SHORT_STACK")
+    # sample batches (the sample buffer is summed in sample order whatever the batch size) and the BVH2 under the pool schedule
+    for env in (dict(RAYLIB_SAMPLE_BATCH="3"), dict(RAYLIB_BVH4="0"), dict(RAYLIB_BVH4="0", RAYLIB_SAMPLE_BATCH="1")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert np.array_equal(bits(ses.render(96, 64, 8, max_path=6)), bits(base)), env
+        for k in env:
+            monkeypatch.delenv(k)
     # windows recomputed by the CPU oracle with the same pixel keys
     flat = helpers.objflat.load_obj(obj, oracle, texture_loader=helpers.texture_loader, sun_illuminance=(20, 20, 20), sun_direction=(-1.0, -1.0, 0.0))
     scene = oracle.scene_create(flat, 1)
