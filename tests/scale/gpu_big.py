@@ -1,7 +1,7 @@
 """C3-sized scene (298k triangles, sun): parity windows vs the oracle + timing."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 from helpers import ffi, bits, scenes, objflat

@@ -2,7 +2,7 @@
 render (cells r::8) is timed too, and parity windows are checked against the oracle."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 from helpers import ffi, bits, scenes, objflat

@@ -1,7 +1,7 @@
 """GPU diagnostics: detailed parity metrics per case (prints, never asserts)."""
 import ctypes as C, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 from helpers import ffi, bits

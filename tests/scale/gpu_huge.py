@@ -1,7 +1,7 @@
 """Large scene (2.36 M triangles by default): build time, depth, render rate, parity windows vs the oracle."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 from helpers import ffi, bits, scenes, objflat

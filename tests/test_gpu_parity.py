@@ -455,7 +455,7 @@ def test_full_size_pool_schedule_bit_identical(full_size, monkeypatch):
 def test_configs2_size_scene_all_schedules_agree(gpu_lib, workdir, monkeypatch):
     """BASELINE configs[2]-size scene (298 k triangles, sun, 1080p; 2 spp to keep the suite short): the default schedule
     (pool, 19-entry LDS stack), the pool with the whole stack in LDS and the one-path-per-lane kernel give the same bits
-    and the same ray / shading counts.  (Windows of this scene against the CPU oracle: tools/gpu_big.py.)"""
+    and the same ray / shading counts.  (Windows of this scene against the CPU oracle: tests/scale/gpu_big.py.)"""
     from raylib_amd import binding
     d = os.path.join(str(workdir), "c2"); os.makedirs(d, exist_ok=True)
     obj, n = helpers.scenes.cornell(os.path.join(d, "c2.obj"), tess=137, displace_fraction=0.2)

@@ -1,0 +1,55 @@
+"""Schedule fuzz: random scenes / cameras / settings rendered under every schedule of the megakernel; all must give the same bits
+and the same ray and shading counts.  usage: python tools/gpu_fuzz.py [cases=60] [seed=1]   (run it under `timeout`)"""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "software-raytracing_amd"))
+from raylib_amd import binding, scenes
+lib = binding.load()
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+d = tempfile.mkdtemp()
+MODES = [dict(RAYLIB_POOL="0"), dict(), dict(RAYLIB_BVH4="0"), dict(RAYLIB_POOL_SHORT_STACK="0"), dict(RAYLIB_BVH4="0", RAYLIB_POOL_SHORT_STACK="4"),
+         dict(RAYLIB_POOL="3", RAYLIB_BVH4="0"), dict(RAYLIB_POOL="2", RAYLIB_SAMPLE_BATCH="1")]
+bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    kind = rng.randint(4)
+    if kind == 0:
+        obj, n = scenes.cornell(os.path.join(d, "f%d.obj" % case), tess=int(rng.randint(1, 20)), displace_fraction=float(rng.choice([0.0, 0.1, 0.3])),
+                                tall_material=str(rng.choice([scenes.MIRROR, scenes.GLASS, scenes.WHITE])), short_material=str(rng.choice([scenes.WHITE, scenes.GLASS])))
+    elif kind == 1:
+        obj, n = scenes.soup(os.path.join(d, "f%d.obj" % case), n_tris=int(rng.randint(10, 30000)), seed=int(rng.randint(1 << 30)), extent=float(rng.uniform(1, 5)), size=float(rng.uniform(0.05, 1.0)))
+    elif kind == 2:
+        obj, n = scenes.cutout(os.path.join(d, "f%d.obj" % case), tess=int(rng.randint(1, 12)))
+    else:
+        obj, n = scenes.colonnade(os.path.join(d, "f%d.obj" % case), tess=int(rng.randint(1, 4)))
+    sun = (0, 0, 0) if rng.rand() < 0.4 else tuple(float(x) for x in rng.uniform(1, 20, 3))
+    sun_dir = tuple(float(x) for x in rng.uniform(-1, 1, 3) * np.array([1, 1, 1]) + np.array([0, -1.2, 0]))
+    sky = scenes.sky_panorama() if rng.rand() < 0.4 else None
+    origin = tuple(float(x) for x in np.array([0, 1, 4]) + rng.uniform(-1.5, 1.5, 3))
+    w, h = int(rng.randint(9, 200)), int(rng.randint(9, 120))
+    spp, max_path = int(rng.choice([1, 2, 5, 8])), int(rng.choice([1, 2, 5, 9]))
+    aperture = 0.0 if rng.rand() < 0.6 else float(rng.uniform(0.01, 0.2))
+    ses = binding.SceneSession(lib, obj, origin, (0, 1, -1), float(rng.uniform(30, 80)), w / h, sun=sun, sun_dir=sun_dir, sky_image=sky,
+                               aperture=aperture, focal=4.0, shutter=(0.0, float(rng.choice([0.0, 1.0]))))
+    lib.RaylibAMD_SetSeed(int(rng.randint(1, 1 << 30)))
+    ref = None
+    for env in MODES:
+        for k, v in env.items(): os.environ[k] = v
+        img = ses.render(w, h, spp, max_path=max_path)
+        st = ses.stats().as_dict()
+        for k in env: del os.environ[k]
+        # cut-out scenes run the alpha test on traversal candidates, whose number depends on the order candidates are met in:
+        # their shading / texel counts are schedule-dependent, rays and samples are not
+        key = (st["rays"], st["cameraSamples"]) if kind == 2 else (st["rays"], st["shadedHits"], st["cameraSamples"], st["texFetches"])
+        if ref is None: ref = (img, key)
+        elif not (np.array_equal(bits(img), bits(ref[0])) and key == ref[1]):
+            bad += 1
+            print("MISMATCH case %d kind %d tris %d %dx%d spp %d len %d env %s: %d pixels differ, counts %s vs %s" % (
+                case, kind, n, w, h, spp, max_path, env, int((bits(img) != bits(ref[0])).any(-1).sum()), key, ref[1]), flush=True)
+    ses.close()
+    if case % 10 == 9: print("case %d done (%.0f s), mismatches so far %d" % (case + 1, time.time() - t0, bad), flush=True)
+lib.RaylibAMD_SetSeed(1)
+print("fuzz: %d cases x %d schedules, mismatches: %d" % (cases, len(MODES), bad))
+sys.exit(1 if bad else 0)
