@@ -1518,12 +1518,12 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 		}
 		WaveLdsSync();
 		// (2) hits are shaded 64 at a time by whichever lane: the expensive material code always runs with a full wave.
-		//     A remainder below 64 waits in its slots for the next trip's hits (unless nothing else is going on).
+		//     A remainder below 64 waits in its slots for the next trip's hits (until the job queue is empty).
 		//     The path registers come from the home lane by ds_bpermute and return through the slot's hit fields.
 		uint32_t shadedEnd = 0;
 		for (;;) {
 			if (shadedEnd >= nHit) break;
-			if (nHit - shadedEnd < 64u && !(exhausted && nQuery == 0)) break;
+			if (nHit - shadedEnd < 64u && !exhausted) break;   // once the job queue is empty no refill will top the list up: waiting only stretches the tail
 #ifdef RL_POOL_WATCHDOG
 			if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); wdAbort = true; break; }
 #endif
@@ -2102,9 +2102,12 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		hipLaunchKernelGGL((k_aov<STACK, PRIMS>), dim3(blocks), dim3(RL_BLOCK), 0, R.stream, P, D->view, out, R.counters);
 		HIP_OK(hipGetLastError());
 	} else {
-		// sample batches: bound the sample buffer to ~2 GiB
+		// sample batches: one launch per <= 16 GiB of sample buffer (288 GB of HBM: few, large launches -- every launch pays its
+		// ramp-up and its tail once; measured on the 298 k-triangle scene at 128 spp: 1 launch 61.3 ms, 2 launches 68.9, 4 launches 90.1)
 		const size_t perSample = (size_t)numSlots * sizeof(float4);
-		uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(SPP, ((size_t)2 << 30) / perSample));
+		size_t capBytes = (size_t)16 << 30;
+		if (const char* e = getenv("RAYLIB_SAMPLE_BUFFER_GIB")) { const int v = atoi(e); if (v > 0) capBytes = (size_t)v << 30; }
+		uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(SPP, capBytes / perSample));
 		if (const char* e = getenv("RAYLIB_SAMPLE_BATCH")) { int v = atoi(e); if (v > 0) batch = std::min<uint32_t>((uint32_t)v, SPP); }
 		if (!Grow(R.samples, R.samplesBytes, perSample * batch)) return false;
 		if (batch < SPP && !Grow(R.accum, R.accumBytes, perSample)) return false;
