@@ -1037,6 +1037,9 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #ifndef RL_POOL_MAXBLOCKS
 #define RL_POOL_MAXBLOCKS 4   /* workgroups per CU the pool kernel is compiled for (register budget 512 / (4 * blocks) per lane) */
 #endif
+#ifndef RL_POOL_CUT_EXH
+#define RL_POOL_CUT_EXH 40   /* the same once the job queue is empty */
+#endif
 #ifndef RL_POOL_CUT
 #define RL_POOL_CUT 40    /* with the pool handed out: shade once no more than this many lanes still traverse */
 #endif
@@ -1446,7 +1449,8 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 					continue;
 				}
 				// all queries handed out and only a few long rays left: shade what is there, the stragglers go on next trip
-				if (nextSlot >= (uint32_t)PP && nBusy <= RL_POOL_CUT && finished > 0) break;
+				const int cutAt = exhausted ? RL_POOL_CUT_EXH : RL_POOL_CUT;
+				if (nextSlot >= (uint32_t)PP && nBusy <= cutAt && finished > 0) break;
 				// one step for the larger (cost-weighted) party, lanes at inner nodes or lanes at leaves, until enough lanes
 				// have finished to make a fetch worth it
 				int nb;
@@ -1471,7 +1475,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 					const unsigned long long bm = __ballot(busy);
 					nb = (int)__popcll(bm);
 					finished += (uint32_t)__popcll(__ballot(fin));
-				} while (nb > (nextSlot < (uint32_t)PP ? RL_POOL_KEEP : (finished > 0 ? RL_POOL_CUT : 0)));
+				} while (nb > (nextSlot < (uint32_t)PP ? RL_POOL_KEEP : (finished > 0 ? cutAt : 0)));
 			}
 			WaveLdsSync();
 		}
