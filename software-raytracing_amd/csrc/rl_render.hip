@@ -201,7 +201,7 @@ __device__ __noinline__ int AlphaTestCandidateNI(const DTriShade* shade, const D
 	if (M->type != MAT_MICROFACET || M->tex[0] < 0) return 1;
 	float U = (1 - a - b) * s0 + a * s1 + b * s2;
 	float V = (1 - a - b) * t0 + a * t1 + b * t2;
-	float4 px = TexFetch(textures, texels, M->tex[0], true, U, V);
+	float4 px = TexFetch(textures, texels, M->tex[0], false, U, V);   // tex[0] points at the pow(2.2) copy made at upload
 	return (px.w >= 0.5f ? 1 : 0) | 2;
 }
 __device__ __forceinline__ bool AlphaTestCandidate(const DSceneView& S, int tri, float a, float b, Counters& c)
@@ -586,7 +586,7 @@ __device__ __forceinline__ V3 GetAlbedo(const DSceneView& S, const Mat& m, float
 	if (m.type == MAT_LAMBERTIAN || m.type == MAT_METAL) return m.albedo;
 	if (m.type == MAT_MICROFACET) {
 		V3 albedo = m.albedo;
-		if (m.tex0 >= 0) { float4 px = TexSample(S, m.tex0, true, U, V, c); albedo = v3(px.x, px.y, px.z) * px.w; }
+		if (m.tex0 >= 0) { float4 px = TexSample(S, m.tex0, false, U, V, c); albedo = v3(px.x, px.y, px.z) * px.w; }   // tex0: the pow(2.2) copy made at upload
 		return albedo;
 	}
 	return v3s(0.0f);
@@ -2001,6 +2001,34 @@ bool UploadScene(Scene& sc)
 		const Image& im = *sc.textures[i];
 		texs[i].offset = (uint32_t)(pool.size() / 4); texs[i].width = (int32_t)im.width; texs[i].height = (int32_t)im.height; texs[i].pad = 0;
 		pool.insert(pool.end(), im.rgba.begin(), im.rgba.end());
+	}
+	// Albedo maps are read through Texture2D::Sample(bSRGB = true): nearest texel, then pow(texel, 2.2) on all four channels
+	// (reference render/texture.cc:44-50, material.cc:383,400) -- four powf per shading event and per alpha-tested candidate.
+	// The power of a texel does not depend on the ray: every texture some material uses as albedo gets a converted copy here
+	// (host powf = the reference's own function, the one csrc/rl_glibc_math.h restates), and the material points at the copy.
+	{
+		std::vector<int32_t> converted(texs.size(), -1);
+		for (DMaterial& m : mats) {
+			if (m.type != MAT_MICROFACET || m.tex[0] < 0 || (size_t)m.tex[0] >= converted.size()) continue;
+			const size_t src = (size_t)m.tex[0];
+			if (converted[src] < 0) {
+				DTexture t = texs[src];
+				const size_t count = (size_t)t.width * t.height * 4, from = (size_t)t.offset * 4;
+				t.offset = (uint32_t)(pool.size() / 4);
+				pool.resize(pool.size() + count);
+				float* dst = pool.data() + (size_t)t.offset * 4; const float* in = pool.data() + from;
+				unsigned threads = count >= (1u << 20) ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+				std::vector<std::thread> workers;
+				const size_t per = (count + threads - 1) / threads;
+				auto run = [dst, in](size_t a, size_t b) { for (size_t i = a; i < b; ++i) dst[i] = powf(in[i], 2.2f); };
+				for (unsigned w = 1; w < threads; ++w) { const size_t a = std::min(count, w * per), b = std::min(count, (w + 1) * per); if (a < b) workers.emplace_back(run, a, b); }
+				run(0, std::min(count, per));
+				for (std::thread& th : workers) th.join();
+				converted[src] = (int32_t)texs.size();
+				texs.push_back(t);
+			}
+			m.tex[0] = converted[src];
+		}
 	}
 	if (!Upload(D->nodes, sc.bvh.nodes.data(), sc.bvh.nodes.size())) return false;
 	if (!sc.bvh.nodes4.empty()) { if (!Upload(D->nodes4, sc.bvh.nodes4.data(), sc.bvh.nodes4.size())) return false; D->stackNeed4 = sc.bvh.stackNeed4; }
