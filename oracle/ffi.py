@@ -71,7 +71,7 @@ class FlatSceneDesc(C.Structure):
 
 class OracleCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("cameraSamples", C.c_uint64),
-                ("closestHitTies", C.c_uint64)]
+                ("closestHitTies", C.c_uint64), ("hitsOutsideOwnBox", C.c_uint64)]
 
 
 def make_camera(origin, look_at, fov_y, aspect, aperture=0.0, focal=1.0, t0=0.0, t1=0.0):
@@ -198,7 +198,7 @@ class Checker:
         c = OracleCounters()
         self.lib.oracle_get_counters(scene, C.byref(c))
         return {"rays": c.rays, "nodes_visited": c.nodesVisited, "tris_tested": c.trisTested, "camera_samples": c.cameraSamples,
-                "closest_hit_ties": c.closestHitTies}
+                "closest_hit_ties": c.closestHitTies, "hits_outside_own_box": c.hitsOutsideOwnBox}
 
     # -- known-answer helpers --------------------------------------------------
     def closest_hit(self, scene, rays, tmin=1e-4):

@@ -19,6 +19,7 @@ typedef struct OracleCounters {
 	uint64_t trisTested;    /* Triangle::Hit calls (reference triangle.cc:18) */
 	uint64_t cameraSamples;
 	uint64_t closestHitTies; /* BVH nodes where both subtrees returned a hit at exactly the same t (answer depends on the tree shape) */
+	uint64_t hitsOutsideOwnBox; /* triangle hits accepted although the ray fails the box test of the triangle's own AABB (reachability depends on the tree) */
 } OracleCounters;
 
 void*   oracle_scene_create(const FlatSceneDesc* desc, uint64_t buildSeed);

@@ -44,8 +44,8 @@ static_assert(sizeof(DNode4) == 128, "DNode4");
 struct alignas(64) DTriIsect {
 	float v0[3];
 	float n[3];      // unit geometric normal, normalize(cross(v1-v0, v2-v0)) (geom/triangle.h:34-38)
-	float u[3];
-	float v[3];
+	float v1[3];     // the other two vertices: the edges u = v1 - v0, v = v2 - v0 are formed on the device (the reference's own
+	float v2[3];     // subtraction), and the exact AABB of the three vertices is what the candidate rule tests the ray against
 	float uv, uu, vv, denom;
 };
 static_assert(sizeof(DTriIsect) == 64, "DTriIsect");

@@ -165,14 +165,15 @@ __device__ __forceinline__ Mat LoadMat(const DSceneView& S, int i)
 // Closest hit on the flat BVH2.
 struct HitRec { float t, a, b; int tri; };   // tri: triangle slot, or (kind << 28) | index for sphere (1) / cube (2, with the face in a)
 
-struct Tri { V3 v0, n, u, v; float uv, uu, vv, denom; };
+struct Tri { V3 v0, n, v1, v2, u, v; float uv, uu, vv, denom; };
 __device__ __forceinline__ Tri LoadTri(const DSceneView& S, int i)
 {
 	const float4* p = (const float4*)(S.isect + i);
 	float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
 	Tri t;
 	t.v0 = v3(q0.x, q0.y, q0.z); t.n = v3(q0.w, q1.x, q1.y);
-	t.u = v3(q1.z, q1.w, q2.x); t.v = v3(q2.y, q2.z, q2.w);
+	t.v1 = v3(q1.z, q1.w, q2.x); t.v2 = v3(q2.y, q2.z, q2.w);
+	t.u = t.v1 - t.v0; t.v = t.v2 - t.v0;   // geom/triangle.cc:30-31
 	t.uv = q3.x; t.uu = q3.y; t.vv = q3.z; t.denom = q3.w;
 	return t;
 }
@@ -212,11 +213,39 @@ __device__ __forceinline__ bool AlphaTestCandidate(const DSceneView& S, int tri,
 	return (r & 1) != 0;
 }
 
+// Relative slack of every box test of a traversal (and of the candidate rule below): far above float rounding of the slab
+// arithmetic (a few ulp), far below anything visible.
+#define RL_BOX_WIDEN 1.00001f
+#define RL_CANDIDATE_SLACK 1.000009f   /* a little less than the boxes' slack: the pool schedule's v_rcp_f32 reciprocals may move a box entry by an ulp */
+
+// A candidate that passed the triangle test counts only if the ray also passes the reference's own box test
+// (geom/aabb.h:39-54, unwidened, t_max = FLT_MAX) on the triangle's exact AABB.  Why: the barycentric test accepts points a few
+// ulp -- on slivers far more -- outside the triangle, i.e. outside every box around it; whether such a candidate is ever REACHED then
+// depends on which boxes a traversal happens to test (BVH2 or BVH4, widened by 3 or 6 ulp, the reference's random tree).  With
+// this rule the set of accepted hits is a property of the ray and the triangle alone: every schedule and tree width returns the
+// same hit, and since every box of the reference's tree contains this AABB (and rounding is monotone) the reference accepts
+// whatever is accepted here.  (What it accepts beyond that -- a hit outside the triangle's own box but inside its random
+// parent's -- is tree-dependent on its side; the oracle counts those events so that tests can tell them from real mismatches.)
+__device__ __forceinline__ bool OwnBoxPass(V3 a, V3 b, V3 c, V3 o, V3 inv /* exact 1/d */, float tMin, float t)
+{
+	const V3 mn = v3(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
+	const V3 mx = v3(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
+	float lo = tMin, hi = FLT_MAX;
+	{ float t0 = (mn.x - o.x) * inv.x, t1 = (mx.x - o.x) * inv.x; if (inv.x < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = t0 > lo ? t0 : lo; hi = t1 < hi ? t1 : hi; }
+	bool ok = !(hi < lo);
+	{ float t0 = (mn.y - o.y) * inv.y, t1 = (mx.y - o.y) * inv.y; if (inv.y < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = t0 > lo ? t0 : lo; hi = t1 < hi ? t1 : hi; }
+	ok = ok && !(hi < lo);
+	{ float t0 = (mn.z - o.z) * inv.z, t1 = (mx.z - o.z) * inv.z; if (inv.z < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = t0 > lo ? t0 : lo; hi = t1 < hi ? t1 : hi; }
+	// ... and the candidate's t must not lie before the ray enters that box (by more than the slack the box tests are
+	// widened by): then "this box starts beyond the best hit so far" implies "nothing in it is closer", whatever the order
+	return ok && !(hi < lo) && t * RL_CANDIDATE_SLACK >= lo;
+}
+
 // Slab test of one child box against [tMin, tMax] (reference geom/aabb.h:39-54:
 // same products (bound - o) * invD, same "swap if invD < 0", NaN keeps the old
 // bound).  tMax is widened by 2 ulp so the test stays conservative.
 __device__ __forceinline__ bool Slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                     V3 o, V3 inv, bool nx, bool ny, bool nz, float tMin, float tMax, float& tNear, const float widen = 1.0000004f)
+                                     V3 o, V3 inv, bool nx, bool ny, bool nz, float tMin, float tMax, float& tNear, const float widen = RL_BOX_WIDEN)
 {
 	float tn = tMin, tf = tMax;
 	float a0 = ((nx ? mxx : mnx) - o.x) * inv.x, a1 = ((nx ? mnx : mxx) - o.x) * inv.x;
@@ -370,7 +399,7 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 					const float wv = dot(w, T.v), wu = dot(w, T.u);
 					const float pa = (T.uv * wv - T.vv * wu) / T.denom;
 					const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-					if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
+					if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, inv, tMin, t)) {
 						if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 						best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 						if (ANYHIT) return true;
@@ -420,7 +449,7 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 				tn = fmaxf(tn, (nX.k - o.x) * inv.x); tf = fminf(tf, (fX.k - o.x) * inv.x); \
 				tn = fmaxf(tn, (nY.k - o.y) * inv.y); tf = fminf(tf, (fY.k - o.y) * inv.y); \
 				tn = fmaxf(tn, (nZ.k - o.z) * inv.z); tf = fminf(tf, (fZ.k - o.z) * inv.z); \
-				tk = (tf * 1.0000004f < tn) ? INFINITY : tn; }
+				tk = (tf * RL_BOX_WIDEN < tn) ? INFINITY : tn; }
 			RL_SLAB4B(x, t0) RL_SLAB4B(y, t1) RL_SLAB4B(z, t2) RL_SLAB4B(w, t3)
 			#undef RL_SLAB4B
 			int r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
@@ -453,7 +482,7 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 				const float wv = dot(w, T.v), wu = dot(w, T.u);
 				const float pa = (T.uv * wv - T.vv * wu) / T.denom;
 				const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
+				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, inv, tMin, t)) {
 					if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 					best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 					if (ANYHIT) return true;
@@ -1108,7 +1137,7 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #define Q_PENDING_SHADOW (-6)
 #define Q_MISS     (-7)   /* result of a closest-hit query that hit nothing (distinct from Q_CLOSEST: a straggler may deliver it while the next phase is handing out slots) */
 #define Q_CLEAR    (-8)   /* result of a sun query: nothing in the way */
-#define RL_POOL_WIDEN 1.0000007f   /* slab test with v_rcp_f32 reciprocals: 6 ulp instead of Slab()'s 3 */
+#define RL_POOL_WIDEN RL_BOX_WIDEN
 #define RL_POOL_SHORT_LSTACK 19   /* LDS entries of the "short" 32-deep stack: 19 KiB + 20.5 KiB pool = 4 workgroups per CU */
 #define RL_POOL_SHORT_MAXDEPTH 24 /* BVH depth up to which the short variant is used (deeper trees overflow too often: measured) */
 #ifndef RL_POOL_MAXBLOCKS
@@ -1250,7 +1279,7 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 			const float wv = dot(w, TT.v), wu = dot(w, TT.u);
 			const float pa = (TT.uv * wv - TT.vv * wu) / TT.denom;
 			const float pb = (TT.uv * wu - TT.uu * wv) / TT.denom;
-			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f) {
+			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(TT.v0, TT.v1, TT.v2, o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tMin, t)) {
 				if (!alpha || AlphaTestCandidate(S, i, pa, pb, c)) {
 					T.best.t = t; T.best.a = pa; T.best.b = pb; T.best.tri = i;
 					if (T.anyhit) return true;
@@ -2044,8 +2073,8 @@ bool UploadScene(Scene& sc)
 		const float uvuv = uv * uv, uuvv = uu * vv;                  // :39-40
 		I.v0[0] = t.v0.x; I.v0[1] = t.v0.y; I.v0[2] = t.v0.z;
 		I.n[0] = nrm.x; I.n[1] = nrm.y; I.n[2] = nrm.z;
-		I.u[0] = u.x; I.u[1] = u.y; I.u[2] = u.z;
-		I.v[0] = v.x; I.v[1] = v.y; I.v[2] = v.z;
+		I.v1[0] = t.v1.x; I.v1[1] = t.v1.y; I.v1[2] = t.v1.z;
+		I.v2[0] = t.v2.x; I.v2[1] = t.v2.y; I.v2[2] = t.v2.z;
 		I.uv = uv; I.uu = uu; I.vv = vv; I.denom = uvuv - uuvv;
 		DTriShade& Sh = shade[k];
 		Sh.n0[0] = t.n0.x; Sh.n0[1] = t.n0.y; Sh.n0[2] = t.n0.z;

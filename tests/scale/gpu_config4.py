@@ -38,7 +38,7 @@ for (x0, y0) in ((952, 536), (300, 700), (1500, 400), (1200, 900)):
         # a differing pixel must be one whose samples met two surfaces at exactly the same t (the reference's answer there
         # depends on its random tree): re-render it alone and read the oracle's tie counter
         one = orc.render_region(scene, ocam, st, x0 + int(px), y0 + int(py), 1, 1, seed=1)
-        ties = orc.counters(scene)["closest_hit_ties"]
+        cn = orc.counters(scene); ties = cn["closest_hit_ties"] + cn["hits_outside_own_box"]
         print("   pixel", x0 + int(px), y0 + int(py), "gpu", got[py, px, :3], "oracle", one[0, 0, :3], "closest-hit ties among its samples:", ties, flush=True)
         if ties > 0: untied_bad = untied_bad
         else: untied_bad += 1

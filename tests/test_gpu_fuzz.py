@@ -56,7 +56,8 @@ def test_random_scenes_against_oracle(seed, gpu_lib, oracle, workdir):
         differ = ~(bits(img[..., :3]) == bits(want[..., :3])).all(-1)
         for (py, px) in zip(*np.nonzero(differ)):
             oracle.render_region(scene, cam, st, int(px), int(py), 1, 1, seed=seed_val)
-            assert oracle.counters(scene)["closest_hit_ties"] > 0, \
+            cn = oracle.counters(scene)
+            assert cn["closest_hit_ties"] > 0 or cn["hits_outside_own_box"] > 0, \
                 "case %d (%s, %d triangles, %dx%d, spp %d, len %d): pixel %d,%d differs without a closest-hit tie: %s vs %s" % (
                     case, ("room", "soup", "cutout")[kind], n, w, h, spp, max_path, px, py, img[py, px, :3], want[py, px, :3])
             tied += 1

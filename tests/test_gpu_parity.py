@@ -70,7 +70,8 @@ def window_mismatches_without_a_tie(oracle, scene, cam, st, img, x0, y0, size):
     tied = untied = 0
     for (py, px) in zip(*np.nonzero(~e)):
         oracle.render_region(scene, cam, st, x0 + int(px), y0 + int(py), 1, 1, seed=1)
-        if oracle.counters(scene)["closest_hit_ties"] > 0:
+        cn = oracle.counters(scene)
+        if cn["closest_hit_ties"] > 0 or cn["hits_outside_own_box"] > 0:
             tied += 1
         else:
             untied += 1

@@ -12,18 +12,19 @@ MODES = [dict(RAYLIB_POOL="0"), dict(), dict(RAYLIB_BVH4="0"), dict(RAYLIB_POOL_
          dict(RAYLIB_POOL="3", RAYLIB_BVH4="0"), dict(RAYLIB_POOL="2", RAYLIB_SAMPLE_BATCH="1")]
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 bad = 0
+only = int(os.environ.get("FUZZ_ONLY", "-1"))
 t0 = time.time()
 for case in range(cases):
     kind = rng.randint(4)
     if kind == 0:
-        obj, n = scenes.cornell(os.path.join(d, "f%d.obj" % case), tess=int(rng.randint(1, 20)), displace_fraction=float(rng.choice([0.0, 0.1, 0.3])),
-                                tall_material=str(rng.choice([scenes.MIRROR, scenes.GLASS, scenes.WHITE])), short_material=str(rng.choice([scenes.WHITE, scenes.GLASS])))
+        gen = (scenes.cornell, dict(tess=int(rng.randint(1, 20)), displace_fraction=float(rng.choice([0.0, 0.1, 0.3])),
+                                    tall_material=str(rng.choice([scenes.MIRROR, scenes.GLASS, scenes.WHITE])), short_material=str(rng.choice([scenes.WHITE, scenes.GLASS]))))
     elif kind == 1:
-        obj, n = scenes.soup(os.path.join(d, "f%d.obj" % case), n_tris=int(rng.randint(10, 30000)), seed=int(rng.randint(1 << 30)), extent=float(rng.uniform(1, 5)), size=float(rng.uniform(0.05, 1.0)))
+        gen = (scenes.soup, dict(n_tris=int(rng.randint(10, 30000)), seed=int(rng.randint(1 << 30)), extent=float(rng.uniform(1, 5)), size=float(rng.uniform(0.05, 1.0))))
     elif kind == 2:
-        obj, n = scenes.cutout(os.path.join(d, "f%d.obj" % case), tess=int(rng.randint(1, 12)))
+        gen = (scenes.cutout, dict(tess=int(rng.randint(1, 12))))
     else:
-        obj, n = scenes.colonnade(os.path.join(d, "f%d.obj" % case), tess=int(rng.randint(1, 4)))
+        gen = (scenes.colonnade, dict(tess=int(rng.randint(1, 4))))
     sun = (0, 0, 0) if rng.rand() < 0.4 else tuple(float(x) for x in rng.uniform(1, 20, 3))
     sun_dir = tuple(float(x) for x in rng.uniform(-1, 1, 3) * np.array([1, 1, 1]) + np.array([0, -1.2, 0]))
     sky = scenes.sky_panorama() if rng.rand() < 0.4 else None
@@ -31,9 +32,12 @@ for case in range(cases):
     w, h = int(rng.randint(9, 200)), int(rng.randint(9, 120))
     spp, max_path = int(rng.choice([1, 2, 5, 8])), int(rng.choice([1, 2, 5, 9]))
     aperture = 0.0 if rng.rand() < 0.6 else float(rng.uniform(0.01, 0.2))
+    seed_val = int(rng.randint(1, 1 << 30))
+    if only >= 0 and case != only: continue
+    obj, n = gen[0](os.path.join(d, "f%d.obj" % case), **gen[1])
     ses = binding.SceneSession(lib, obj, origin, (0, 1, -1), float(rng.uniform(30, 80)), w / h, sun=sun, sun_dir=sun_dir, sky_image=sky,
                                aperture=aperture, focal=4.0, shutter=(0.0, float(rng.choice([0.0, 1.0]))))
-    lib.RaylibAMD_SetSeed(int(rng.randint(1, 1 << 30)))
+    lib.RaylibAMD_SetSeed(seed_val)
     ref = None
     for env in MODES:
         for k, v in env.items(): os.environ[k] = v
@@ -46,8 +50,11 @@ for case in range(cases):
         if ref is None: ref = (img, key)
         elif not (np.array_equal(bits(img), bits(ref[0])) and key == ref[1]):
             bad += 1
-            print("MISMATCH case %d kind %d tris %d %dx%d spp %d len %d env %s: %d pixels differ, counts %s vs %s" % (
-                case, kind, n, w, h, spp, max_path, env, int((bits(img) != bits(ref[0])).any(-1).sum()), key, ref[1]), flush=True)
+            dpx = np.argwhere((bits(img) != bits(ref[0])).any(-1))
+            print("MISMATCH case %d kind %d tris %d %dx%d spp %d len %d env %s: %d pixels differ %s, counts %s vs %s" % (
+                case, kind, n, w, h, spp, max_path, env, len(dpx), dpx[:3].tolist(), key, ref[1]), flush=True)
+            if True:
+                for (py, px) in dpx[:1]: print("   pixel", px, py, img[py, px, :3], "vs", ref[0][py, px, :3], "case params", gen[1], origin, sun, sun_dir, aperture, flush=True)
     ses.close()
     if case % 10 == 9: print("case %d done (%.0f s), mismatches so far %d" % (case + 1, time.time() - t0, bad), flush=True)
 lib.RaylibAMD_SetSeed(1)
