@@ -497,3 +497,22 @@ def test_bench_multi_rank_frame_assembly_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["frame_check"] == "assembled frame bit-identical to a one-GPU render"
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_bench_rccl_gather_path_with_one_rank():
+    """bench.py launched the way the driver launches N > 1 (torch.distributed.run, backend nccl = RCCL), with the one rank a 1-GPU box
+    allows: process group on the device, asynchronous gather on RCCL's stream, assembly on rank 0, frame check.  The ranks' device
+    selection, double-buffered send and stream ordering are the ones the multi-GPU run uses; only the peer count differs."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RAYLIB_POOL", "RAYLIB_LIB", "BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29534",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["frame_check"] == "assembled frame bit-identical to a one-GPU render"
