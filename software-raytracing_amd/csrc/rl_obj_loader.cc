@@ -20,7 +20,15 @@
 #include <chrono>
 #include <stdint.h>
 #include <string.h>
+#include <limits.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <algorithm>
+#include <atomic>
 #include <map>
+#include <memory>
+#include <thread>
 
 namespace rl {
 namespace {
@@ -172,26 +180,138 @@ float ParseFloat(const char* b, const char* e)
 	return neg ? -v : v;
 }
 
-struct Corner { int v, vt, vn; };
+// One "v/vt/vn" token as written: raw 1-based / negative-relative indices, kAbsent where a component is missing or
+// unreadable.  Resolution against the element counts at the face's line happens after the chunks' prefix counts are known.
+constexpr int kAbsent = INT_MIN;
+struct RawCorner { int v, vt, vn; };
 
-bool ParseCorner(const char* p, int nV, int nVT, int nVN, Corner& c)
+bool ParseRawCorner(const char* p, RawCorner& c)
 {
-	c.v = c.vt = c.vn = -1;
+	c.v = c.vt = c.vn = kAbsent;
 	char* end;
 	long a = strtol(p, &end, 10);
 	if (end == p) return false;
-	c.v = a > 0 ? (int)a - 1 : nV + (int)a;
+	c.v = (int)a;
 	if (*end == '/') {
 		p = end + 1;
-		if (*p != '/') { long b = strtol(p, &end, 10); if (end != p) c.vt = b > 0 ? (int)b - 1 : nVT + (int)b; }
+		if (*p != '/') { long b = strtol(p, &end, 10); if (end != p) c.vt = (int)b; }
 		else end = (char*)p;
 		if (*end == '/') {
 			p = end + 1;
 			long d = strtol(p, &end, 10);
-			if (end != p) c.vn = d > 0 ? (int)d - 1 : nVN + (int)d;
+			if (end != p) c.vn = (int)d;
 		}
 	}
-	return c.v >= 0 && c.v < nV;
+	return true;
+}
+
+inline int ResolveIndex(int raw, int count) { return raw == kAbsent ? -1 : (raw > 0 ? raw - 1 : count + raw); }
+
+// What one thread extracts from its run of lines.  Everything that depends on the lines before the chunk (element counts for
+// relative indices and the "defined before use" check, the material in force, the shape number) is stored relative to the chunk
+// start and resolved once the chunks' prefix sums are known.
+struct Poly {
+	uint32_t firstCorner, numCorners;   // numCorners == 0: the line held a corner the reader could not parse -> dropped
+	int nV, nVT, nVN;                   // elements defined in this chunk before the line
+	int usemtlSeen;                     // usemtl lines in this chunk before the line (0: the material carried into the chunk)
+	int shapeSeen;                      // o / g lines in this chunk before the line
+};
+struct MtlEvent { bool isLib; bool hasName; std::vector<std::string> names; };
+struct Chunk {
+	const char* begin; const char* end;
+	std::vector<float> V, VT, VN;
+	std::vector<Poly> polys;
+	std::vector<RawCorner> corners;
+	std::vector<MtlEvent> events;       // usemtl / mtllib lines in file order
+	int usemtlCount = 0, shapeCount = 0;
+	// filled by the serial resolution pass
+	size_t baseV = 0, baseVT = 0, baseVN = 0;
+	int baseShape = 0, materialIn = -1;
+	std::vector<int> usemtlMaterial;    // material id after the k-th usemtl line of the chunk
+	size_t triBase = 0, numTris = 0;
+	int invalidTexcoords = 0;
+};
+
+inline bool IsSpace(char ch) { return ch == ' ' || ch == '\t' || ch == '\r'; }
+// next token of the current line: [b, e); false at end of line / comment / end of the chunk
+inline bool NextToken(const char*& p, const char* end, const char*& b, const char*& e)
+{
+	while (p < end && IsSpace(*p)) ++p;
+	if (p >= end || *p == '\n' || *p == '#') return false;
+	b = p;
+	while (p < end && *p != '\n' && !IsSpace(*p)) ++p;
+	e = p;
+	return true;
+}
+inline bool Is(const char* b, const char* e, const char* word) { const size_t n = strlen(word); return (size_t)(e - b) == n && memcmp(b, word, n) == 0; }
+
+// Token rules: whitespace separated, a token starting with '#' ends the line, numbers by strtof / strtol at the token start.
+// The buffer is NUL-terminated after the last chunk and every chunk ends after a '\n' (or at the NUL), so strtol / strtof
+// stop inside the chunk's last line.
+void ParseChunk(Chunk& c)
+{
+	const char* p = c.begin;
+	const char* const end = c.end;
+	auto number = [&](float dflt) -> float {
+		const char* b; const char* e;
+		if (!NextToken(p, end, b, e)) return dflt;
+		return ParseFloat(b, e);
+	};
+	while (p < end) {
+		const char* b; const char* e;
+		if (NextToken(p, end, b, e)) {
+			if (Is(b, e, "v")) { const float x = number(0.0f), y = number(0.0f), z = number(0.0f); c.V.push_back(x); c.V.push_back(y); c.V.push_back(z); }
+			else if (Is(b, e, "vt")) { const float u = number(0.0f), v = number(0.0f); c.VT.push_back(u); c.VT.push_back(v); }
+			else if (Is(b, e, "vn")) { const float x = number(0.0f), y = number(0.0f), z = number(0.0f); c.VN.push_back(x); c.VN.push_back(y); c.VN.push_back(z); }
+			else if (Is(b, e, "o") || Is(b, e, "g")) ++c.shapeCount;
+			else if (Is(b, e, "usemtl")) {
+				MtlEvent ev; ev.isLib = false;
+				const char* nb; const char* ne;
+				ev.hasName = NextToken(p, end, nb, ne);
+				if (ev.hasName) ev.names.emplace_back(nb, ne);
+				c.events.push_back(std::move(ev));
+				++c.usemtlCount;
+			}
+			else if (Is(b, e, "mtllib")) {
+				MtlEvent ev; ev.isLib = true; ev.hasName = false;
+				const char* nb; const char* ne;
+				while (NextToken(p, end, nb, ne)) ev.names.emplace_back(nb, ne);
+				c.events.push_back(std::move(ev));
+			}
+			else if (Is(b, e, "f")) {
+				Poly poly;
+				poly.firstCorner = (uint32_t)c.corners.size(); poly.numCorners = 0;
+				poly.nV = (int)(c.V.size() / 3); poly.nVT = (int)(c.VT.size() / 2); poly.nVN = (int)(c.VN.size() / 3);
+				poly.usemtlSeen = c.usemtlCount; poly.shapeSeen = c.shapeCount;
+				bool ok = true;
+				const char* cb; const char* ce;
+				while (NextToken(p, end, cb, ce)) {
+					RawCorner rc;
+					if (!ParseRawCorner(cb, rc)) { ok = false; break; }
+					c.corners.push_back(rc);
+				}
+				if (ok) poly.numCorners = (uint32_t)(c.corners.size() - poly.firstCorner);
+				else c.corners.resize(poly.firstCorner);
+				if (poly.numCorners >= 3) c.polys.push_back(poly);
+				else c.corners.resize(poly.firstCorner);
+			}
+		}
+		while (p < end && *p != '\n') ++p;   // rest of the line
+		if (p < end) ++p;
+	}
+}
+
+// fn(i) for i in [0, n) on up to `threads` threads, items handed out one at a time
+template <class F> void ForEachParallel(size_t n, unsigned threads, F fn)
+{
+	if (threads <= 1 || n <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+	std::atomic<size_t> next(0);
+	auto worker = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= n) return; fn(i); } };
+	std::vector<std::thread> pool;
+	const unsigned extra = (unsigned)std::min<size_t>(threads, n) - 1u;
+	for (unsigned t = 0; t < extra; ++t) pool.emplace_back(worker);
+	worker();
+	for (auto& t : pool) t.join();
 }
 
 } // namespace
@@ -205,103 +325,119 @@ bool LoadOBJ(const char* path, OBJModel& out)
 	// OBJ is 2.7 GB of text; the string-per-token parser spent 3x the BVH build's time here).  Token rules as before:
 	// whitespace separated, a token starting with '#' ends the line, numbers by strtof / strtol at the token start.
 	const auto tl0 = std::chrono::steady_clock::now();
-	std::vector<char> text;
+	// threads: RAYLIB_BUILD_THREADS, else the host's (at most 32)
+	unsigned threads = std::thread::hardware_concurrency();
+	if (const char* e = getenv("RAYLIB_BUILD_THREADS")) { int v = atoi(e); if (v > 0) threads = (unsigned)v; }
+	threads = std::max(1u, std::min(32u, threads));
+	std::unique_ptr<char[]> text;
+	size_t textSize = 0;
 	{
-		FILE* fp = fopen(path, "rb");
-		if (!fp) { Log("LoadOBJ: cannot open %s", path); return false; }
-		fseek(fp, 0, SEEK_END); const long sz = ftell(fp); fseek(fp, 0, SEEK_SET);
-		if (sz < 0) { fclose(fp); Log("LoadOBJ: cannot open %s", path); return false; }
-		text.resize((size_t)sz + 1);
-		const size_t got = sz ? fread(text.data(), 1, (size_t)sz, fp) : 0;
-		fclose(fp);
-		text[got] = 0;
-		for (size_t i = 0; i < got; ++i) if (text[i] == 0) text[i] = ' ';   // stray NULs would end the C-string parsing early
+		const int fd = open(path, O_RDONLY);
+		struct stat sb;
+		if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { if (fd >= 0) close(fd); Log("LoadOBJ: cannot open %s", path); return false; }
+		textSize = (size_t)sb.st_size;
+		text.reset(new char[textSize + 1]);   // not zero-filled: every byte is read into below
+		// blocks of 32 MB read concurrently (from the page cache this is a copy, and one thread copies 2.9 GB in over a second)
+		const size_t block = (size_t)32 << 20, numBlocks = (textSize + block - 1) / block;
+		std::atomic<bool> failed(false);
+		ForEachParallel(numBlocks, threads, [&](size_t i) {
+			const size_t from = i * block, to = std::min(textSize, from + block);
+			size_t at = from;
+			while (at < to) {
+				const ssize_t r = pread(fd, text.get() + at, to - at, (off_t)at);
+				if (r <= 0) { failed = true; return; }
+				at += (size_t)r;
+			}
+			// stray NULs would end the C-string number parsing early
+			for (char* z = text.get() + from; (z = (char*)memchr(z, 0, (size_t)(text.get() + to - z))) != nullptr; ) *z = ' ';
+		});
+		close(fd);
+		if (failed) { Log("LoadOBJ: cannot read %s", path); return false; }
+		text[textSize] = 0;
 	}
 	const std::string dir = DirOf(path);
 
-	std::vector<float> V, VT, VN;
+	// Chunks of whole lines, parsed concurrently (files under 4 MB on the calling thread).  The result does not depend on the chunking: see Chunk.
+	size_t numChunks = textSize < (4u << 20) ? 1 : std::min<size_t>(threads * 8u, textSize >> 19);
+	if (const char* e = getenv("RAYLIB_PARSE_CHUNKS")) { int v = atoi(e); if (v > 0) numChunks = (size_t)v; }   // tests: force a chunking
+	numChunks = std::max<size_t>(1, std::min(numChunks, textSize + 1));
+	std::vector<Chunk> chunks(numChunks);
+	{
+		const char* const base = text.get();
+		const char* const fileEnd = base + textSize;
+		const char* cursor = base;
+		for (size_t i = 0; i < numChunks; ++i) {
+			chunks[i].begin = cursor;
+			const char* stop = i + 1 == numChunks ? fileEnd : std::max(cursor, base + (textSize / numChunks) * (i + 1));
+			while (stop < fileEnd && stop > base && stop[-1] != '\n') ++stop;   // a chunk ends after a newline
+			chunks[i].end = cursor = stop;
+		}
+	}
+	const auto tl1 = std::chrono::steady_clock::now();
+	ForEachParallel(numChunks, threads, [&](size_t i) { ParseChunk(chunks[i]); });
+	const auto tl2 = std::chrono::steady_clock::now();
+
+	// Serial pass over the chunks in file order: element bases, shape numbers, and the usemtl / mtllib lines replayed in
+	// order (a usemtl sees the libraries read before it, as in a one-pass reader).
 	std::vector<MtlRecord> mtl;
 	std::map<std::string, int> mtlIndex;
-	struct Face { Corner c[3]; int material; int shape; };
-	std::vector<Face> faces;
-	int curMaterial = -1;
-	int curShape = -1, numShapes = 0;
-	bool shapeHasFaces = false;
-	std::vector<Corner> cs;
-
-	auto isSpace = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r'; };
-	// next token of the current line: [b, e); false at end of line / comment
-	auto nextToken = [&](const char*& p, const char*& b, const char*& e) -> bool {
-		while (isSpace(*p)) ++p;
-		if (*p == 0 || *p == '\n' || *p == '#') return false;
-		b = p;
-		while (*p && *p != '\n' && !isSpace(*p)) ++p;
-		e = p;
-		return true;
-	};
-	auto number = [&](const char*& p, float dflt) -> float {
-		const char* b; const char* e;
-		if (!nextToken(p, b, e)) return dflt;
-		return ParseFloat(b, e);
-	};
-	auto is = [](const char* b, const char* e, const char* word) { const size_t n = strlen(word); return (size_t)(e - b) == n && memcmp(b, word, n) == 0; };
-
-	const auto tl1 = std::chrono::steady_clock::now();
-	const char* p = text.data();
-	while (*p) {
-		const char* b; const char* e;
-		if (nextToken(p, b, e)) {
-			if (is(b, e, "v")) { const float x = number(p, 0.0f), y = number(p, 0.0f), z = number(p, 0.0f); V.push_back(x); V.push_back(y); V.push_back(z); }
-			else if (is(b, e, "vt")) { const float u = number(p, 0.0f), v = number(p, 0.0f); VT.push_back(u); VT.push_back(v); }
-			else if (is(b, e, "vn")) { const float x = number(p, 0.0f), y = number(p, 0.0f), z = number(p, 0.0f); VN.push_back(x); VN.push_back(y); VN.push_back(z); }
-			else if (is(b, e, "o") || is(b, e, "g")) {
-				// a new shape starts; shapes that end up without faces are dropped
-				if (shapeHasFaces || curShape < 0) { curShape = numShapes++; }
-				shapeHasFaces = false;
-			}
-			else if (is(b, e, "usemtl")) {
-				const char* nb; const char* ne;
-				auto it = nextToken(p, nb, ne) ? mtlIndex.find(std::string(nb, ne)) : mtlIndex.end();
-				curMaterial = it == mtlIndex.end() ? -1 : it->second;
-			}
-			else if (is(b, e, "mtllib")) {
-				const char* nb; const char* ne;
-				while (nextToken(p, nb, ne)) {
-					size_t before = mtl.size();
-					ParseMTL(dir + std::string(nb, ne), mtl);
+	size_t totalV = 0, totalVT = 0, totalVN = 0;
+	int shapesSoFar = 0, curMaterial = -1;
+	for (Chunk& c : chunks) {
+		c.baseV = totalV; c.baseVT = totalVT; c.baseVN = totalVN;
+		totalV += c.V.size() / 3; totalVT += c.VT.size() / 2; totalVN += c.VN.size() / 3;
+		c.baseShape = shapesSoFar; shapesSoFar += c.shapeCount;
+		c.materialIn = curMaterial;
+		for (const MtlEvent& ev : c.events) {
+			if (ev.isLib) {
+				for (const std::string& name : ev.names) {
+					const size_t before = mtl.size();
+					ParseMTL(dir + name, mtl);
 					for (size_t j = before; j < mtl.size(); ++j) mtlIndex[mtl[j].name] = (int)j;
 				}
-			}
-			else if (is(b, e, "f")) {
-				if (curShape < 0) { curShape = numShapes++; }
-				cs.clear();
-				bool ok = true;
-				const char* cb; const char* ce;
-				while (nextToken(p, cb, ce)) {
-					Corner c;
-					if (!ParseCorner(cb, (int)V.size() / 3, (int)VT.size() / 2, (int)VN.size() / 3, c)) { ok = false; break; }
-					cs.push_back(c);
-				}
-				if (ok && cs.size() >= 3) {
-					for (size_t j = 1; j + 1 < cs.size(); ++j) {   // triangle fan
-						Face f; f.c[0] = cs[0]; f.c[1] = cs[j]; f.c[2] = cs[j + 1]; f.material = curMaterial; f.shape = curShape;
-						faces.push_back(f);
-					}
-					shapeHasFaces = true;
-				}
+			} else {
+				auto it = ev.hasName ? mtlIndex.find(ev.names[0]) : mtlIndex.end();
+				curMaterial = it == mtlIndex.end() ? -1 : it->second;
+				c.usemtlMaterial.push_back(curMaterial);
 			}
 		}
-		while (*p && *p != '\n') ++p;   // rest of the line
-		if (*p == '\n') ++p;
 	}
-	text.clear(); text.shrink_to_fit();
-	const auto tl2 = std::chrono::steady_clock::now();
-	if (faces.empty()) { Log("LoadOBJ: No shapes found in: %s", path); return false; }
+	// faces before any o / g line are shape 0, those after the k-th such line shape k; shapes without faces are dropped below
+	const int numShapes = shapesSoFar + 1;
+
+	// uninitialised: every element is written by the chunk copies below (zero-filling 10^7 vertices first costs as much as parsing them)
+	std::unique_ptr<float[]> Vbuf(new float[3 * totalV + 1]), VTbuf(new float[2 * totalVT + 1]), VNbuf(new float[3 * totalVN + 1]);
+	float* const V = Vbuf.get(); float* const VT = VTbuf.get(); float* const VN = VNbuf.get();
+	// A polygon counts if every corner names a position defined BEFORE its line (a one-pass reader knows no others).
+	// Marks dropped polygons (numCorners = 0) and counts each chunk's triangles (fans).
+	ForEachParallel(numChunks, threads, [&](size_t i) {
+		Chunk& c = chunks[i];
+		if (!c.V.empty()) memcpy(&V[3 * c.baseV], c.V.data(), c.V.size() * sizeof(float));
+		if (!c.VT.empty()) memcpy(&VT[2 * c.baseVT], c.VT.data(), c.VT.size() * sizeof(float));
+		if (!c.VN.empty()) memcpy(&VN[3 * c.baseVN], c.VN.data(), c.VN.size() * sizeof(float));
+		std::vector<float>().swap(c.V); std::vector<float>().swap(c.VT); std::vector<float>().swap(c.VN);
+		size_t tris = 0;
+		for (Poly& poly : c.polys) {
+			const int nV = (int)c.baseV + poly.nV;
+			bool ok = true;
+			for (uint32_t k = 0; k < poly.numCorners && ok; ++k) {
+				const int v = ResolveIndex(c.corners[poly.firstCorner + k].v, nV);
+				ok = v >= 0 && v < nV;
+			}
+			if (ok) tris += poly.numCorners - 2; else poly.numCorners = 0;
+		}
+		c.numTris = tris;
+	});
+	size_t totalTris = 0;
+	for (Chunk& c : chunks) { c.triBase = totalTris; totalTris += c.numTris; }
+	text.reset();
+	const auto tl3 = std::chrono::steady_clock::now();
+	if (totalTris == 0) { Log("LoadOBJ: No shapes found in: %s", path); return false; }
 
 	// compact shape ids (drop empty shapes)
 	std::vector<int> remap(numShapes, -1);
 	int nShapes = 0;
-	for (const Face& f : faces) if (remap[f.shape] < 0) remap[f.shape] = 0;
+	for (const Chunk& c : chunks) for (const Poly& poly : c.polys) if (poly.numCorners) remap[c.baseShape + poly.shapeSeen] = 0;
 	for (int i = 0; i < numShapes; ++i) if (remap[i] == 0) remap[i] = nShapes++;
 
 	out.materials.clear(); out.materialNames.clear(); out.images.clear(); out.triangles.clear();
@@ -339,38 +475,56 @@ bool LoadOBJ(const char* path, OBJModel& out)
 	}
 	const int fallback = (int)out.materials.size() - 1;
 
-	out.triangles.reserve(faces.size());
+	const auto tl5 = std::chrono::steady_clock::now();
+	out.triangles.resize(totalTris);
+	const int nVTall = (int)totalVT, nVNall = (int)totalVN;
+	ForEachParallel(numChunks, threads, [&](size_t ci) {
+		Chunk& c = chunks[ci];
+		HostTriangle* dst = out.triangles.data() + c.triBase;
+		int invalidTexcoords = 0;
+		for (const Poly& poly : c.polys) {
+			if (!poly.numCorners) continue;
+			const int nV = (int)c.baseV + poly.nV, nVT = (int)c.baseVT + poly.nVT, nVN = (int)c.baseVN + poly.nVN;
+			const int material = poly.usemtlSeen ? c.usemtlMaterial[poly.usemtlSeen - 1] : c.materialIn;
+			const RawCorner* rc = &c.corners[poly.firstCorner];
+			for (uint32_t j = 1; j + 1 < poly.numCorners; ++j) {   // triangle fan
+				const RawCorner* corner[3] = { &rc[0], &rc[j], &rc[j + 1] };
+				HostTriangle t; memset(&t, 0, sizeof(t));
+				f3 pos[3], nrm[3]; float tu[3], tv[3];
+				bool validNormal = true;
+				for (int k = 0; k < 3; ++k) {
+					const int v = ResolveIndex(corner[k]->v, nV), vt = ResolveIndex(corner[k]->vt, nVT), vn = ResolveIndex(corner[k]->vn, nVN);
+					pos[k] = F3(V[3 * (size_t)v], V[3 * (size_t)v + 1], V[3 * (size_t)v + 2]);
+					if (vt >= 0 && vt < nVTall) { tu[k] = VT[2 * (size_t)vt]; tv[k] = VT[2 * (size_t)vt + 1]; }
+					else { tu[k] = tv[k] = 0.0f; ++invalidTexcoords; }
+					if (vn >= 0 && vn < nVNall) nrm[k] = F3(VN[3 * (size_t)vn], VN[3 * (size_t)vn + 1], VN[3 * (size_t)vn + 2]);
+					else { nrm[k] = F3(0, 0, 0); validNormal = false; }
+				}
+				if (!validNormal) {
+					f3 n = normalize(cross(pos[1] - pos[0], pos[2] - pos[0]));
+					nrm[0] = nrm[1] = nrm[2] = n;
+				}
+				t.v0 = pos[0]; t.v1 = pos[1]; t.v2 = pos[2];
+				t.n0 = nrm[0]; t.n1 = nrm[1]; t.n2 = nrm[2];
+				t.s0 = tu[0]; t.t0 = tv[0]; t.s1 = tu[1]; t.t1 = tv[1]; t.s2 = tu[2]; t.t2 = tv[2];
+				t.material = (material >= 0 && material < fallback) ? material : fallback;
+				t.shape = remap[c.baseShape + poly.shapeSeen];
+				*dst++ = t;
+			}
+		}
+		c.invalidTexcoords = invalidTexcoords;
+		std::vector<Poly>().swap(c.polys); std::vector<RawCorner>().swap(c.corners);
+	});
 	int numInvalidTexcoords = 0;
-	for (const Face& f : faces) {
-		HostTriangle t; memset(&t, 0, sizeof(t));
-		f3 pos[3], nrm[3]; float tu[3], tv[3];
-		bool validNormal = true;
-		for (int c = 0; c < 3; ++c) {
-			const Corner& k = f.c[c];
-			pos[c] = F3(V[3 * k.v], V[3 * k.v + 1], V[3 * k.v + 2]);
-			if (k.vt >= 0 && k.vt < (int)VT.size() / 2) { tu[c] = VT[2 * k.vt]; tv[c] = VT[2 * k.vt + 1]; }
-			else { tu[c] = tv[c] = 0.0f; ++numInvalidTexcoords; }
-			if (k.vn >= 0 && k.vn < (int)VN.size() / 3) nrm[c] = F3(VN[3 * k.vn], VN[3 * k.vn + 1], VN[3 * k.vn + 2]);
-			else { nrm[c] = F3(0, 0, 0); validNormal = false; }
-		}
-		if (!validNormal) {
-			f3 n = normalize(cross(pos[1] - pos[0], pos[2] - pos[0]));
-			nrm[0] = nrm[1] = nrm[2] = n;
-		}
-		t.v0 = pos[0]; t.v1 = pos[1]; t.v2 = pos[2];
-		t.n0 = nrm[0]; t.n1 = nrm[1]; t.n2 = nrm[2];
-		t.s0 = tu[0]; t.t0 = tv[0]; t.s1 = tu[1]; t.t1 = tv[1]; t.s2 = tu[2]; t.t2 = tv[2];
-		t.material = (f.material >= 0 && f.material < fallback) ? f.material : fallback;
-		t.shape = remap[f.shape];
-		out.triangles.push_back(t);
-	}
+	for (const Chunk& c : chunks) numInvalidTexcoords += c.invalidTexcoords;
 	out.numShapes = nShapes;
 	out.finalized = false;
-	if (getenv("RAYLIB_BUILD_TIMING")) Log("LoadOBJ: read %.2f s, parse %.2f s, materials + triangle assembly %.2f s", std::chrono::duration<double>(tl1 - tl0).count(),
-		std::chrono::duration<double>(tl2 - tl1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tl2).count());
+	if (getenv("RAYLIB_BUILD_TIMING")) Log("LoadOBJ: read %.2f s, parse %.2f s (%d chunks, %u threads), gather + validate %.2f s, materials %.2f s, triangle assembly %.2f s",
+		std::chrono::duration<double>(tl1 - tl0).count(), std::chrono::duration<double>(tl2 - tl1).count(), (int)numChunks, threads,
+		std::chrono::duration<double>(tl3 - tl2).count(), std::chrono::duration<double>(tl5 - tl3).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tl5).count());
 	Log("LoadOBJ: Load %s", path);
 	Log("\tTotal shapes: %d", nShapes);
-	Log("\tTotal vertices: %d", (int)(V.size() / 3));
+	Log("\tTotal vertices: %d", (int)totalV);
 	Log("\tTotal materials: %d", (int)mtl.size());
 	if (numInvalidTexcoords > 0) Log("WARNING: Num triangles with invalid UVs: %d", numInvalidTexcoords);
 	return true;

@@ -349,3 +349,49 @@ def test_obj_number_reader_is_correctly_rounded(lib):
         if struct.pack("<f", got) != struct.pack("<f", want) and not (got == 0.0 and want == 0.0):
             bad.append((t, got, want))
     assert not bad, bad[:5]
+
+
+def test_obj_reader_result_does_not_depend_on_its_chunking(lib, workdir, monkeypatch):
+    """The OBJ text is parsed in chunks of whole lines on several threads (files from 4 MB on).  State that a one-pass reader carries
+    from line to line -- element counts behind relative indices and the defined-before-use check, the material in force, mtllib
+    before/after usemtl, the o/g shape number, dropped polygons -- must come out the same for every chunking, including chunks
+    that hold a single line or nothing."""
+    from raylib_amd import binding
+    d = os.path.join(str(workdir), "chunks"); os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "a.mtl"), "w") as f:
+        f.write("newmtl red\nKd 0.6 0.1 0.1\nNs 10\nnewmtl mirror\nKd 0.9 0.9 0.9\nillum 3\n")
+    with open(os.path.join(d, "b.mtl"), "w") as f:
+        f.write("newmtl late\nKd 0.1 0.2 0.7\nNs 50\n")
+    rng = np.random.RandomState(5)
+    lines = ["# faces before any shape or material", "usemtl red   # not known yet: fallback material", "v 0 0 0", "v 1 0 0", "v 0 1 0", "f 1 2 3",
+             "f 1 2 4   # vertex 4 is defined later: dropped", "v 1 1 0", "mtllib a.mtl", "usemtl red", "f -4 -3 -1 -2", "o first", "o empty", "g second",
+             "vt 0.25 0.5", "vn 0 0 1", "f 1/1/1 2//1 3/1", "f 1/2/1 2/1/1 3/1/1  # vt 2 comes later: valid index at assembly", "vt 0.75 0.125",
+             "usemtl nosuch", "f 1 2 3 4 1", "usemtl", "f 2 3 4", "f 1 x 3", "f 1 2", "usemtl late", "f 1 3 4", "mtllib b.mtl missing.mtl", "usemtl late", "g third", "f 4/0/0 3/-1/-1 1/-2/5"]
+    for i in range(400):                                   # bulk, so that forced chunkings cut everywhere
+        x, y, z = rng.rand(3)
+        lines += ["v %.6f %.6f %.6f" % (x, y, z), "v %.6f %.6f %.6f" % (x + 0.1, y, z), "v %.6f %.6f %.6f" % (x, y + 0.1, z)]
+        if i % 7 == 0: lines.append("vn %.4f %.4f %.4f" % tuple(rng.rand(3)))
+        if i % 5 == 0: lines.append("usemtl %s" % ["red", "mirror", "late", "gone"][i // 5 % 4])
+        if i % 11 == 0: lines.append("o part%d" % i)
+        lines.append("f -3//-1 -2//-1 -1//-1" if i % 3 else "f -3 -2 -1")
+    obj = os.path.join(d, "tricky.obj")
+    with open(obj, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    seen = {}
+    for chunks, threads in (("1", "1"), ("2", "2"), ("3", "8"), ("17", "4"), ("400", "8"), ("100000", "3")):
+        monkeypatch.setenv("RAYLIB_PARSE_CHUNKS", chunks)
+        monkeypatch.setenv("RAYLIB_BUILD_THREADS", threads)
+        ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+        tris, mats = ses.export_flat()
+        seen[chunks] = (tris.tobytes(), mats.tobytes())
+        if chunks == "1":
+            first = tris
+        ses.close()
+    assert len(set(seen.values())) == 1
+    # spot checks of the one-pass rules on the single-chunk result
+    assert len(first) == 1 + 2 + 2 + 3 + 1 + 1 + 1 + 400
+    mat = first["material"]
+    assert list(mat[:11]) == [3, 0, 0, 0, 0, 3, 3, 3, 3, 3, 2]   # red = 0, mirror = 1, late = 2 (only once b.mtl was read), fallback = 3: name not
+                                                                 # known yet, "usemtl nosuch", bare "usemtl", "late" before its mtllib
+    assert list(first["shape"][:11]) == [0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2]   # before any o/g; "second" ("first" and "empty" hold no faces: dropped); "third"
+    assert np.array_equal(first["st"][4][:2], np.float32([0.75, 0.125]))   # vt 2, defined after the face that names it
