@@ -71,6 +71,15 @@ __device__ __forceinline__ bool isZero(V3 a) { return a.x == 0.0f && a.y == 0.0f
 
 #define RL_PI 3.14159265359f   /* BRDF::PI, reference render/brdf.h:8 */
 
+// diagnostic build (-DRL_DIAG_TIMELINE=1, RAYLIB_PRINT_STAMPS=1): k_trace's waves record when they start, when they first find the
+// job queue empty and when they end (s_memrealtime, 100 MHz), three arrays of 8192 slots behind the counters
+#ifdef RL_DIAG_TIMELINE
+#define RL_TIMELINE_SLOTS (3 * 8192)
+#define RL_TIMELINE(which) { if (lane == 0 && (gtid >> 6) < 8192u) counters[CNT_COUNT + 24 + (which) * 8192 + (gtid >> 6)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define RL_TIMELINE_SLOTS 0
+#define RL_TIMELINE(which)
+#endif
 #ifdef RL_DIAG_STAMPS
 #define RL_DIAG_BIND(c) { (c).diag = nullptr; (c).tLast = 0; (c).tAcc[0] = (c).tAcc[1] = (c).tAcc[2] = (c).tAcc[3] = 0; }
 #else
@@ -960,6 +969,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	// per wave and bounce was exactly that rate: the kernel ran at the atomic's speed.)
 	uint32_t chunkNext = 0, chunkEnd = 0;
 	bool globalDone = false;
+	RL_TIMELINE(0);
 #ifdef RL_DIAG_STAMPS
 	// diagnostic build only: shader-clock time per phase (refill | traverse | shade | fold), summed per wave
 	unsigned long long stampAcc[4] = { 0, 0, 0, 0 }, subAcc[4] = { 0, 0, 0, 0 };
@@ -987,7 +997,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				uint32_t base = 0;
 				if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
 				base = __shfl(base, 0);
-				if (base >= P.numJobs) { globalDone = true; }
+				if (base >= P.numJobs) { globalDone = true; RL_TIMELINE(1); }
 				else { chunkNext = base; chunkEnd = min(base + P.jobChunk, P.numJobs); }
 			}
 			const uint32_t avail = chunkEnd - chunkNext;
@@ -1105,6 +1115,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 #ifdef RL_DIAG_STAMPS
 	if (lane == 0) for (int k = 0; k < 4; ++k) { atomicAdd(&counters[CNT_COUNT + k], stampAcc[k]); atomicAdd(&counters[CNT_COUNT + 8 + k], subAcc[k]); atomicAdd(&counters[CNT_COUNT + 12 + k], c.tAcc[k]); }
 #endif
+	RL_TIMELINE(2);
 	// ---- counters: wave reduction, one atomic per wave and counter ----
 	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples, c.trips };
 	for (int k = 0; k < CNT_COUNT; ++k) {
@@ -2030,7 +2041,7 @@ bool EnsureRuntime()
 	R.numCUs = prop.multiProcessorCount;
 	HIP_OK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
 	for (int i = 0; i < 4; ++i) HIP_OK(hipEventCreate(&R.ev[i]));
-	HIP_OK(hipMalloc(&R.counters, (CNT_COUNT + 24) * sizeof(unsigned long long)));
+	HIP_OK(hipMalloc(&R.counters, (CNT_COUNT + 24 + RL_TIMELINE_SLOTS) * sizeof(unsigned long long)));
 	HIP_OK(hipMalloc(&R.jobCounter, sizeof(unsigned int)));
 	Log("raylib(MI355X): device %d %s (%s), %d CUs", dev, prop.name, prop.gcnArchName, R.numCUs);
 	R.ok = true;
@@ -2238,7 +2249,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	float4* out = (float4*)req.outDevice;
 	if (!out) { if (!Grow(R.image, R.imageBytes, outBytes ? outBytes : 16)) return false; out = R.image; }
 
-	HIP_OK(hipMemsetAsync(R.counters, 0, (CNT_COUNT + 24) * sizeof(unsigned long long), R.stream));
+	HIP_OK(hipMemsetAsync(R.counters, 0, (CNT_COUNT + 24 + RL_TIMELINE_SLOTS) * sizeof(unsigned long long), R.stream));
 	uint32_t schedulePaths = 1;
 	float traceMs = 0.0f;
 	uint32_t launches = 0;
@@ -2335,6 +2346,19 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	stats.shadedHits = cnt[CNT_SHADED]; stats.texFetches = cnt[CNT_TEXELS]; stats.cameraSamples = cnt[CNT_SAMPLES];
 	stats.waveTrips = cnt[CNT_TRIPS];
 	stats.pathsPerWave = 64u * schedulePaths; stats.reserved0 = 0;
+#ifdef RL_DIAG_TIMELINE
+	if (getenv("RAYLIB_PRINT_STAMPS")) {
+		std::vector<unsigned long long> tl(RL_TIMELINE_SLOTS);
+		HIP_OK(hipMemcpy(tl.data(), R.counters + CNT_COUNT + 24, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		std::vector<double> st, ex, en;
+		unsigned long long t0 = ~0ull;
+		for (int w = 0; w < 8192; ++w) if (tl[w] && tl[w] < t0) t0 = tl[w];
+		for (int w = 0; w < 8192; ++w) if (tl[w]) { st.push_back((tl[w] - t0) * 0.01); if (tl[8192 + w]) ex.push_back((tl[8192 + w] - t0) * 0.01); en.push_back((tl[16384 + w] - t0) * 0.01); }
+		auto pct = [](std::vector<double>& v, double q) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+		Log("timeline (us from the first wave's start; last launch, %d waves): start p50 %.1f max %.1f | queue seen empty min %.1f p50 %.1f max %.1f | end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f",
+			(int)st.size(), pct(st, 0.5), pct(st, 1.0), pct(ex, 0.0), pct(ex, 0.5), pct(ex, 1.0), pct(en, 0.0), pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), pct(en, 1.0));
+	}
+#endif
 	if (getenv("RAYLIB_PRINT_STAMPS")) {
 		const double tot = (double)(cnt[CNT_COUNT] + cnt[CNT_COUNT + 1] + cnt[CNT_COUNT + 2] + cnt[CNT_COUNT + 3]);
 		Log("wave steps: node %llu (lane steps %llu, eff %.3f)  tri %llu (lane %llu, eff %.3f)  leaf rounds %llu  trips %llu", cnt[CNT_COUNT + 4], cnt[CNT_NODES], cnt[CNT_NODES] / (64.0 * cnt[CNT_COUNT + 4] + 1), cnt[CNT_COUNT + 5], cnt[CNT_TRIS], cnt[CNT_TRIS] / (64.0 * cnt[CNT_COUNT + 5] + 1), cnt[CNT_COUNT + 6], cnt[CNT_TRIPS]);
