@@ -395,3 +395,19 @@ def test_obj_reader_result_does_not_depend_on_its_chunking(lib, workdir, monkeyp
                                                                  # known yet, "usemtl nosuch", bare "usemtl", "late" before its mtllib
     assert list(first["shape"][:11]) == [0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2]   # before any o/g; "second" ("first" and "empty" hold no faces: dropped); "third"
     assert np.array_equal(first["st"][4][:2], np.float32([0.75, 0.125]))   # vt 2, defined after the face that names it
+
+
+def test_chunked_obj_reader_matches_oracle_side_parser_on_a_multi_megabyte_file(lib, oracle, workdir, monkeypatch):
+    """A file above the 4 MB threshold goes through the default chunking (several chunks, several threads); the flat scene must be
+    the one the independent Python parser produces from the same text."""
+    from raylib_amd import binding
+    obj, n = scenes.cornell(os.path.join(str(workdir), "chunked_big.obj"), tess=24, displace_fraction=0.2)
+    assert os.path.getsize(obj) > (4 << 20), os.path.getsize(obj)
+    monkeypatch.setenv("RAYLIB_BUILD_THREADS", "4")
+    monkeypatch.delenv("RAYLIB_PARSE_CHUNKS", raising=False)
+    flat = helpers.objflat.load_obj(obj, oracle)
+    ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+    tris, mats = ses.export_flat()
+    ses.close()
+    assert len(tris) == n == len(flat.triangles)
+    assert tris.tobytes() == flat.triangles.tobytes() and mats.tobytes() == flat.materials.tobytes()
