@@ -99,7 +99,8 @@ def main():
     # BENCH_SHARE_GPU=1 (test aid, 1-GPU box): several ranks on the one device, the gather staged through the host over gloo --
     # RCCL refuses two ranks per device.  It exercises the N > 1 frame assembly, not its speed.
     share = os.environ.get("BENCH_SHARE_GPU", "0") == "1"
-    device_index = local_rank % torch.cuda.device_count() if share else local_rank
+    # one visible device per rank (a launcher that masks devices per process) or all of the node's devices visible to every rank
+    device_index = local_rank % max(1, torch.cuda.device_count())
     os.environ["RAYLIB_DEVICE"] = str(device_index)
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
