@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <thread>
 #include <float.h>
 #include <stdio.h>
@@ -2253,6 +2254,7 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	uint32_t schedulePaths = 1;
 	float traceMs = 0.0f;
 	uint32_t launches = 0;
+	bool lastBatchPending = false;
 	HIP_OK(hipEventRecord(R.ev[0], R.stream));
 	if (numSlots == 0) {
 		// nothing to do for this rank
@@ -2292,7 +2294,14 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
 		schedulePaths = pathsPerThread;
 		int blocksPerCU = 0;
-		HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, traceKernel, RL_BLOCK, 0));
+		{   // asked once per kernel (the runtime lock is held)
+			static std::map<const void*, int> known;
+			auto it = known.find((const void*)traceKernel);
+			if (it == known.end()) {
+				HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, traceKernel, RL_BLOCK, 0));
+				known[(const void*)traceKernel] = blocksPerCU;
+			} else blocksPerCU = it->second;
+		}
 		if (blocksPerCU < 1) blocksPerCU = 1;
 		if (const char* e = getenv("RAYLIB_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) blocksPerCU = v; }
 		const int depthSlots = st.maxPathLength > 1 ? st.maxPathLength : 1;
@@ -2325,22 +2334,28 @@ bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 			hipLaunchKernelGGL(k_resolve, dim3(rblocks), dim3(RL_BLOCK), 0, R.stream,
 			                   P, R.samples, R.accum, out, (int)(s0 == 0), (int)(s0 + cnt >= SPP));
 			HIP_OK(hipGetLastError());
-			HIP_OK(hipEventSynchronize(R.ev[3]));
-			float ms = 0.0f;
-			HIP_OK(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]));
-			traceMs += ms;
 			++launches;
+			if (s0 + cnt < SPP) {   // the event pair is reused by the next batch; the last batch's pair is read after the one final sync
+				HIP_OK(hipEventSynchronize(R.ev[3]));
+				float ms = 0.0f;
+				HIP_OK(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]));
+				traceMs += ms;
+			} else lastBatchPending = true;
 		}
 	}
+	// one host synchronisation per render: end event, counters and (if asked for) the image are queued behind the kernels
 	HIP_OK(hipEventRecord(R.ev[1], R.stream));
-	HIP_OK(hipEventSynchronize(R.ev[1]));
-	float totalMs = 0.0f;
-	HIP_OK(hipEventElapsedTime(&totalMs, R.ev[0], R.ev[1]));
-
 	unsigned long long cnt[CNT_COUNT + 24];
 	HIP_OK(hipMemcpyAsync(cnt, R.counters, sizeof(cnt), hipMemcpyDeviceToHost, R.stream));
 	if (req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, outBytes, hipMemcpyDeviceToHost, R.stream));
 	HIP_OK(hipStreamSynchronize(R.stream));
+	if (lastBatchPending) {
+		float ms = 0.0f;
+		HIP_OK(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]));
+		traceMs += ms;
+	}
+	float totalMs = 0.0f;
+	HIP_OK(hipEventElapsedTime(&totalMs, R.ev[0], R.ev[1]));
 
 	stats.rays = cnt[CNT_RAYS]; stats.nodesVisited = cnt[CNT_NODES]; stats.trisTested = cnt[CNT_TRIS];
 	stats.shadedHits = cnt[CNT_SHADED]; stats.texFetches = cnt[CNT_TEXELS]; stats.cameraSamples = cnt[CNT_SAMPLES];
