@@ -615,6 +615,7 @@ __device__ __forceinline__ float SinPhi(V3 w) { float s = SinThetaL(w); return (
 // reference render/material.cc:83-165
 __device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y, Counters& cn)
 {
+	(void)cn;   // diagnostic builds count Newton iterations
 	const float Pi = RL_PI;
 	if ((double)cosThetaI > .9999) {
 		float r = sqrtf(-rtm::log_(1.0f - U1));
@@ -1602,14 +1603,13 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 		// ---- shading (TraceScene after the accel->Hit call, reference render/renderer.cc:129-208) ----
 		// (1) the cheap outcomes are finished by the slot's home lane: a miss runs the sky lookup and (with a sun) turns
 		//     into an occlusion query, a returned occlusion query ends the path.  Hits are only LISTED.
-		uint32_t nHit = 0, nQuery = 0;
+		uint32_t nHit = 0;
 		uint32_t hitIdx[K];
 		#pragma unroll
 		for (int p = 0; p < K; ++p) {
 			const int slot = p * 64 + (int)lane;
 			const int q = __float_as_int(pool[F_TRI][slot]);
 			const bool isHit = stActive[p] && q >= 0;
-			bool isQuery = stActive[p] && (q == Q_CLOSEST || q == Q_SHADOW || q == Q_PENDING || q == Q_PENDING_SHADOW);
 			if (stActive[p] && (q == Q_MISS || q == Q_CLEAR || q == Q_OCCLUDED)) {
 				const V3 d = v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
 				bool done = true;
@@ -1620,7 +1620,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 						// the sky part waits in the direction fields (the sun query brings its own direction)
 						pool[F_DX][slot] = L.x; pool[F_DY][slot] = L.y; pool[F_DZ][slot] = L.z;
 						pool[F_TRI][slot] = __int_as_float(Q_SHADOW);
-						done = false; isQuery = true;
+						done = false;
 					}
 				} else {
 					L = d;
@@ -1637,7 +1637,6 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 			hitIdx[p] = isHit ? nHit + (uint32_t)__popcll(hm & laneLt) : 0xffffffffu;
 			if (isHit) freeList[hitIdx[p]] = (unsigned char)slot;
 			nHit += (uint32_t)__popcll(hm);
-			nQuery += (uint32_t)__popcll(__ballot(isQuery));
 		}
 		WaveLdsSync();
 		// (2) hits are shaded 64 at a time by whichever lane: the expensive material code always runs with a full wave.
@@ -1663,7 +1662,6 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 				const int a3 = __shfl(stDepth[k], h);
 				if (pp == k) { rngLo = a0; rngHi = a1; outIndex = a2; depth = a3; }
 			}
-			uint32_t cont = 0;
 			if (on) {
 				const V3 o = v3(pool[F_OX][slot], pool[F_OY][slot], pool[F_OZ][slot]);
 				const V3 d = v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
@@ -1688,7 +1686,6 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 						pool[F_OX][slot] = sf.p.x; pool[F_OY][slot] = sf.p.y; pool[F_OZ][slot] = sf.p.z;
 						pool[F_DX][slot] = outD.x; pool[F_DY][slot] = outD.y; pool[F_DZ][slot] = outD.z;
 						pool[F_TRI][slot] = __int_as_float(Q_CLOSEST);
-						cont = 1;
 					}
 				} else {
 					L = v3s(0.0f) + E;                            // radiance(0) += Emitted, renderer.cc:137,151
@@ -1704,7 +1701,6 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 				pool[F_A][slot] = __int_as_float((int)(uint32_t)(g.s.state >> 32));
 				pool[F_B][slot] = __int_as_float(done ? -1 : depth);
 			}
-			nQuery += (uint32_t)__popcll(__ballot(cont != 0));
 			shadedEnd += 64u;
 		}
 		WaveLdsSync();
