@@ -71,3 +71,24 @@ def test_partition_covers_every_pixel_once():
                 idx = tiling.pixel_index_map(w, h, r, world)
                 np.add.at(seen, idx[idx >= 0], 1)
             assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("world", [3, 4, 8])
+def test_scatter_plan_reassembles_for_the_world_sizes_the_driver_runs(world):
+    """bench.py's rank-0 assembly (stack the gathered, padded buffers, one indexed copy) for 4 and 8 ranks and an odd count, without
+    processes: the buffers are what the ranks would have sent."""
+    import torch
+    from raylib_amd import tiling
+    for (w, h) in ((1920, 1080), (40, 28), (9, 7)):
+        image = np.random.RandomState(world).rand(h, w, 4).astype(np.float32)
+        pad = tiling.padded_cells(w, h, world) * 64
+        bufs = []
+        for r in range(world):
+            mine = np.full((pad, 4), -1.0, np.float32)              # padding must never reach the frame
+            cells = tiling.extract_cells(image, r, world)
+            mine[: len(cells)] = cells
+            bufs.append(torch.from_numpy(mine))
+        src, dst = tiling.torch_scatter_plan(w, h, world, "cpu")
+        out = torch.full((h * w, 4), -2.0)
+        out[dst] = torch.stack(bufs).reshape(-1, 4)[src]
+        assert np.array_equal(out.numpy().reshape(h, w, 4), image)
