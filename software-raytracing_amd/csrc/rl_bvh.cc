@@ -261,6 +261,8 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 	// sub-trees of at most this many primitives are tasks.  Not far below kParallelRange: between the two sizes a range is
 	// binned by ONE thread while the others wait (10 M triangles, 32 threads: 1.3 s of a 2.3 s build went there with n / 16T)
 	B.taskSize = threads > 1 ? std::max<uint32_t>(4096u, std::min<uint32_t>(kParallelRange - 1u, n / (threads * 4u))) : 0u;
+	// large scenes: everything below the all-thread ranges is a task -- no range is left for one thread to bin while the others wait
+	if (threads > 1 && n >= 8u * kParallelRange) B.taskSize = kParallelRange - 1u;
 
 	const auto tb0 = std::chrono::steady_clock::now();
 	Ctx top;
