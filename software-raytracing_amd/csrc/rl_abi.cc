@@ -173,6 +173,7 @@ void Raylib_DumpImageData(ImageHandle h, float* outDest)
 {
 	Image* img = (Image*)h;
 	if (!img || !outDest) return;
+	img->SyncHost();   // the one read-back of a rendered / post-processed frame
 	const size_t n = (size_t)img->width * img->height;
 	for (size_t k = 0; k < n; ++k) {   // reference render/image.cc:121-135: packed RGB, row-major
 		outDest[3 * k + 0] = img->rgba[4 * k + 0];
@@ -263,11 +264,12 @@ void Raylib_Render(const RendererSettings* settings, SceneHandle scene, CameraHa
 	if (settings->viewportWidth != img->width || settings->viewportHeight != img->height)
 		img->Reallocate(settings->viewportWidth, settings->viewportHeight, 0.0f, 0.0f, 0.0f, 1.0f);   // renderer.cc:292-296
 	if ((size_t)img->width * img->height == 0) return;
-	void* dev = DeviceImagePixels(*img);   // the frame stays resident for Raylib_PostProcess
-	img->devValid = false;
-	if (!RenderInternal(settings, (Scene*)scene, (Camera*)camera, 0, 1, dev, img->rgba.data()))
+	void* dev = DeviceImagePixels(*img);   // the frame stays on the device: Raylib_PostProcess works on it there, and the host pixels
+	img->devValid = false;                 // are fetched when somebody asks for them (Raylib_DumpImageData, Raylib_WriteImageToDisk, ...)
+	img->hostStale = false;
+	if (!RenderInternal(settings, (Scene*)scene, (Camera*)camera, 0, 1, dev, dev ? nullptr : img->rgba.data()))
 		fprintf(stderr, "Raylib_Render: FAILED (no HIP device or invalid arguments); the image was not written\n");
-	else img->devValid = (dev != nullptr);
+	else { img->devValid = (dev != nullptr); img->hostStale = (dev != nullptr); }
 }
 
 int32_t Raylib_Denoise(ImageHandle, int32_t, ImageHandle, ImageHandle, ImageHandle)
@@ -455,6 +457,7 @@ void RaylibAMD_SceneExportTexture(SceneHandle sh, int32_t i, float* out)
 {
 	Scene* s = (Scene*)sh;
 	if (!s || !out || i < 0 || i >= (int32_t)s->textures.size()) return;
+	s->textures[i]->SyncHost();
 	memcpy(out, s->textures[i]->rgba.data(), s->textures[i]->rgba.size() * sizeof(float));
 }
 void RaylibAMD_SceneGetSun(SceneHandle sh, float ill[3], float dir[3])
@@ -514,6 +517,7 @@ void RaylibAMD_DumpImageRGBA(ImageHandle h, float* out)
 {
 	Image* img = (Image*)h;
 	if (!img || !out) return;
+	img->SyncHost();
 	memcpy(out, img->rgba.data(), img->rgba.size() * sizeof(float));
 }
 float RaylibAMD_ParseFloat(const char* token) { return token ? ParseDecimalFloat(token) : 0.0f; }

@@ -70,9 +70,13 @@ struct Image {
 	void* devPixels = nullptr;
 	size_t devBytes = 0;
 	bool devValid = false;
+	// Raylib_Render / Raylib_PostProcess leave the result on the device and mark the host pixels stale; whoever reads `rgba`
+	// on the host calls SyncHost() first (one read-back when the pixels are asked for, none per render)
+	bool hostStale = false;
+	void SyncHost() const;
 	Image() = default;
-	Image(const Image& o) : width(o.width), height(o.height), rgba(o.rgba) {}
-	Image& operator=(const Image& o) { width = o.width; height = o.height; rgba = o.rgba; devValid = false; return *this; }
+	Image(const Image& o) : width(o.width), height(o.height) { o.SyncHost(); rgba = o.rgba; }
+	Image& operator=(const Image& o) { o.SyncHost(); width = o.width; height = o.height; rgba = o.rgba; devValid = false; hostStale = false; return *this; }
 	~Image();
 	void Reallocate(uint32_t w, uint32_t h, float r, float g, float b, float a);
 };
@@ -191,6 +195,7 @@ bool EncodeJPEG(uint32_t w, uint32_t h, const uint8_t* rgbTopDown, std::vector<u
 bool DeviceRender(Scene& scene, const RenderRequest& req, RaylibAMDStats& stats);
 bool DeviceClosestHit(Scene& scene, const float* rays, int32_t n, float tMin, void* outHits);
 bool DevicePostProcess(Image& img);          // Image2D::PostProcess on the device; false when no device
+bool DeviceReadback(Image& img);            // device copy -> img.rgba (the caller checked hostStale)
 void* DeviceImagePixels(Image& img);          // (re)allocates img.devPixels for width*height float4; nullptr when no device
 void DeviceFreePixels(void* p);
 bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out);

@@ -19,8 +19,17 @@ namespace rl {
 
 Image::~Image() { if (devPixels) DeviceFreePixels(devPixels); }
 
+void Image::SyncHost() const
+{
+	if (!hostStale) return;
+	Image& self = const_cast<Image&>(*this);
+	if (!DeviceReadback(self)) Log("Image: the device copy could not be read back; host pixels are stale");
+	self.hostStale = false;
+}
+
 void Image::Reallocate(uint32_t w, uint32_t h, float r, float g, float b, float a)
 {
+	SyncHost();
 	devValid = false;
 	// reference render/image.cc:29-34: vector::resize keeps existing pixels, new ones get the clear colour
 	width = w; height = h;
@@ -273,6 +282,7 @@ Image* LoadImageFile(const char* path)
 
 bool WriteImageFile(const Image& img, const char* path, uint32_t fileType)
 {
+	img.SyncHost();
 	switch (fileType) {
 		case RAYLIB_IMAGEFILETYPE_Bitmap: return WriteBMP(img, path);
 		case RAYLIB_IMAGEFILETYPE_Png:    return WritePNG(img, path);

@@ -2016,6 +2016,7 @@ struct Runtime {
 	std::mutex lock;
 };
 Runtime g_rt;
+bool ReadbackLocked(Image& img);   // device copy -> img.rgba; the runtime lock is held by the caller
 
 bool EnsureRuntime()
 {
@@ -2114,6 +2115,11 @@ bool UploadScene(Scene& sc)
 	for (size_t i = 0; i < texs.size(); ++i) {
 		const Image& im = *sc.textures[i];
 		texs[i].offset = (uint32_t)(pool.size() / 4); texs[i].width = (int32_t)im.width; texs[i].height = (int32_t)im.height; texs[i].pad = 0;
+		if (im.hostStale) {   // a rendered image used as a texture / sky: fetch it (the runtime lock is held here)
+			Image& w = const_cast<Image&>(im);
+			if (!ReadbackLocked(w)) Log("UploadScene: texture %zu could not be read back from the device", i);
+			w.hostStale = false;
+		}
 		pool.insert(pool.end(), im.rgba.begin(), im.rgba.end());
 	}
 	// Albedo maps are read through Texture2D::Sample(bSRGB = true): nearest texel, then pow(texel, 2.2) on all four channels
@@ -2489,6 +2495,25 @@ void* DeviceImagePixels(Image& img)
 	return img.devPixels;
 }
 
+bool DeviceReadback(Image& img)
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	return ReadbackLocked(img);
+}
+namespace {
+bool ReadbackLocked(Image& img)
+{
+	const size_t n = (size_t)img.width * img.height;
+	if (n == 0) return true;
+	if (!g_rt.ok || !img.devPixels || !img.devValid || img.devBytes < n * sizeof(float4)) return false;
+	HIP_OK(hipSetDevice(g_rt.device));
+	img.rgba.resize(n * 4);
+	HIP_OK(hipMemcpyAsync(img.rgba.data(), img.devPixels, n * sizeof(float4), hipMemcpyDeviceToHost, g_rt.stream));
+	HIP_OK(hipStreamSynchronize(g_rt.stream));
+	return true;
+}
+} // namespace
+
 void DeviceFreePixels(void* p)
 {
 	if (!p) return;
@@ -2507,7 +2532,7 @@ bool DevicePostProcess(Image& img)
 	if (!px) return false;
 	std::lock_guard<std::mutex> lk(g_rt.lock);
 	HIP_OK(hipSetDevice(g_rt.device));
-	if (!img.devValid) HIP_OK(hipMemcpyAsync(px, img.rgba.data(), n * sizeof(float4), hipMemcpyHostToDevice, g_rt.stream));
+	if (!img.devValid) HIP_OK(hipMemcpyAsync(px, img.rgba.data(), n * sizeof(float4), hipMemcpyHostToDevice, g_rt.stream));   // (never stale here: stale implies devValid)
 	unsigned int one; { float f = 1.0f; memcpy(&one, &f, 4); }
 	HIP_OK(hipMemcpyAsync(g_rt.jobCounter, &one, sizeof(one), hipMemcpyHostToDevice, g_rt.stream));
 	const uint32_t blocks = (uint32_t)std::min<size_t>((n + RL_BLOCK - 1) / RL_BLOCK, 2048);
@@ -2515,11 +2540,11 @@ bool DevicePostProcess(Image& img)
 	HIP_OK(hipGetLastError());
 	hipLaunchKernelGGL(k_pp_map, dim3((uint32_t)((n + RL_BLOCK - 1) / RL_BLOCK)), dim3(RL_BLOCK), 0, g_rt.stream, px, n, g_rt.jobCounter);
 	HIP_OK(hipGetLastError());
-	HIP_OK(hipMemcpyAsync(img.rgba.data(), px, n * sizeof(float4), hipMemcpyDeviceToHost, g_rt.stream));
 	float white = 1.0f;
 	HIP_OK(hipMemcpyAsync(&white, g_rt.jobCounter, 4, hipMemcpyDeviceToHost, g_rt.stream));
 	HIP_OK(hipStreamSynchronize(g_rt.stream));
 	img.devValid = true;
+	img.hostStale = true;   // read back when the pixels are asked for (Image::SyncHost)
 	Log("Max white luminance: %f", white);
 	return true;
 }

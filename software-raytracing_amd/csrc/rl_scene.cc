@@ -157,6 +157,7 @@ void Scene::BuildAccel(float t0, float t1)
 // scan, extended Reinhard on luminance, clamp to white, gamma 1/2.2.
 void PostProcessHost(Image& img)
 {
+	img.SyncHost();
 	const size_t len = (size_t)img.width * img.height;
 	float maxWhiteLuminance = 1.0f;
 	for (size_t i = 0; i < len; ++i) {

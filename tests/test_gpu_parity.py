@@ -516,3 +516,54 @@ def test_bench_rccl_gather_path_with_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["config"]["frame_check"] == "assembled frame bit-identical to a one-GPU render"
+
+
+def test_deferred_readback_reaches_every_host_reader(gpu_lib, workdir):
+    """Raylib_Render and Raylib_PostProcess leave the frame on the device; the host pixels are fetched when something reads them.
+    Every reader must see the rendered frame: the two dump calls, the file writer (without a dump before it), an image used as a
+    sky panorama of another scene, and a second render into the same handle with a different viewport (reallocation)."""
+    from raylib_amd import binding
+    lib = gpu_lib
+    obj, c = helpers.build_case("cornell", workdir)
+    ses = binding.SceneSession(lib, obj, c["origin"], c["look_at"], 45.0, 32 / 24)
+    want = ses.render(32, 24, 4)                                     # SceneSession.render dumps RGBA
+    st = ses.settings(32, 24, 4)
+    # (1) writer straight after the render, no dump in between
+    img = lib.Raylib_CreateImage(32, 24)
+    lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, img)
+    bmp = os.path.join(str(workdir), "deferred.bmp")
+    assert lib.Raylib_WriteImageToDisk(img, bmp.encode(), 0) == 1
+    back = lib.Raylib_LoadImage(bmp.encode()); assert back
+    got8 = np.zeros((24, 32, 4), np.float32)
+    lib.RaylibAMD_DumpImageRGBA(back, got8.ctypes.data_as(C.POINTER(C.c_float)))
+    assert got8[..., :3].max() > 0.0                                 # not the cleared host buffer
+    ref8 = (((want[..., :3] * np.float32(255.0)).astype(np.uint32) & 0xff).astype(np.float32) / np.float32(255.0))   # image.h:62-69: no clamp
+    assert np.array_equal(got8[..., :3], ref8)
+    lib.Raylib_DestroyImage(back)
+    # (2) both dumps after the writer
+    rgba = np.zeros((24, 32, 4), np.float32)
+    lib.RaylibAMD_DumpImageRGBA(img, rgba.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(bits(rgba), bits(want))
+    rgb = np.zeros(24 * 32 * 3, np.float32)
+    lib.Raylib_DumpImageData(img, rgb.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(bits(rgb.reshape(24, 32, 3)), bits(want[..., :3]))
+    # (3) a rendered image as the sky of an empty scene: every camera ray returns a sky texel, none of them the cleared value
+    lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, img)       # stale again
+    sc = lib.Raylib_CreateScene(); lib.Raylib_SetSkyPanorama(sc, img); lib.Raylib_FinalizeScene(sc)
+    sky = lib.Raylib_CreateImage(16, 16)
+    st2 = binding.RendererSettings(16, 16, 1, 5, 0.0001, 0)
+    lib.Raylib_Render(C.byref(st2), sc, ses.camera, sky)
+    out = np.zeros((16, 16, 4), np.float32)
+    lib.RaylibAMD_DumpImageRGBA(sky, out.ctypes.data_as(C.POINTER(C.c_float)))
+    texels = {tuple(p) for p in bits(want[..., :3]).reshape(-1, 3)}
+    assert all(tuple(p) in texels for p in bits(out[..., :3]).reshape(-1, 3))
+    assert out[..., :3].max() > 0.0
+    lib.Raylib_DestroyScene(sc); lib.Raylib_DestroyImage(sky)
+    # (4) the same handle rendered at another size
+    st3 = ses.settings(24, 16, 1)
+    lib.Raylib_Render(C.byref(st3), ses.scene, ses.camera, img)
+    small = np.zeros(24 * 16 * 3, np.float32)
+    lib.Raylib_DumpImageData(img, small.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(small.reshape(16, 24, 3), ses.render(24, 16, 1)[..., :3])
+    lib.Raylib_DestroyImage(img)
+    ses.close()

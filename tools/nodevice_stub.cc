@@ -8,6 +8,7 @@ bool DeviceRender(Scene&, const RenderRequest&, RaylibAMDStats&) { return false;
 bool DeviceClosestHit(Scene&, const float*, int32_t, float, void*) { return false; }
 bool DevicePostProcess(Image&) { return false; }
 void* DeviceImagePixels(Image&) { return nullptr; }
+bool DeviceReadback(Image&) { return false; }
 void DeviceFreePixels(void*) {}
 bool DeviceEvalMath(int, const float*, const float*, int, float*) { return false; }
 bool DeviceEvalHook(int, Scene*, const DCamera*, int, int, const float*, int, uint64_t, float*) { return false; }
