@@ -222,12 +222,16 @@ def main():
         bytes_per_launch = acc["bytes"] / launches
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = None
+        valu = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(args.workload)
                 if rec and world == 1:
                     traffic = rec["hbm_bytes_per_launch"]
+                    # what actually binds this kernel (same PMC passes): VALU issue and the share of lanes doing work
+                    valu = {"busy_fraction": rec.get("valu_busy_fraction"), "lane_utilisation": rec.get("valu_lane_utilisation"),
+                            "insts_per_launch": rec.get("valu_insts_per_launch")}
             except Exception:
                 traffic = None
         out = {
@@ -250,7 +254,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_trace" if stats.pathsPerWave <= 64 else "k_trace_pool", "paths_per_wave": int(stats.pathsPerWave), "avg_launch_ms": avg_launch_ms, "launches": acc["launches"],
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "valu": valu,
                          "note": "rank 0's launches; algorithmic bytes = 64 B x (BVH nodes + triangle records + shading records) + 16 B x (texels + pixels)"},
         }
         if world == 1 and not args.no_cpu_baseline:
