@@ -44,6 +44,13 @@ namespace rl {
 #ifndef RL_REFILL_ROUNDS
 #define RL_REFILL_ROUNDS 4
 #endif
+// paths of up to this many vertices fetch all their vertex records before the fold's dependent chain (0: one fetch per step)
+#ifndef RL_FOLD_PREFETCH
+#define RL_FOLD_PREFETCH 5
+#endif
+#ifndef RL_FOLD_PREFETCH_POOL
+#define RL_FOLD_PREFETCH_POOL RL_FOLD_PREFETCH
+#endif
 
 // ---------------------------------------------------------------------------
 // device float3 (reference core/vec3.h conventions; see rl_host.h f3)
@@ -1096,6 +1103,30 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 			RL_STAMP(2);
 			if (done) {
 				// fold back to the camera: radiance = (0 + refl*Li*sp/pdf) + E at every vertex
+#if RL_FOLD_PREFETCH > 0
+				if (depth <= RL_FOLD_PREFETCH) {
+					// all vertex records of the path are fetched before the dependent chain starts (one memory latency instead of one per vertex)
+					float4 q0[RL_FOLD_PREFETCH], q1[RL_FOLD_PREFETCH];
+					#pragma unroll
+					for (int k = 0; k < RL_FOLD_PREFETCH; ++k) {
+						const int kk = k < depth ? k : 0;
+						const float4* st = (const float4*)pathStack + ((size_t)kk * P.stackStride + gtid) * 2u;
+						q0[k] = st[0]; q1[k] = st[1];
+					}
+					#pragma unroll
+					for (int k = RL_FOLD_PREFETCH - 1; k >= 0; --k) {
+						if (k < depth) {
+							const V3 refl = v3(q0[k].x, q0[k].y, q0[k].z);
+							const float sp = q0[k].w, pdf = q1[k].x;
+							const V3 E = v3(q1[k].y, q1[k].z, q1[k].w);
+							V3 radiance = v3s(0.0f);
+							radiance = radiance + refl * L * sp / pdf;
+							radiance = radiance + E;
+							L = radiance;
+						}
+					}
+				} else
+#endif
 				for (int k = depth - 1; k >= 0; --k) {
 					const float4* st = (const float4*)pathStack + ((size_t)k * P.stackStride + gtid) * 2u;
 					const float4 r0 = st[0], r1 = st[1];
@@ -1336,6 +1367,30 @@ __device__ __forceinline__ V3 MissSky(const DSceneView& S, const SkyRot& R, V3 d
 // in the reference's operation order (renderer.cc:139-151).
 __device__ __forceinline__ V3 FoldPath(const float* __restrict__ pathStack, uint32_t stackStride, uint32_t home, int depth, V3 L)
 {
+#if RL_FOLD_PREFETCH_POOL > 0
+	if (depth <= RL_FOLD_PREFETCH_POOL) {
+		float4 q0[RL_FOLD_PREFETCH_POOL], q1[RL_FOLD_PREFETCH_POOL];
+		#pragma unroll
+		for (int k = 0; k < RL_FOLD_PREFETCH_POOL; ++k) {
+			const int kk = k < depth ? k : 0;
+			const float4* rec = (const float4*)pathStack + ((size_t)kk * stackStride + home) * 2u;
+			q0[k] = rec[0]; q1[k] = rec[1];
+		}
+		#pragma unroll
+		for (int k = RL_FOLD_PREFETCH_POOL - 1; k >= 0; --k) {
+			if (k < depth) {
+				const V3 refl = v3(q0[k].x, q0[k].y, q0[k].z);
+				const float sp = q0[k].w, pdf = q1[k].x;
+				const V3 E = v3(q1[k].y, q1[k].z, q1[k].w);
+				V3 radiance = v3s(0.0f);
+				radiance = radiance + refl * L * sp / pdf;
+				radiance = radiance + E;
+				L = radiance;
+			}
+		}
+		return L;
+	}
+#endif
 	for (int k = depth - 1; k >= 0; --k) {
 		const float4* rec = (const float4*)pathStack + ((size_t)k * stackStride + home) * 2u;
 		const float4 r0 = rec[0], r1 = rec[1];
