@@ -188,6 +188,13 @@ struct RenderRequest {
 };
 bool DeviceAvailable();
 float ParseDecimalFloat(const char* token);   // csrc/rl_obj_loader.cc: the OBJ parser's number reader (= strtof, with exact fast paths)
+// Decoders refuse images beyond this many pixels (16384 x 16384), and images whose claimed size the file cannot plausibly hold:
+// a corrupt header must not turn into a multi-gigabyte allocation.
+constexpr uint64_t kMaxImagePixels = 1ull << 28;
+inline bool PlausibleImageSize(uint64_t w, uint64_t h, uint64_t fileBytes, uint64_t maxPixelsPerByte)
+{
+	return w > 0 && h > 0 && w <= 65535 && h <= 65535 && w * h <= kMaxImagePixels && w * h <= (fileBytes + 64) * maxPixelsPerByte;
+}
 // csrc/rl_jpeg.cc: top-down RGBA8
 bool DecodeJPEG(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 bool DecodeTGA(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);

@@ -8,6 +8,8 @@
 // 24-bit sources (ConvertTo32Bits), row 0 = top (image.cc:203-226).
 // JPEG is not decoded (returns null, like a failed FreeImage load: image.cc:161-165).
 #include "rl_host.h"
+#include <exception>
+#include <limits.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -72,9 +74,11 @@ Image* LoadBMP(const std::vector<uint8_t>& d)
 	uint16_t bpp = le16(&d[28]);
 	uint32_t comp = le32(&d[30]);
 	if ((bpp != 24 && bpp != 32) || (comp != 0 && comp != 3) || w <= 0 || h == 0) return nullptr;
+	if (h == INT32_MIN) return nullptr;
 	bool bottomUp = h > 0; if (h < 0) h = -h;
+	if (!PlausibleImageSize((uint64_t)w, (uint64_t)h, d.size(), 1)) return nullptr;   // uncompressed: at least 3 bytes per pixel
 	size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
-	if (d.size() < off + stride * h) return nullptr;
+	if (off > d.size() || d.size() - off < stride * (size_t)h) return nullptr;
 	std::vector<uint8_t> px((size_t)w * h * 4);
 	for (int32_t y = 0; y < h; ++y) {
 		const uint8_t* row = &d[off + stride * (bottomUp ? (h - 1 - y) : y)];
@@ -109,6 +113,7 @@ Image* LoadPNG(const std::vector<uint8_t>& d)
 	if (!w || !h || depth != 8 || interlace != 0) return nullptr;
 	int ch = color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : color == 6 ? 4 : 0;
 	if (!ch) return nullptr;
+	if (!PlausibleImageSize(w, h, idat.size(), 1100)) return nullptr;   // deflate expands by at most ~1032:1
 	size_t stride = (size_t)w * ch;
 	std::vector<uint8_t> raw((stride + 1) * h);
 	uLongf rawLen = (uLongf)raw.size();
@@ -158,6 +163,7 @@ Image* LoadHDR(const std::vector<uint8_t>& d)
 	if (!formatOk || !line(ln)) return nullptr;
 	int w = 0, h = 0;
 	if (sscanf(ln.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) return nullptr;
+	if (!PlausibleImageSize((uint64_t)w, (uint64_t)h, d.size(), 128)) return nullptr;   // RLE: a run byte pair covers at most 127 pixels of one channel
 	std::vector<uint8_t> row((size_t)w * 4);
 	Image* img = new Image;
 	img->width = (uint32_t)w; img->height = (uint32_t)h;
@@ -264,6 +270,7 @@ bool WritePNG(const Image& img, const char* path)
 Image* LoadImageFile(const char* path)
 {
 	if (path == nullptr) return nullptr;
+	try {
 	std::vector<uint8_t> d;
 	if (!ReadFile(path, d)) return nullptr;
 	if (Image* i = LoadPNG(d)) return i;
@@ -277,6 +284,9 @@ Image* LoadImageFile(const char* path)
 		    DecodeTGA(d, w, h, px)) return FromBytesRGBA(w, h, px);   // TGA has no signature: by extension, as FreeImage_GetFIFFromFilename does
 	}
 	Log("LoadImage: unsupported image format: %s (BMP, 8-bit PNG, JPEG (8-bit Huffman), TGA and Radiance HDR are decoded)", path);
+	} catch (const std::exception& e) {   // out of memory on a huge (but plausible) image: never across the C ABI
+		Log("LoadImage: %s: %s", path, e.what());
+	}
 	return nullptr;
 }
 

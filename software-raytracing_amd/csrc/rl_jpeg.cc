@@ -69,7 +69,8 @@ struct BitReader {
 			bits += 8;
 		}
 	}
-	int get(int n) { if (n == 0) return 0; fill(); int v = (int)(acc >> (32 - n)); acc <<= n; bits -= n; return v; }
+	// n: 1..16 in a valid stream (a magnitude category or an EOB-run length); a corrupt Huffman table can name any byte -> clamped
+	int get(int n) { if (n <= 0) return 0; if (n > 16) n = 16; fill(); int v = (int)(acc >> (32 - n)); acc <<= n; bits -= n; return v; }
 	int bit() { return get(1); }
 	int decode(const Huff& h)
 	{
@@ -84,29 +85,44 @@ struct BitReader {
 };
 inline int Extend(int v, int s) { return (s && v < (1 << (s - 1))) ? v - (1 << s) + 1 : v; }
 
+// 32-bit integer with two's-complement wrap-around: what libjpeg's INT32 arithmetic does in practice.  On valid streams nothing
+// wraps; on corrupt ones (coefficients far outside the 8-bit range) the result is garbage pixels, as with libjpeg, instead of
+// undefined behaviour.
+struct W32 {
+	uint32_t u;
+	W32() : u(0) {}
+	W32(int32_t v) : u((uint32_t)v) {}
+	int32_t s() const { return (int32_t)u; }
+};
+inline W32 operator+(W32 a, W32 b) { W32 r; r.u = a.u + b.u; return r; }
+inline W32 operator-(W32 a, W32 b) { W32 r; r.u = a.u - b.u; return r; }
+inline W32 operator*(W32 a, W32 b) { W32 r; r.u = a.u * b.u; return r; }
+inline W32 Sar8(W32 a) { return W32(a.s() >> 8); }
+
 // jidctfst.c with the IFAST multipliers of jddctmgr.c; out: 64 samples 0..255
 void IdctIfast(const int16_t* coef, const int32_t* mult, uint8_t* out)
 {
-	const int32_t F1_082 = 277, F1_414 = 362, F1_847 = 473, F2_613 = 669;
-	#define JMUL(v, c) (((v) * (c)) >> 8)
-	int32_t ws[64];
+	const W32 F1_082 = 277, F1_414 = 362, F1_847 = 473, F2_613 = 669, NEG_F2_613 = -669;
+	#define JMUL(v, c) Sar8((v) * (c))
+	W32 ws[64];
 	for (int c = 0; c < 8; ++c) {
-		const int16_t* in = coef + c; const int32_t* q = mult + c; int32_t* w = ws + c;
-		int32_t tmp0 = in[0] * q[0], tmp1 = in[16] * q[16], tmp2 = in[32] * q[32], tmp3 = in[48] * q[48];
-		int32_t tmp10 = tmp0 + tmp2, tmp11 = tmp0 - tmp2;
-		int32_t tmp13 = tmp1 + tmp3, tmp12 = JMUL(tmp1 - tmp3, F1_414) - tmp13;
+		const int16_t* in = coef + c; const int32_t* q = mult + c; W32* w = ws + c;
+		W32 tmp0 = W32(in[0]) * W32(q[0]), tmp1 = W32(in[16]) * W32(q[16]), tmp2 = W32(in[32]) * W32(q[32]), tmp3 = W32(in[48]) * W32(q[48]);
+		W32 tmp10 = tmp0 + tmp2, tmp11 = tmp0 - tmp2;
+		W32 tmp13 = tmp1 + tmp3, tmp12 = JMUL(tmp1 - tmp3, F1_414) - tmp13;
 		tmp0 = tmp10 + tmp13; tmp3 = tmp10 - tmp13; tmp1 = tmp11 + tmp12; tmp2 = tmp11 - tmp12;
-		int32_t tmp4 = in[8] * q[8], tmp5 = in[24] * q[24], tmp6 = in[40] * q[40], tmp7 = in[56] * q[56];
-		int32_t z13 = tmp6 + tmp5, z10 = tmp6 - tmp5, z11 = tmp4 + tmp7, z12 = tmp4 - tmp7;
+		W32 tmp4 = W32(in[8]) * W32(q[8]), tmp5 = W32(in[24]) * W32(q[24]), tmp6 = W32(in[40]) * W32(q[40]), tmp7 = W32(in[56]) * W32(q[56]);
+		W32 z13 = tmp6 + tmp5, z10 = tmp6 - tmp5, z11 = tmp4 + tmp7, z12 = tmp4 - tmp7;
 		tmp7 = z11 + z13; tmp11 = JMUL(z11 - z13, F1_414);
-		int32_t z5 = JMUL(z10 + z12, F1_847);
+		W32 z5 = JMUL(z10 + z12, F1_847);
 		tmp10 = JMUL(z12, F1_082) - z5;
-		tmp12 = JMUL(z10, -F2_613) + z5;
+		tmp12 = JMUL(z10, NEG_F2_613) + z5;
 		tmp6 = tmp12 - tmp7; tmp5 = tmp11 - tmp6; tmp4 = tmp10 + tmp5;
 		w[0] = tmp0 + tmp7; w[56] = tmp0 - tmp7; w[8] = tmp1 + tmp6; w[48] = tmp1 - tmp6;
 		w[16] = tmp2 + tmp5; w[40] = tmp2 - tmp5; w[32] = tmp3 + tmp4; w[24] = tmp3 - tmp4;
 	}
-	auto limit = [](int32_t x) -> uint8_t {
+	auto limit = [](W32 xw) -> uint8_t {
+		const int32_t x = xw.s();
 		// range_limit[(x >> 5) & RANGE_MASK] of the IDCT table (jdmaster.c prepare_range_limit_table), CENTERJSAMPLE folded in
 		const int idx = (x >> 5) & 1023;
 		if (idx < 128) return (uint8_t)(128 + idx);
@@ -115,16 +131,16 @@ void IdctIfast(const int16_t* coef, const int32_t* mult, uint8_t* out)
 		return (uint8_t)(idx - 896);
 	};
 	for (int r = 0; r < 8; ++r) {
-		const int32_t* w = ws + 8 * r; uint8_t* o = out + 8 * r;
-		int32_t tmp10 = w[0] + w[4], tmp11 = w[0] - w[4];
-		int32_t tmp13 = w[2] + w[6], tmp12 = JMUL(w[2] - w[6], F1_414) - tmp13;
-		int32_t tmp0 = tmp10 + tmp13, tmp3 = tmp10 - tmp13, tmp1 = tmp11 + tmp12, tmp2 = tmp11 - tmp12;
-		int32_t z13 = w[5] + w[3], z10 = w[5] - w[3], z11 = w[1] + w[7], z12 = w[1] - w[7];
-		int32_t tmp7 = z11 + z13; tmp11 = JMUL(z11 - z13, F1_414);
-		int32_t z5 = JMUL(z10 + z12, F1_847);
+		const W32* w = ws + 8 * r; uint8_t* o = out + 8 * r;
+		W32 tmp10 = w[0] + w[4], tmp11 = w[0] - w[4];
+		W32 tmp13 = w[2] + w[6], tmp12 = JMUL(w[2] - w[6], F1_414) - tmp13;
+		W32 tmp0 = tmp10 + tmp13, tmp3 = tmp10 - tmp13, tmp1 = tmp11 + tmp12, tmp2 = tmp11 - tmp12;
+		W32 z13 = w[5] + w[3], z10 = w[5] - w[3], z11 = w[1] + w[7], z12 = w[1] - w[7];
+		W32 tmp7 = z11 + z13; tmp11 = JMUL(z11 - z13, F1_414);
+		W32 z5 = JMUL(z10 + z12, F1_847);
 		tmp10 = JMUL(z12, F1_082) - z5;
-		tmp12 = JMUL(z10, -F2_613) + z5;
-		int32_t tmp6 = tmp12 - tmp7, tmp5 = tmp11 - tmp6, tmp4 = tmp10 + tmp5;
+		tmp12 = JMUL(z10, NEG_F2_613) + z5;
+		W32 tmp6 = tmp12 - tmp7, tmp5 = tmp11 - tmp6, tmp4 = tmp10 + tmp5;
 		o[0] = limit(tmp0 + tmp7); o[7] = limit(tmp0 - tmp7); o[1] = limit(tmp1 + tmp6); o[6] = limit(tmp1 - tmp6);
 		o[2] = limit(tmp2 + tmp5); o[5] = limit(tmp2 - tmp5); o[4] = limit(tmp3 + tmp4); o[3] = limit(tmp3 - tmp4);
 	}
@@ -179,6 +195,7 @@ struct Decoder {
 				progressive = (m == 0xC2);
 				height = (b[1] << 8) | b[2]; width = (b[3] << 8) | b[4]; ncomp = b[5];
 				if (!width || !height || (ncomp != 1 && ncomp != 3) || bl < 6 + 3 * (size_t)ncomp) return false;
+				if (!PlausibleImageSize((uint64_t)width, (uint64_t)height, (uint64_t)n, 4096)) return false;   // a scan cannot be that much smaller than its picture
 				for (int c = 0; c < ncomp; ++c) {
 					comp[c].id = b[6 + 3 * c]; comp[c].h = b[7 + 3 * c] >> 4; comp[c].v = b[7 + 3 * c] & 15; comp[c].tq = b[8 + 3 * c] & 3;
 					if (comp[c].h < 1 || comp[c].h > 4 || comp[c].v < 1 || comp[c].v > 4) return false;
@@ -283,7 +300,7 @@ struct Decoder {
 		if (!progressive) {
 			const Huff& hd = dc[C.td]; const Huff& ha = ac[C.ta];
 			if (!hd.present || !ha.present) return false;
-			int s = br.decode(hd);
+			int s = br.decode(hd); if (s > 16) s = 16;   // DC category: <= 11 in a valid 8-bit stream; a corrupt table can name any byte
 			int diff = s ? Extend(br.get(s), s) : 0;
 			C.pred += diff; blk[0] = (int16_t)C.pred;
 			for (int k = 1; k < 64;) {
@@ -297,7 +314,7 @@ struct Decoder {
 		if (Ss == 0) {
 			if (Ah == 0) {
 				const Huff& hd = dc[C.td]; if (!hd.present) return false;
-				const int s = br.decode(hd);
+				int s = br.decode(hd); if (s > 16) s = 16;
 				const int diff = s ? Extend(br.get(s), s) : 0;
 				C.pred += diff; blk[0] = (int16_t)(C.pred * (1 << Al));
 			} else if (br.bit()) blk[0] = (int16_t)(blk[0] | (1 << Al));
@@ -415,6 +432,7 @@ bool DecodeTGA(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::vec
 	w = (uint32_t)(d[12] | (d[13] << 8)); h = (uint32_t)(d[14] | (d[15] << 8));
 	const int bpp = d[16], desc = d[17];
 	if (!w || !h || cmapType > 1) return false;
+	if (!PlausibleImageSize(w, h, d.size(), 128)) return false;   // RLE packets: at most 128 pixels per 2 bytes
 	const bool rle = type >= 9;
 	const int base = rle ? type - 8 : type;
 	if (base < 1 || base > 3) return false;

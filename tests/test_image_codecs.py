@@ -125,3 +125,38 @@ def test_jpeg_writer_roundtrip(lib, workdir):
         assert os.path.getsize(path) <= 1.25 * len(bio.getvalue()) + 64
         fast = _turbo_fast_decode(open(path, "rb").read()).astype(np.float32)
         assert np.array_equal(np.rint(mine), fast)       # the library's decoder on the library's file = libjpeg's fast path, bit for bit
+
+
+def test_corrupt_files_are_refused_or_decoded_without_harm(lib, tmp_path):
+    """What the sanitizer fuzz (tools/fuzz_codecs.py) found, pinned: a header that claims an enormous picture must be refused before anything
+    is allocated for it; a Huffman table naming an impossible magnitude category and coefficients far outside the 8-bit range must decode
+    to *something* (as libjpeg does) without undefined behaviour.  Plus a short mutation run over every format."""
+    import struct, subprocess, sys, zlib
+    def load(name, data):
+        p = tmp_path / name; p.write_bytes(data)
+        h = lib.Raylib_LoadImage(str(p).encode())
+        if h: lib.Raylib_DestroyImage(h)
+        return bool(h)
+    # PNG whose IHDR claims 60000 x 60000 with a 20-byte IDAT
+    def chunk(t, b): return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 60000, 60000, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b"")
+    assert not load("huge.png", png)
+    # BMP / TGA / HDR headers with absurd sizes
+    bmp = bytearray(b"BM" + b"\0" * 52); struct.pack_into("<I", bmp, 10, 54); struct.pack_into("<ii", bmp, 18, 0x7fffffff, -0x80000000); struct.pack_into("<H", bmp, 28, 24)
+    assert not load("huge.bmp", bytes(bmp))
+    tga = bytearray(18); tga[2] = 10; struct.pack_into("<HH", tga, 12, 65535, 65535); tga[16] = 32
+    assert not load("huge.tga", bytes(tga) + b"\xff\0\0\0\0")
+    assert not load("huge.hdr", b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2000000000 +X 2000000000\n" + b"\0" * 64)
+    # a JPEG whose DC table maps the shortest code to "category 255", and one with every entropy-coded byte set to 0x7f
+    im = _picture(40, 32, 3); b = io.BytesIO(); im.save(b, "JPEG", quality=85); good = bytearray(b.getvalue())
+    i = good.find(b"\xff\xc4"); assert i > 0
+    bad = bytearray(good); n = (bad[i + 2] << 8) | bad[i + 3]
+    for k in range(i + 4 + 17, i + 2 + n): bad[k] = 255                      # every symbol of the first table becomes 255
+    load("dc255.jpg", bytes(bad))                                            # either outcome is fine; it must return
+    sos = good.find(b"\xff\xda"); bad = bytearray(good)
+    for k in range(sos + 14, len(bad) - 2): bad[k] = 0x7f
+    load("flood.jpg", bytes(bad))
+    # mutation run (the sanitizer build runs the same script for tens of thousands of files)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_codecs.py"), "400", "5"], capture_output=True, text=True, timeout=300)
+    assert "no crash" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]

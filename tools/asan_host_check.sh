@@ -11,3 +11,7 @@ cd "$ROOT"
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
 LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so)" RAYLIB_LIB="$OUT" \
     python -m pytest tests/test_host_logic.py tests/test_image_codecs.py -x -q
+# mutation fuzz of the image decoders under the same sanitizers (a decoder may refuse a file; it must not misbehave)
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:allocator_may_return_null=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so)" RAYLIB_LIB="$OUT" \
+    python tools/fuzz_codecs.py ${FUZZ_FILES:-6000} ${FUZZ_SEED:-1} | tail -1
