@@ -15,3 +15,6 @@ LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.s
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:allocator_may_return_null=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
 LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so)" RAYLIB_LIB="$OUT" \
     python tools/fuzz_codecs.py ${FUZZ_FILES:-6000} ${FUZZ_SEED:-1} | tail -1
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:allocator_may_return_null=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so)" RAYLIB_LIB="$OUT" \
+    python tools/fuzz_obj.py ${FUZZ_OBJ_FILES:-2000} ${FUZZ_SEED:-1} | tail -1
