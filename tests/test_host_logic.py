@@ -411,3 +411,29 @@ def test_chunked_obj_reader_matches_oracle_side_parser_on_a_multi_megabyte_file(
     ses.close()
     assert len(tris) == n == len(flat.triangles)
     assert tris.tobytes() == flat.triangles.tobytes() and mats.tobytes() == flat.materials.tobytes()
+
+
+def test_null_arguments_are_survivable(lib):
+    """Errors are return codes, never a crash across the C ABI (reference raylib.cc checks only the destroy paths; a null handle there is UB,
+    here every export takes null handles / null pointers and returns).  Run under ASan + UBSan by tools/asan_host_check.sh."""
+    from raylib_amd import binding
+    st = binding.RendererSettings(16, 16, 1, 5, 1e-4, 0)
+    calls = [
+     ("Raylib_LoadOBJModel", (None,)), ("Raylib_LoadOBJModel", (b"/nonexistent.obj",)), ("Raylib_TransformOBJModel", (0, 0,0,0, 0,0,0, 1,1,1)), ("Raylib_FinalizeOBJModel", (0,)), ("Raylib_UnloadOBJModel", (0,)),
+     ("Raylib_LoadImage", (None,)), ("Raylib_LoadImage", (b"/nonexistent.png",)), ("Raylib_AddSceneElement", (0, 0)), ("Raylib_AddOBJModelToScene", (0, 0)), ("Raylib_SetSkyPanorama", (0, 0)),
+     ("Raylib_SetSunIlluminance", (0, 1.0, 1.0, 1.0)), ("Raylib_SetSunDirection", (0, 0.0, -1.0, 0.0)), ("Raylib_FinalizeScene", (0,)), ("Raylib_DestroyScene", (0,)),
+     ("Raylib_CameraSetPosition", (0, 0.0, 0.0, 0.0)), ("Raylib_CameraSetLookAt", (0, 0.0, 0.0, 0.0)), ("Raylib_CameraSetPerspective", (0, 45.0, 1.0)), ("Raylib_CameraSetLens", (0, 0.0, 1.0)), ("Raylib_CameraSetMotion", (0, 0.0, 0.0)),
+     ("Raylib_CameraCopy", (0, 0)), ("Raylib_DestroyCamera", (0,)), ("Raylib_DumpImageData", (0, None)), ("Raylib_DestroyImage", (0,)), ("Raylib_Render", (None, 0, 0, 0)), ("Raylib_Render", (C.byref(st), 0, 0, 0)),
+     ("Raylib_Denoise", (0, 0, 0, 0, 0)), ("Raylib_PostProcess", (0,)), ("Raylib_GetRenderModeString", (99,)), ("Raylib_WriteImageToDisk", (0, None, 0)), ("Raylib_WriteImageToDisk", (0, b"/tmp/x.png", 7)),
+     ("RaylibAMD_RenderDevice", (None, 0, 0, 0, 1, None)), ("RaylibAMD_RenderDevice", (C.byref(st), 0, 0, 0, 1, None)), ("RaylibAMD_SceneNumTriangles", (0,)), ("RaylibAMD_SceneBVHHash", (0,)),
+     ("RaylibAMD_ImageSize", (0, None, None)), ("RaylibAMD_DumpImageRGBA", (0, None)), ("RaylibAMD_DestroyMaterial", (0,)), ("RaylibAMD_DestroySceneElement", (0,)), ("RaylibAMD_GetLastStats", (None,)),
+     ("RaylibAMD_ParseFloat", (None,)), ("RaylibAMD_CameraExport", (0, None)), ("RaylibAMD_OBJModelSetTexture", (0, None, 0, 0)),
+    ]
+    # with live objects but null partners
+    img = lib.Raylib_CreateImage(8, 8); sc = lib.Raylib_CreateScene(); cam = lib.Raylib_CreateCamera()
+    calls += [("Raylib_Render", (C.byref(st), sc, 0, img)), ("Raylib_Render", (C.byref(st), 0, cam, img)), ("Raylib_Render", (C.byref(st), sc, cam, 0)), ("Raylib_SetSkyPanorama", (sc, 0)),
+              ("Raylib_AddOBJModelToScene", (sc, 0)), ("Raylib_AddSceneElement", (sc, 0)), ("Raylib_DumpImageData", (img, None)), ("Raylib_WriteImageToDisk", (img, None, 0)), ("Raylib_CameraCopy", (cam, 0)), ("Raylib_CameraCopy", (0, cam))]
+    for name, args in calls:
+        getattr(lib, name)(*args)
+    for h, fn in ((img, lib.Raylib_DestroyImage), (sc, lib.Raylib_DestroyScene), (cam, lib.Raylib_DestroyCamera)):
+        assert fn(h) == 1
