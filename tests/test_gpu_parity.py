@@ -569,15 +569,16 @@ def test_deferred_readback_reaches_every_host_reader(gpu_lib, workdir):
     ses.close()
 
 
-@pytest.mark.parametrize("name", ["cornell"])   # cornell_glass_sun: the two defined variants disagree on half of the pixels -- open item, DESIGN section 7
-def test_reflectance_aov_matches_the_oracle_definition(name, sessions, gpu_lib, oracle, workdir):
-    """Mode 6 (and 3) read an uninitialised tangent frame in the reference (renderer.cc:89-93,104-108), so no reference fixture exists.  The
+@pytest.mark.parametrize("name", ["cornell", "cornell_glass_sun"])
+def test_reflectance_and_microsurface_aovs_match_the_oracle_definition(name, sessions, gpu_lib, oracle, workdir):
+    """Modes 3 and 6 read an uninitialised tangent frame in the reference (renderer.cc:89-93,104-108), so no reference fixture exists.  The
     defined variant -- the frame built first, as TraceScene does -- is what the oracle restates; the device must give the same bits, including
-    the random draws Scatter makes after the camera ray's.  (Mode 3: see test_aov_modes_bit_exact_vs_reference_goldens.)"""
+    the random draws Scatter makes after the camera ray's (open aperture and shutter in the second case)."""
     ses = sessions[name]
     obj, c, flat = helpers.flat_for_case(name, workdir, oracle)
-    cam = ffi.make_camera(c["origin"], c["look_at"], c["fov"], c["aspect"])
+    cam = helpers.camera_for_case(c)
     scene = oracle.scene_create(flat, 1)
-    ties = tie_mask(oracle, flat, cam, 64, 64)
-    want = oracle.render(scene, cam, ffi.make_settings(64, 64, 1, mode=6), seed=1)
-    assert_same_outside_ties(ses.render(64, 64, 1, mode=6), want, ties, "mode 6 of %s" % name)
+    ties = tie_mask(oracle, flat, ffi.make_camera(c["origin"], c["look_at"], c["fov"], c["aspect"]), 64, 64)
+    for mode in (6, 3):
+        want = oracle.render(scene, cam, ffi.make_settings(64, 64, 1, mode=mode), seed=1)
+        assert_same_outside_ties(ses.render(64, 64, 1, mode=mode), want, ties, "mode %d of %s" % (mode, name))
