@@ -211,7 +211,7 @@ CONFIG_CAMERAS = {
 
 # ---------------------------------------------------------------------------------
 # Textured / cut-out test scene (exercises map_Kd, sRGB decode, alpha test inside
-# traversal, the emissive-texture path and the sky panorama)
+# traversal and the sky panorama; the other map slots: pbr_maps below)
 
 CUTOUT_MTL = """
 newmtl cutout
@@ -259,6 +259,146 @@ def cutout(path, tess=1):
     objs.append(("card", CUTOUT, [_quad((-0.6, 0.2, 0.7), (0.6, 0.2, 0.7), (0.6, 1.4, 0.7), (-0.6, 1.4, 0.7))]))
     obj, n = write_obj(path, objs, CORNELL_MTL, tess=tess, extra_mtl=CUTOUT_MTL)
     write_png_rgba(os.path.join(os.path.dirname(os.path.abspath(path)), "leaf.png"), leaf_texture())
+    return obj, n
+
+
+# ---------------------------------------------------------------------------------
+# PBR test scene: every MicrofacetMaterial input the MTL path can set (reference
+# loader/obj_loader.cc:372-395, render/material.cc:290-431) away from the Cornell
+# defaults -- roughness in (0,1) from `Pr` and from the Phong pair `Ns`/`Ks`, metallic
+# > 0, a normal map through `norm` and through the `map_bump` fallback, `map_Pr`,
+# `map_Pm`, `map_Ke` (the (U,U) / .b quirk of Emitted), an albedo map with partial
+# alpha (GetAlbedo multiplies by it) and a surface with roughness < 0.1 (IsMirrorLike
+# in the albedo AOV).
+
+FLOOR_PR, PHONG, MAPPED, BUMPED, GLOSSY, BRUSHED, EMITMAP = "floor_pr", "phong", "mapped", "bumped", "glossy", "brushed", "emitmap"
+
+PBR_MTL = """
+newmtl floor_pr
+Kd 0.6 0.5 0.4
+Pr 0.35
+Pm 0.7
+
+newmtl phong
+Kd 0.7 0.7 0.7
+Ns 96
+Ks 0.5 0.5 0.5
+illum 2
+
+newmtl mapped
+Kd 0.8 0.8 0.8
+Ns 40
+Ks 0.3 0.2 0.1
+map_Kd pbr_albedo%(ext_albedo)s
+norm pbr_normal%(ext_normal)s
+map_Pr pbr_rough%(ext_rough)s
+map_Pm pbr_metal%(ext_metal)s
+
+newmtl bumped
+Kd 0.3 0.5 0.7
+Pr 0.6
+Pm 0.2
+map_bump pbr_normal%(ext_normal)s
+
+newmtl glossy
+Kd 0.9 0.6 0.3
+Pr 0.05
+Pm 1
+
+newmtl brushed
+Kd 0.95 0.93 0.88
+Pr 0.25
+Pm 1.0
+Ke 0.02 0.01 0.0
+
+newmtl emitmap
+Kd 0.2 0.2 0.2
+Ke 1 1 1
+map_Ke pbr_emit%(ext_emit)s
+"""
+
+
+def pbr_textures():
+    """name -> (H, W, 4) uint8.  Sizes differ per map and are not powers of two."""
+    out = {}
+    h, w = 12, 20
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.zeros((h, w, 4), np.uint8)
+    a[..., 0] = 60 + 9 * xx; a[..., 1] = 200 - 11 * yy; a[..., 2] = 90 + 5 * ((xx + yy) % 7)
+    a[..., 3] = np.where((xx + 2 * yy) % 5 == 0, 180, 255)          # partial alpha, all above the 0.5 cut-out
+    out["pbr_albedo"] = a
+    h, w = 16, 16
+    yy, xx = np.mgrid[0:h, 0:w]
+    n = np.zeros((h, w, 4), np.uint8)
+    n[..., 0] = np.clip(128 + 70 * np.sin(xx * 0.9), 0, 255); n[..., 1] = np.clip(128 + 60 * np.cos(yy * 0.7), 0, 255)
+    n[..., 2] = 230; n[..., 3] = 255
+    out["pbr_normal"] = n
+    h, w = 9, 13
+    yy, xx = np.mgrid[0:h, 0:w]
+    r = np.zeros((h, w, 4), np.uint8)
+    r[..., 0] = 8 + (17 * xx + 23 * yy) % 230                       # 0.03 .. 0.93: both sides of IsMirrorLike's 0.1
+    r[..., 1] = 255 - r[..., 0]; r[..., 2] = 40; r[..., 3] = 255    # .g / .b must not be what is read
+    out["pbr_rough"] = r
+    h, w = 7, 5
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = np.zeros((h, w, 4), np.uint8)
+    m[..., 0] = (xx * 63) % 256; m[..., 1] = 10; m[..., 2] = 250; m[..., 3] = 255
+    m[0, 0, 0] = 255
+    out["pbr_metal"] = m
+    h, w = 10, 10
+    yy, xx = np.mgrid[0:h, 0:w]
+    e = np.zeros((h, w, 4), np.uint8)
+    e[..., 0] = 255; e[..., 1] = 12 * yy; e[..., 2] = 25 * ((xx + yy) % 10); e[..., 3] = 255   # only .b reaches the image
+    out["pbr_emit"] = e
+    return out
+
+
+def random_pbr_mtl(rng):
+    """PBR_MTL's material names with random constants and a random subset of the map statements (fuzzing)."""
+    maps = (("map_Kd", "pbr_albedo"), ("norm", "pbr_normal"), ("map_bump", "pbr_normal"), ("map_Pr", "pbr_rough"),
+            ("map_Pm", "pbr_metal"), ("map_Ke", "pbr_emit"))
+    out = []
+    for name in (FLOOR_PR, PHONG, MAPPED, BUMPED, GLOSSY, BRUSHED, EMITMAP):
+        out.append("newmtl %s" % name)
+        out.append("Kd %s %s %s" % tuple(_f(x) for x in rng.uniform(0.05, 1.0, 3)))
+        if rng.rand() < 0.5:
+            out.append("Pr %s" % _f(rng.choice([0.02, 0.08, 0.1, 0.3, 0.7, 1.0, 1.5]) if rng.rand() < 0.5 else rng.uniform(0.01, 1.0)))
+        else:
+            out.append("Ns %s" % _f(rng.choice([1.0, 10.0, 96.0, 400.0, 1000.0])))
+            out.append("Ks %s %s %s" % tuple(_f(x) for x in rng.uniform(0.0, 1.0, 3)))
+        if rng.rand() < 0.6:
+            out.append("Pm %s" % _f(rng.choice([0.0, 0.5, 1.0, 1.7]) if rng.rand() < 0.5 else rng.uniform(0.0, 1.0)))
+        if rng.rand() < 0.3:
+            out.append("Ke %s %s %s" % tuple(_f(x) for x in rng.uniform(0.0, 3.0, 3)))
+        for stmt, tex in maps:
+            if rng.rand() < 0.35:
+                out.append("%s %s.png" % (stmt, tex))
+        out.append("")
+    return "\n".join(out) + "\n"
+
+
+def pbr_maps(path, tess=1, ext=None, mtl=None):
+    """Cornell-shaped room whose surfaces carry the materials of PBR_MTL (or of `mtl`, same material names).  `ext` maps a
+    texture name to the file extension its MTL statement uses (default .png for all); the caller writes non-PNG files itself."""
+    ext = dict(ext or {})
+    objs = [
+        ("floor", FLOOR_PR, [_quad((-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1))]),
+        ("ceiling", WHITE, [_quad((-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1))]),
+        ("backwall", PHONG, [_quad((-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1))]),
+        ("leftwall", MAPPED, [_quad((-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1))]),
+        ("rightwall", BUMPED, [_quad((1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1))]),
+        ("light", LIGHT, [_quad((-0.24, 1.98, -0.22), (0.23, 1.98, -0.22), (0.23, 1.98, 0.16), (-0.24, 1.98, 0.16))]),
+        ("sign", EMITMAP, [_quad((-0.5, 1.2, -0.97), (0.5, 1.2, -0.97), (0.5, 1.8, -0.97), (-0.5, 1.8, -0.97))]),
+        ("shortbox", GLOSSY, _box((0.33, 0.3 + 1.0 / 1024, 0.35), (0.6, 0.6, 0.6), -17.0)),
+        ("tallbox", BRUSHED, _box((-0.33, 0.6 + 1.0 / 1024, -0.3), (0.6, 1.2, 0.6), 17.0)),
+        ("panel", MAPPED, [_quad((0.15, 0.05, 0.95), (0.85, 0.05, 0.8), (0.85, 0.75, 0.8), (0.15, 0.75, 0.95))]),
+    ]
+    names = {"ext_" + k[4:]: ext.get(k, ".png") for k in ("pbr_albedo", "pbr_normal", "pbr_rough", "pbr_metal", "pbr_emit")}
+    obj, n = write_obj(path, objs, CORNELL_MTL, tess=tess, extra_mtl=(PBR_MTL % names) if mtl is None else mtl)
+    d = os.path.dirname(os.path.abspath(path))
+    for name, img in pbr_textures().items():
+        if ext.get(name, ".png") == ".png":
+            write_png_rgba(os.path.join(d, name + ".png"), img)
     return obj, n
 
 

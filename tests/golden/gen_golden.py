@@ -18,7 +18,12 @@ from helpers import ffi, scenes, objflat  # noqa: E402
 SEED, BUILD_SEED = 1, 1
 
 
-def main():
+def main(only=None):
+    """only: names of fixture files to (re)generate (default all) -- np.savez output is not byte-reproducible (zip time stamps),
+    so unchanged fixtures are better left alone."""
+    def want(name):
+        return only is None or name in only
+
     ref = ffi.load_ref(True)
     assert ref is not None and ref.lib.ref_is_seeded() == 1, "build oracle/_ref first (make -C oracle ref)"
     orc = ffi.load_oracle()   # only for the MTL rule inside objflat (not reference-pinned; see objflat.py)
@@ -26,6 +31,8 @@ def main():
 
     # ---- image-level goldens ------------------------------------------------------
     for name in helpers.CASES:
+        if not want(name):
+            continue
         obj, c, flat = helpers.flat_for_case(name, tmp, orc)
         scene = ref.scene_create(flat, BUILD_SEED)
         cam = helpers.camera_for_case(c)
@@ -59,6 +66,16 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, "done", {k: v.shape for k, v in out.items() if k.startswith("mode0_spp")})
 
+    # ---- BASELINE configs[0]: Cornell box 256x256, 4 spp, the reference's CPU path ---------------
+    if want("config0"):
+        obj, c, flat = helpers.flat_for_case("cornell", tmp, orc)
+        scene = ref.scene_create(flat, BUILD_SEED)
+        img = ref.render(scene, helpers.camera_for_case(c), ffi.make_settings(256, 256, 4), seed=SEED)
+        np.savez_compressed(os.path.join(HERE, "config0.npz"), mode0_256x256_spp4=img)
+        print("config0 done", img.shape, float(img[..., :3].mean()))
+
+    if only is not None and not (want("procedural") or want("kat") or want("soup")):
+        return
     # ---- procedural scene: spheres, a moving cube, Metal / DiffuseLight / Dielectric / Mirror -----------------------
     flat, c = helpers.procedural_flat()
     scene = ref.scene_create(flat, BUILD_SEED)
@@ -128,4 +145,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]) or None)

@@ -17,8 +17,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def texture_loader(path):
     """What the product must decode from leaf.png, straight from the generator."""
-    if os.path.basename(path) == "leaf.png":
+    name = os.path.basename(path)
+    if name == "leaf.png":
         return scenes.texture_as_float(scenes.leaf_texture())
+    stem, ext = os.path.splitext(name)
+    if ext == ".png" and stem in scenes.pbr_textures():
+        return scenes.texture_as_float(scenes.pbr_textures()[stem])
     return None
 
 
@@ -34,7 +38,13 @@ CASES = {
                                  sun=(0, 0, 0), sun_dir=(0.0, -1.0, -0.5), sky=False),
     "cutout_sky": dict(gen=scenes.cutout, kw={}, origin=(0, 1, 4), look_at=(0, 1, -1), fov=45.0, aspect=1.0,
                        aperture=0.0, focal=1.0, shutter=(0.0, 0.0), sun=(3, 3, 3), sun_dir=(0.1, -0.2, -1.0), sky=True),
+    # MicrofacetMaterial away from the Cornell defaults: roughness in (0,1) from Pr and from Ns/Ks, metallic > 0, normal /
+    # roughness / metallic / emissive maps, a mirror-like (roughness < 0.1) surface (scenes.pbr_maps)
+    "pbr_maps": dict(gen=scenes.pbr_maps, kw={}, origin=(0.1, 1.1, 4), look_at=(0, 0.95, -1), fov=45.0, aspect=1.0,
+                     aperture=0.0, focal=1.0, shutter=(0.0, 0.0), sun=(0, 0, 0), sun_dir=(0.0, -1.0, -0.5), sky=False),
 }
+# cases without a normal map: the microsurface-normal AOV must equal the surface-normal AOV
+NO_NORMAL_MAP = ("cornell", "cornell_glass_sun", "cornell_flat_normals")
 
 
 def build_case(name, tmpdir):

@@ -100,7 +100,7 @@ def test_aov_modes_bit_exact_vs_reference_goldens(name, sessions, gpu_lib, oracl
         assert_same_outside_ties(ses.render(64, 64, 1, mode=mode), g["mode%d" % mode], ties, "mode %d of %s" % (mode, name))
     # mode 3 (microsurface normal) has no golden: the reference reads an uninitialised tangent frame there
     # (renderer.cc:89-93).  Without a normal map it must equal the surface-normal AOV.
-    if name != "cutout_sky":
+    if name in helpers.NO_NORMAL_MAP:
         assert np.array_equal(bits(ses.render(64, 64, 1, mode=3)), bits(ses.render(64, 64, 1, mode=2)))
 
 
@@ -117,6 +117,17 @@ def test_path_tracing_vs_reference_goldens(name, sessions, gpu_lib, oracle, work
         assert_same_outside_ties(img, want, ties, "%s spp %d" % (name, spp))
         keep = ~ties
         assert l2(img[keep], want[keep]) < L2_TOL
+
+
+def test_config0_cornell_256_4spp_vs_reference_golden(sessions, oracle, workdir):
+    """BASELINE configs[0] at its own size: Cornell box 256x256, 4 spp.  The fixture is the reference's CPU render (oracle/_ref); the
+    product has no CPU path, so this is the HIP path on the plumbing config."""
+    g = golden("config0")["mode0_256x256_spp4"]
+    obj, c, flat = helpers.flat_for_case("cornell", workdir, oracle)
+    img = sessions["cornell"].render(256, 256, 4)
+    ties = tie_mask(oracle, flat, helpers.camera_for_case(c), 256, 256)
+    assert_same_outside_ties(img, g, ties, "config0")
+    assert l2(img[~ties], g[~ties]) < L2_TOL
 
 
 @pytest.mark.parametrize("name", list(helpers.CASES))
@@ -569,7 +580,7 @@ def test_deferred_readback_reaches_every_host_reader(gpu_lib, workdir):
     ses.close()
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_glass_sun"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_glass_sun", "pbr_maps"])
 def test_reflectance_and_microsurface_aovs_match_the_oracle_definition(name, sessions, gpu_lib, oracle, workdir):
     """Modes 3 and 6 read an uninitialised tangent frame in the reference (renderer.cc:89-93,104-108), so no reference fixture exists.  The
     defined variant -- the frame built first, as TraceScene does -- is what the oracle restates; the device must give the same bits, including

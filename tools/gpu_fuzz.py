@@ -15,7 +15,7 @@ bad = 0
 only = int(os.environ.get("FUZZ_ONLY", "-1"))
 t0 = time.time()
 for case in range(cases):
-    kind = rng.randint(4)
+    kind = rng.randint(5)
     if kind == 0:
         gen = (scenes.cornell, dict(tess=int(rng.randint(1, 20)), displace_fraction=float(rng.choice([0.0, 0.1, 0.3])),
                                     tall_material=str(rng.choice([scenes.MIRROR, scenes.GLASS, scenes.WHITE])), short_material=str(rng.choice([scenes.WHITE, scenes.GLASS]))))
@@ -23,8 +23,10 @@ for case in range(cases):
         gen = (scenes.soup, dict(n_tris=int(rng.randint(10, 30000)), seed=int(rng.randint(1 << 30)), extent=float(rng.uniform(1, 5)), size=float(rng.uniform(0.05, 1.0))))
     elif kind == 2:
         gen = (scenes.cutout, dict(tess=int(rng.randint(1, 12))))
-    else:
+    elif kind == 3:
         gen = (scenes.colonnade, dict(tess=int(rng.randint(1, 4))))
+    else:
+        gen = (scenes.pbr_maps, dict(tess=int(rng.randint(1, 10)), mtl=scenes.random_pbr_mtl(rng)))
     sun = (0, 0, 0) if rng.rand() < 0.4 else tuple(float(x) for x in rng.uniform(1, 20, 3))
     sun_dir = tuple(float(x) for x in rng.uniform(-1, 1, 3) * np.array([1, 1, 1]) + np.array([0, -1.2, 0]))
     sky = scenes.sky_panorama() if rng.rand() < 0.4 else None
@@ -46,7 +48,7 @@ for case in range(cases):
         for k in env: del os.environ[k]
         # cut-out scenes run the alpha test on traversal candidates, whose number depends on the order candidates are met in:
         # their shading / texel counts are schedule-dependent, rays and samples are not
-        key = (st["rays"], st["cameraSamples"]) if kind == 2 else (st["rays"], st["shadedHits"], st["cameraSamples"], st["texFetches"])
+        key = (st["rays"], st["cameraSamples"]) if kind in (2, 4) else (st["rays"], st["shadedHits"], st["cameraSamples"], st["texFetches"])
         if ref is None: ref = (img, key)
         elif not (np.array_equal(bits(img), bits(ref[0])) and key == ref[1]):
             bad += 1
