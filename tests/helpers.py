@@ -81,6 +81,14 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def same(a, b):
+    """Element-wise: the same float32 bits, or NaN on both sides.  (The reference itself produces NaN radiance on some paths --
+    e.g. a near-specular Beckmann lobe, roughness 0.05 -- and a NaN's payload / sign is not part of parity: x86 SSE makes
+    0xFFC00000, the GPU 0x7FC00000.)"""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
 def random_rays(n, seed, extent=4.0):
     rng = np.random.RandomState(seed)
     o = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
