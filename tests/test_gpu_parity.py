@@ -406,7 +406,9 @@ def test_pool_schedule_vs_reference_goldens(name, pool, sessions, gpu_lib, oracl
     img = ses.render(64, 64, 16)
     st1 = ses.stats().as_dict()
     assert helpers.same(img, base).all()                   # ties included: the closest hit does not depend on the schedule
-    for k in ("rays", "shadedHits", "cameraSamples", "texFetches"):
+    # scenes with an albedo map run the cut-out test on traversal CANDIDATES (triangle.cc:54), whose number depends on the order a
+    # schedule meets them in: there only the queries and samples are schedule-independent
+    for k in (("rays", "cameraSamples") if name in ("cutout_sky", "pbr_maps") else ("rays", "shadedHits", "cameraSamples", "texFetches")):
         assert st0[k] == st1[k], k                          # same queries, same shading events
 
 
