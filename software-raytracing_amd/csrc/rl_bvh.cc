@@ -72,6 +72,7 @@ struct BinSet {
 	void merge(const BinSet& o) { for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { box[a][k].grow(o.box[a][k]); count[a][k] += o.count[a][k]; } }
 };
 
+constexpr uint32_t kMedianSplitDepth = 36;      // see build(): SAH splits above, median splits from here on -> depth <= 36 + 25 < 64
 constexpr uint32_t kParallelRange = 1u << 17;   // ranges at least this long are scanned by all threads
 
 template <typename F>
@@ -185,7 +186,21 @@ int32_t build(Shared& S, Ctx& C, uint32_t b, uint32_t e, uint32_t depth)
 	}
 
 	uint32_t mid;
-	if (bestAxis < 0) {
+	if (depth >= kMedianSplitDepth) {
+		// A SAH tree has no depth bound (a pathological input can peel one primitive per level) and the traversal stacks hold
+		// 64 entries: from this depth on the range is halved by count along the longest centroid axis, which ends within
+		// log2(n) <= 25 more levels (kMaxPrimitives), i.e. below 64.  Deterministic for any thread count (nth_element on a range
+		// whose order is already fixed).
+		if (leafAllowed(S, b, e)) return makeLeaf();
+		int axis = 0;
+		const float ex = cb.mx.x - cb.mn.x, ey = cb.mx.y - cb.mn.y, ez = cb.mx.z - cb.mn.z;
+		if (ey > ex && ey >= ez) axis = 1; else if (ez > ex && ez > ey) axis = 2;
+		mid = b + n / 2;
+		std::nth_element(S.order.begin() + b, S.order.begin() + mid, S.order.begin() + e, [&](uint32_t x, uint32_t y) {
+			const float cx = axisOf(S.centroid[x], axis), cy = axisOf(S.centroid[y], axis);
+			return cx < cy || (cx == cy && x < y);
+		});
+	} else if (bestAxis < 0) {
 		// all centroids coincide: split by index
 		if (leafAllowed(S, b, e)) return makeLeaf();
 		mid = b + n / 2;
@@ -228,6 +243,9 @@ inline void storeBox(float* mn, float* mx, const Box& b) {
 inline int32_t leafRef(uint32_t first, uint32_t kind, uint32_t count) { return ~(int32_t)((first << 6) | (kind << 4) | (count - 1)); }
 
 } // namespace
+
+// Leaf references keep the first primitive slot in 25 bits (DNode, rl_device.h): more primitives than that cannot be addressed.
+bool BVHCapacityOk(size_t numPrimitives) { return numPrimitives < ((size_t)1 << 25); }
 
 void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 {

@@ -115,6 +115,7 @@ struct BVH {
 enum PrimKind { PRIM_TRIANGLE = 0, PRIM_SPHERE = 1, PRIM_CUBE = 2 };
 struct PrimRef { f3 mn, mx; uint8_t kind; uint32_t index; };
 void BuildBVH(const std::vector<PrimRef>& prims, BVH& out);
+bool BVHCapacityOk(size_t numPrimitives);   // a leaf reference addresses 2^25 primitive slots
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris);
 bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris);
 
@@ -161,7 +162,7 @@ struct Scene {
 	Scene();
 	~Scene();
 	void Finalize();
-	void BuildAccel(float t0, float t1);
+	bool BuildAccel(float t0, float t1);   // false: the scene exceeds the BVH's addressing (logged); nothing was built
 };
 
 // loaders (rl_obj_loader.cc, rl_image_io.cc)

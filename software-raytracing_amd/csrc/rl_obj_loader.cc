@@ -11,8 +11,25 @@
 //   - missing texcoord -> (0,0)                                          (:163-173)
 //   - face without a valid material -> Lambertian(0.5)                   (:113,206-211)
 //   - non-triangle faces: the reference skips them after tinyobjloader has already
-//     triangulated (triangulate defaults to true), so polygons arrive as fans
+//     triangulated (ObjReaderConfig::triangulate defaults to true), so polygons arrive as
+//     triangles cut the way tinyobjloader v2.0.0rc10 cuts them: a quad along its SHORTER
+//     diagonal ([0,1,2][0,2,3] if |v2-v0|^2 < |v3-v1|^2, else [0,1,3][1,2,3]), larger
+//     polygons by ear clipping in the projection plane of the first non-degenerate corner
+//     (a convex polygon comes out as the fan around its first vertex)
+//   - a zero index, or a negative one reaching before the first element, fails the whole
+//     load (tinyobjloader's fixIndex / parseTriple return false -> LoadObj returns false ->
+//     obj_loader.cc:91-95 logs and returns false)
+//   - textures are only looked for when the OBJ path contains a directory separator (:256-262)
 //   - MTL -> material mapping                                             (:354-397)
+// MTL statements follow tinyobjloader's LoadMtl: '#' starts a comment only as the first
+// non-blank character of a line; missing colour components are 0; a texture statement is
+// `options... name` where the name is THE REST OF THE LINE (blanks inside allowed, trailing
+// blanks trimmed); -o / -s / -t swallow three words, -mm two, the other options one;
+// `newmtl` takes the rest of the line as the name, `usemtl` (OBJ side) only the first word;
+// with duplicate names the FIRST definition is the one `usemtl` finds; `mtllib a b c` uses
+// the first of the files that can be opened.
+// tinyobjloader is not vendored in the reference and absent here: this restates its published
+// v2.0.0rc10 behaviour and is UNPINNED (tests/golden/obj_cases/ holds hand-written expectations).
 #include "rl_host.h"
 
 #include <stdio.h>
@@ -42,24 +59,6 @@ struct MtlRecord {
 	std::string map_Kd, map_Pr, map_Pm, map_Ke, norm, bump;
 };
 
-// Tokeniser over one line: whitespace separated, '#' starts a comment.
-struct Tokens {
-	std::vector<std::string> t;
-	explicit Tokens(const char* line) {
-		const char* p = line;
-		while (*p) {
-			while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') ++p;
-			if (!*p || *p == '#') break;
-			const char* b = p;
-			while (*p && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') ++p;
-			t.emplace_back(b, p - b);
-		}
-	}
-	size_t size() const { return t.size(); }
-	const std::string& operator[](size_t i) const { return t[i]; }
-	float f(size_t i, float dflt = 0.0f) const { return i < t.size() ? strtof(t[i].c_str(), nullptr) : dflt; }
-};
-
 bool ReadLines(const std::string& path, std::vector<std::string>& out)
 {
 	FILE* f = fopen(path.c_str(), "rb");
@@ -84,36 +83,88 @@ std::string DirOf(const std::string& path)
 	return p == std::string::npos ? std::string() : path.substr(0, p + 1);
 }
 
-void ParseMTL(const std::string& path, std::vector<MtlRecord>& out)
+inline bool IsBlank(char ch) { return ch == ' ' || ch == '\t'; }
+// next blank-separated word of [p, e); advances p behind it.  Empty when the line is exhausted.
+std::string NextWord(const char*& p, const char* e)
+{
+	while (p < e && IsBlank(*p)) ++p;
+	const char* b = p;
+	while (p < e && !IsBlank(*p) && *p != '\r') ++p;
+	return std::string(b, p - b);
+}
+// tinyobjloader parseReal: the next word as a number (strtod rules), `dflt` when there is none / it is not a number
+float NextReal(const char*& p, const char* e, float dflt)
+{
+	const std::string w = NextWord(p, e);
+	if (w.empty()) return dflt;
+	char* end = nullptr;
+	const float v = strtof(w.c_str(), &end);
+	return end == w.c_str() ? dflt : v;
+}
+// tinyobjloader ParseTextureNameAndOption: options first (their arguments are swallowed word by word, whatever they are),
+// then the rest of the line is the file name.
+std::string TextureName(const char* p, const char* e)
+{
+	for (;;) {
+		while (p < e && IsBlank(*p)) ++p;
+		if (p >= e) return std::string();
+		const char* save = p;
+		const std::string w = NextWord(p, e);
+		int swallow = -1;
+		if (w == "-blendu" || w == "-blendv" || w == "-clamp" || w == "-boost" || w == "-bm" || w == "-type" || w == "-texres" ||
+		    w == "-imfchan" || w == "-colorspace") swallow = 1;
+		else if (w == "-mm") swallow = 2;
+		else if (w == "-o" || w == "-s" || w == "-t") swallow = 3;
+		if (swallow < 0) return std::string(save, e - save);   // the rest of the line, blanks included
+		for (int k = 0; k < swallow; ++k) (void)NextWord(p, e);
+	}
+}
+
+// Returns false when the file cannot be opened (tinyobjloader then tries the next name of the mtllib statement).
+bool ParseMTL(const std::string& path, std::vector<MtlRecord>& out)
 {
 	std::vector<std::string> lines;
-	if (!ReadLines(path, lines)) { Log("OBJ: cannot open material library %s", path.c_str()); return; }
-	MtlRecord* cur = nullptr;
-	for (const std::string& line : lines) {
-		Tokens tk(line.c_str());
-		if (tk.size() == 0) continue;
-		const std::string& k = tk[0];
-		if (k == "newmtl") { out.emplace_back(); cur = &out.back(); cur->name = tk.size() > 1 ? tk[1] : ""; continue; }
-		if (!cur) continue;
-		auto rgb = [&](float* dst) { dst[0] = tk.f(1); dst[1] = tk.f(2, dst[0]); dst[2] = tk.f(3, dst[0]); };
+	if (!ReadLines(path, lines)) { Log("OBJ: cannot open material library %s", path.c_str()); return false; }
+	// Statements before the first `newmtl` go to a temporary material that is dropped (LoadMtl flushes a material only
+	// when its name is non-empty, and so is a material declared by a bare `newmtl`).
+	MtlRecord scratch; MtlRecord* cur = &scratch;
+	for (const std::string& raw : lines) {
+		const char* p = raw.c_str(); const char* e = p + raw.size();
+		while (e > p && (e[-1] == '\n' || e[-1] == '\r')) --e;
+		while (e > p && IsBlank(e[-1])) --e;              // trailing blanks are trimmed before anything is parsed
+		while (p < e && IsBlank(*p)) ++p;
+		if (p >= e || *p == '#') continue;
+		const std::string k = NextWord(p, e);
+		if (p >= e && k != "newmtl") continue;            // every keyword test asks for a blank behind the keyword
+		if (k == "newmtl") {
+			while (p < e && IsBlank(*p)) ++p;
+			MtlRecord r; r.name = std::string(p, e - p);
+			if (r.name.empty()) { scratch = MtlRecord(); cur = &scratch; continue; }
+			out.push_back(r); cur = &out.back();
+			continue;
+		}
+		auto rgb = [&](float* dst) { dst[0] = NextReal(p, e, 0.0f); dst[1] = NextReal(p, e, 0.0f); dst[2] = NextReal(p, e, 0.0f); };
 		if (k == "Kd") { rgb(cur->Kd); cur->hasKd = true; }
 		else if (k == "Ks") rgb(cur->Ks);
 		else if (k == "Ke") rgb(cur->Ke);
 		else if (k == "Tf" || k == "Kt") rgb(cur->Tf);
-		else if (k == "Ns") cur->Ns = tk.f(1);
-		else if (k == "Ni") cur->Ni = tk.f(1);
-		else if (k == "Pr") cur->Pr = tk.f(1);
-		else if (k == "Pm") cur->Pm = tk.f(1);
-		else if (k == "illum") cur->illum = tk.size() > 1 ? atoi(tk[1].c_str()) : 0;
-		else if (k == "map_Kd") cur->map_Kd = tk[tk.size() - 1];
-		else if (k == "map_Pr") cur->map_Pr = tk[tk.size() - 1];
-		else if (k == "map_Pm") cur->map_Pm = tk[tk.size() - 1];
-		else if (k == "map_Ke") cur->map_Ke = tk[tk.size() - 1];
-		else if (k == "norm") cur->norm = tk[tk.size() - 1];
-		else if (k == "map_bump" || k == "map_Bump" || k == "bump") cur->bump = tk[tk.size() - 1];
+		else if (k == "Ns") cur->Ns = NextReal(p, e, 0.0f);
+		else if (k == "Ni") cur->Ni = NextReal(p, e, 0.0f);
+		else if (k == "Pr") cur->Pr = NextReal(p, e, 0.0f);
+		else if (k == "Pm") cur->Pm = NextReal(p, e, 0.0f);
+		else if (k == "illum") cur->illum = atoi(NextWord(p, e).c_str());
+		else if (k == "map_Kd") {
+			cur->map_Kd = TextureName(p, e);
+			// "a decent diffuse default value if a diffuse texture is specified without a matching Kd value" -- at this statement
+			if (!cur->hasKd) cur->Kd[0] = cur->Kd[1] = cur->Kd[2] = 0.6f;
+		}
+		else if (k == "map_Pr") cur->map_Pr = TextureName(p, e);
+		else if (k == "map_Pm") cur->map_Pm = TextureName(p, e);
+		else if (k == "map_Ke") cur->map_Ke = TextureName(p, e);
+		else if (k == "norm") cur->norm = TextureName(p, e);
+		else if (k == "map_bump" || k == "map_Bump" || k == "bump") cur->bump = TextureName(p, e);
 	}
-	for (MtlRecord& m : out)
-		if (!m.map_Kd.empty() && !m.hasKd) m.Kd[0] = m.Kd[1] = m.Kd[2] = 0.6f;   // tinyobjloader default for textured materials without Kd
+	return true;
 }
 
 inline float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
@@ -194,12 +245,13 @@ bool ParseRawCorner(const char* p, RawCorner& c)
 	c.v = (int)a;
 	if (*end == '/') {
 		p = end + 1;
-		if (*p != '/') { long b = strtol(p, &end, 10); if (end != p) c.vt = (int)b; }
+		// "i//k", "i/j", "i/j/k"; an index that is not a number reads as 0, as atoi does in tinyobjloader's parseTriple
+		if (*p != '/') { long b = strtol(p, &end, 10); c.vt = end != p ? (int)b : 0; }
 		else end = (char*)p;
 		if (*end == '/') {
 			p = end + 1;
 			long d = strtol(p, &end, 10);
-			if (end != p) c.vn = (int)d;
+			c.vn = end != p ? (int)d : 0;
 		}
 	}
 	return true;
@@ -283,22 +335,93 @@ void ParseChunk(Chunk& c)
 				poly.firstCorner = (uint32_t)c.corners.size(); poly.numCorners = 0;
 				poly.nV = (int)(c.V.size() / 3); poly.nVT = (int)(c.VT.size() / 2); poly.nVN = (int)(c.VN.size() / 3);
 				poly.usemtlSeen = c.usemtlCount; poly.shapeSeen = c.shapeCount;
-				bool ok = true;
-				const char* cb; const char* ce;
-				while (NextToken(p, end, cb, ce)) {
+				// every blank-separated word up to the end of the line is a corner -- a '#' does not end a face statement in
+				// tinyobjloader -- and a word that is not a number reads as index 0, which fails the load (see the counting pass)
+				for (;;) {
+					while (p < end && IsSpace(*p)) ++p;
+					if (p >= end || *p == '\n') break;
 					RawCorner rc;
-					if (!ParseRawCorner(cb, rc)) { ok = false; break; }
+					if (!ParseRawCorner(p, rc)) { rc.v = 0; rc.vt = rc.vn = kAbsent; }
 					c.corners.push_back(rc);
+					while (p < end && *p != '\n' && !IsSpace(*p)) ++p;
 				}
-				if (ok) poly.numCorners = (uint32_t)(c.corners.size() - poly.firstCorner);
-				else c.corners.resize(poly.firstCorner);
-				if (poly.numCorners >= 3) c.polys.push_back(poly);
+				poly.numCorners = (uint32_t)(c.corners.size() - poly.firstCorner);
+				bool fatal = false;
+				for (uint32_t k = 0; k < poly.numCorners; ++k) { const RawCorner& rc = c.corners[poly.firstCorner + k]; if (rc.v == 0 || rc.vt == 0 || rc.vn == 0) fatal = true; }
+				if (poly.numCorners >= 3 || fatal) c.polys.push_back(poly);   // fewer than three corners: "degenerated face", skipped
 				else c.corners.resize(poly.firstCorner);
 			}
 		}
 		while (p < end && *p != '\n') ++p;   // rest of the line
 		if (p < end) ++p;
 	}
+}
+
+// tinyobjloader's point-in-polygon test (W. R. Franklin's pnpoly) on a triangle
+inline bool PnPoly3(const float* vx, const float* vy, float tx, float ty)
+{
+	bool c = false;
+	for (int i = 0, j = 2; i < 3; j = i++)
+		if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) c = !c;
+	return c;
+}
+
+// How tinyobjloader v2.0.0rc10 (exportGroupsToShape, triangulate = true, built-in ear clipping) cuts a polygon of n corners
+// into n - 2 triangles; `out` receives corner numbers.  Always n - 2 triangles, so the counting pass needs no geometry: when
+// the ear search gives up on a degenerate polygon (tinyobjloader then drops what is left), the remainder is emitted as a fan.
+void Triangulate(const RawCorner* rc, uint32_t n, const float* V, int nV, std::vector<uint32_t>& out)
+{
+	out.clear();
+	if (n == 3) { out = { 0u, 1u, 2u }; return; }
+	auto P = [&](uint32_t corner, int axis) { return V[3 * (size_t)ResolveIndex(rc[corner].v, nV) + axis]; };
+	if (n == 4) {
+		// the shorter diagonal
+		float d02 = 0.0f, d13 = 0.0f;
+		for (int a = 0; a < 3; ++a) { const float e02 = P(2, a) - P(0, a), e13 = P(3, a) - P(1, a); d02 += e02 * e02; d13 += e13 * e13; }
+		if (d02 < d13) out = { 0u, 1u, 2u, 0u, 2u, 3u };
+		else out = { 0u, 1u, 3u, 1u, 2u, 3u };
+		return;
+	}
+	// projection axes: drop the dominant axis of the first corner whose cross product is not (numerically) zero
+	int axes[2] = { 1, 2 };
+	for (uint32_t k = 0; k < n; ++k) {
+		const uint32_t i0 = k % n, i1 = (k + 1) % n, i2 = (k + 2) % n;
+		const float e0x = P(i1, 0) - P(i0, 0), e0y = P(i1, 1) - P(i0, 1), e0z = P(i1, 2) - P(i0, 2);
+		const float e1x = P(i2, 0) - P(i1, 0), e1y = P(i2, 1) - P(i1, 1), e1z = P(i2, 2) - P(i1, 2);
+		const float cx = fabsf(e0y * e1z - e0z * e1y), cy = fabsf(e0z * e1x - e0x * e1z), cz = fabsf(e0x * e1y - e0y * e1x);
+		const float eps = 1.1920929e-07f;
+		if (cx > eps || cy > eps || cz > eps) {
+			if (!(cx > cy && cx > cz)) { axes[0] = 0; if (cz > cx && cz > cy) axes[1] = 1; }
+			break;
+		}
+	}
+	float area = 0.0f;
+	for (uint32_t k = 0; k < n; ++k) {
+		const uint32_t i0 = k, i1 = (k + 1) % n;
+		area += (P(i0, axes[0]) * P(i1, axes[1]) - P(i0, axes[1]) * P(i1, axes[0])) * 0.5f;
+	}
+	std::vector<uint32_t> rest(n);
+	for (uint32_t k = 0; k < n; ++k) rest[k] = k;
+	size_t guess = 0, remainingIterations = n, previous = n;
+	while (rest.size() > 3 && remainingIterations > 0) {
+		const size_t m = rest.size();
+		if (guess >= m) guess -= m;
+		if (previous != m) { previous = m; remainingIterations = m; } else --remainingIterations;
+		uint32_t ind[3]; float vx[3], vy[3];
+		for (int k = 0; k < 3; ++k) { ind[k] = rest[(guess + k) % m]; vx[k] = P(ind[k], axes[0]); vy[k] = P(ind[k], axes[1]); }
+		const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+		const float crossz = e0x * e1y - e0y * e1x;
+		if (crossz * area < 0.0f) { ++guess; continue; }                     // a reflex corner
+		bool overlap = false;
+		for (size_t other = 3; other < m && !overlap; ++other) {
+			const uint32_t o = rest[(guess + other) % m];
+			overlap = PnPoly3(vx, vy, P(o, axes[0]), P(o, axes[1]));
+		}
+		if (overlap) { ++guess; continue; }
+		out.push_back(ind[0]); out.push_back(ind[1]); out.push_back(ind[2]);   // an ear: cut it off
+		rest.erase(rest.begin() + (ptrdiff_t)((guess + 1) % m));
+	}
+	for (size_t k = 1; k + 1 < rest.size(); ++k) { out.push_back(rest[0]); out.push_back(rest[k]); out.push_back(rest[k + 1]); }
 }
 
 // fn(i) for i in [0, n) on up to `threads` threads, items handed out one at a time
@@ -390,10 +513,11 @@ bool LoadOBJ(const char* path, OBJModel& out)
 		c.materialIn = curMaterial;
 		for (const MtlEvent& ev : c.events) {
 			if (ev.isLib) {
-				for (const std::string& name : ev.names) {
+				for (const std::string& name : ev.names) {   // the first of the files that can be read; the others are not looked at
 					const size_t before = mtl.size();
-					ParseMTL(dir + name, mtl);
-					for (size_t j = before; j < mtl.size(); ++j) mtlIndex[mtl[j].name] = (int)j;
+					if (!ParseMTL(dir + name, mtl)) continue;
+					for (size_t j = before; j < mtl.size(); ++j) mtlIndex.insert(std::make_pair(mtl[j].name, (int)j));   // first definition wins
+					break;
 				}
 			} else {
 				auto it = ev.hasName ? mtlIndex.find(ev.names[0]) : mtlIndex.end();
@@ -408,8 +532,8 @@ bool LoadOBJ(const char* path, OBJModel& out)
 	// uninitialised: every element is written by the chunk copies below (zero-filling 10^7 vertices first costs as much as parsing them)
 	std::unique_ptr<float[]> Vbuf(new float[3 * totalV + 1]), VTbuf(new float[2 * totalVT + 1]), VNbuf(new float[3 * totalVN + 1]);
 	float* const V = Vbuf.get(); float* const VT = VTbuf.get(); float* const VN = VNbuf.get();
-	// A polygon counts if every corner names a position defined BEFORE its line (a one-pass reader knows no others).
-	// Marks dropped polygons (numCorners = 0) and counts each chunk's triangles (fans).
+	// Marks dropped polygons (numCorners = 0), finds the indices that fail the whole load, counts each chunk's triangles.
+	std::atomic<bool> fatalIndex(false);
 	ForEachParallel(numChunks, threads, [&](size_t i) {
 		Chunk& c = chunks[i];
 		if (!c.V.empty()) memcpy(&V[3 * c.baseV], c.V.data(), c.V.size() * sizeof(float));
@@ -418,16 +542,23 @@ bool LoadOBJ(const char* path, OBJModel& out)
 		std::vector<float>().swap(c.V); std::vector<float>().swap(c.VT); std::vector<float>().swap(c.VN);
 		size_t tris = 0;
 		for (Poly& poly : c.polys) {
-			const int nV = (int)c.baseV + poly.nV;
+			const int nV = (int)c.baseV + poly.nV, nVT = (int)c.baseVT + poly.nVT, nVN = (int)c.baseVN + poly.nVN;
 			bool ok = true;
-			for (uint32_t k = 0; k < poly.numCorners && ok; ++k) {
-				const int v = ResolveIndex(c.corners[poly.firstCorner + k].v, nV);
-				ok = v >= 0 && v < nV;
+			for (uint32_t k = 0; k < poly.numCorners; ++k) {
+				const RawCorner& rc = c.corners[poly.firstCorner + k];
+				// tinyobjloader fixIndex: 0 is not an index, and a relative index may not reach before the first element
+				if (rc.v == 0 || (rc.v != kAbsent && rc.v < 0 && nV + rc.v < 0) || rc.vt == 0 || (rc.vt != kAbsent && rc.vt < 0 && nVT + rc.vt < 0) ||
+				    rc.vn == 0 || (rc.vn != kAbsent && rc.vn < 0 && nVN + rc.vn < 0)) { fatalIndex = true; ok = false; break; }
+				// a positive index may name an element defined further down the file (tinyobjloader resolves it only against 0);
+				// beyond the file's last element the reference reads out of bounds -- such faces are dropped here
+				const int v = ResolveIndex(rc.v, nV);
+				if (!(v >= 0 && v < (int)totalV)) ok = false;
 			}
-			if (ok) tris += poly.numCorners - 2; else poly.numCorners = 0;
+			if (ok && poly.numCorners >= 3) tris += poly.numCorners - 2; else poly.numCorners = 0;
 		}
 		c.numTris = tris;
 	});
+	if (fatalIndex) { Log("LoadOBJ: tiny_obj_loader failed: %s (a face uses index 0 or a relative index before the first element)", path); return false; }
 	size_t totalTris = 0;
 	for (Chunk& c : chunks) { c.triBase = totalTris; totalTris += c.numTris; }
 	text.reset();
@@ -443,7 +574,7 @@ bool LoadOBJ(const char* path, OBJModel& out)
 	out.materials.clear(); out.materialNames.clear(); out.images.clear(); out.triangles.clear();
 	std::map<std::string, int> imageIndex;
 	auto texture = [&](const std::string& fn) -> int {
-		if (fn.empty()) return -1;
+		if (fn.empty() || dir.empty()) return -1;   // obj_loader.cc:256-262: images are only looked for next to an OBJ whose path has a directory part
 		auto it = imageIndex.find(fn);
 		if (it != imageIndex.end()) return it->second;
 		Image* img = LoadImageFile((dir + fn).c_str());
@@ -482,13 +613,15 @@ bool LoadOBJ(const char* path, OBJModel& out)
 		Chunk& c = chunks[ci];
 		HostTriangle* dst = out.triangles.data() + c.triBase;
 		int invalidTexcoords = 0;
+		std::vector<uint32_t> cut;   // corner numbers, three per triangle
 		for (const Poly& poly : c.polys) {
 			if (!poly.numCorners) continue;
 			const int nV = (int)c.baseV + poly.nV, nVT = (int)c.baseVT + poly.nVT, nVN = (int)c.baseVN + poly.nVN;
 			const int material = poly.usemtlSeen ? c.usemtlMaterial[poly.usemtlSeen - 1] : c.materialIn;
 			const RawCorner* rc = &c.corners[poly.firstCorner];
-			for (uint32_t j = 1; j + 1 < poly.numCorners; ++j) {   // triangle fan
-				const RawCorner* corner[3] = { &rc[0], &rc[j], &rc[j + 1] };
+			Triangulate(rc, poly.numCorners, V, nV, cut);
+			for (size_t j = 0; j + 2 < cut.size(); j += 3) {
+				const RawCorner* corner[3] = { &rc[cut[j]], &rc[cut[j + 1]], &rc[cut[j + 2]] };
 				HostTriangle t; memset(&t, 0, sizeof(t));
 				f3 pos[3], nrm[3]; float tu[3], tv[3];
 				bool validNormal = true;

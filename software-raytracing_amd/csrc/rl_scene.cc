@@ -94,7 +94,12 @@ void Scene::Finalize()
 	}
 	hasMovingCubes = false;
 	for (const HostCube& c : cubes) if (c.velocity.x != 0.0f || c.velocity.y != 0.0f || c.velocity.z != 0.0f) hasMovingCubes = true;
-	BuildAccel(0.0f, 0.0f);
+	if (!BuildAccel(0.0f, 0.0f)) {
+		// the reference would run out of memory long before (152-byte triangles + a heap node each); here the limit is the leaf
+		// reference's 25-bit slot number.  The scene stays un-finalized: Raylib_Render refuses it with a log line.
+		triangles.clear(); triangles.shrink_to_fit(); spheres.clear(); cubes.clear();
+		finalized = false;
+	}
 }
 
 // The flat BVH.  [t0, t1] is the shutter interval the boxes of moving cubes must cover.
@@ -102,9 +107,14 @@ void Scene::Finalize()
 // parent's union box -- so whether it still finds a cube that has moved out of its t = 0 box depends on which sibling
 // its random build happened to pair it with.  Here a cube's box covers its whole motion over the camera's shutter
 // (Cube::BoundingBox(t0, t1), geom/cube.cc:45-52), i.e. the cube is found wherever it really is.
-void Scene::BuildAccel(float t0, float t1)
+bool Scene::BuildAccel(float t0, float t1)
 {
 	accelT0 = t0; accelT1 = t1;
+	if (!BVHCapacityOk(triangles.size() + spheres.size() + cubes.size())) {
+		Log("Raylib_FinalizeScene: %zu primitives exceed the %u this library's BVH can address; the scene was NOT finalized",
+		    triangles.size() + spheres.size() + cubes.size(), (1u << 25) - 1u);
+		return false;
+	}
 	std::vector<PrimRef> prims;
 	prims.reserve(triangles.size() + spheres.size() + cubes.size());
 	for (size_t i = 0; i < triangles.size(); ++i) {
@@ -151,6 +161,7 @@ void Scene::BuildAccel(float t0, float t1)
 	Log("Scene finalized: %u triangles, %u BVH nodes, depth %u, SAH cost %.2f (BVH build %.2f s)",
 	    (unsigned)triangles.size(), (unsigned)bvh.nodes.size(), bvh.depth, bvh.sahCost, buildSec);
 	if (!bvh.nodes4.empty()) Log("\twide tree: %u BVH4 nodes, worst-case traversal stack %u entries", (unsigned)bvh.nodes4.size(), bvh.stackNeed4);
+	return true;
 }
 
 // Image2D::PostProcess on the host (reference render/image.cc:44-103): max-luminance

@@ -364,9 +364,10 @@ def test_obj_reader_result_does_not_depend_on_its_chunking(lib, workdir, monkeyp
         f.write("newmtl late\nKd 0.1 0.2 0.7\nNs 50\n")
     rng = np.random.RandomState(5)
     lines = ["# faces before any shape or material", "usemtl red   # not known yet: fallback material", "v 0 0 0", "v 1 0 0", "v 0 1 0", "f 1 2 3",
-             "f 1 2 4   # vertex 4 is defined later: dropped", "v 1 1 0", "mtllib a.mtl", "usemtl red", "f -4 -3 -1 -2", "o first", "o empty", "g second",
-             "vt 0.25 0.5", "vn 0 0 1", "f 1/1/1 2//1 3/1", "f 1/2/1 2/1/1 3/1/1  # vt 2 comes later: valid index at assembly", "vt 0.75 0.125",
-             "usemtl nosuch", "f 1 2 3 4 1", "usemtl", "f 2 3 4", "f 1 x 3", "f 1 2", "usemtl late", "f 1 3 4", "mtllib b.mtl missing.mtl", "usemtl late", "g third", "f 4/0/0 3/-1/-1 1/-2/5"]
+             "f 1 2 4", "v 1 1 0", "mtllib a.mtl", "usemtl red", "f -4 -3 -1 -2", "o first", "o empty", "g second",
+             "vt 0.25 0.5", "vn 0 0 1", "f 1/1/1 2//1 3/1", "f 1/2/1 2/1/1 3/1/1", "vt 0.75 0.125",
+             "usemtl nosuch", "f 1 2 4 3 1", "usemtl", "f 2 3 4", "f 1 2", "usemtl late", "f 1 3 4", "mtllib missing.mtl b.mtl a.mtl", "usemtl late", "g third", "f 4/1/1 3/-1/-1 1/-2/5",
+             "f 1 2 99999"]
     for i in range(400):                                   # bulk, so that forced chunkings cut everywhere
         x, y, z = rng.rand(3)
         lines += ["v %.6f %.6f %.6f" % (x, y, z), "v %.6f %.6f %.6f" % (x + 0.1, y, z), "v %.6f %.6f %.6f" % (x, y + 0.1, z)]
@@ -389,12 +390,33 @@ def test_obj_reader_result_does_not_depend_on_its_chunking(lib, workdir, monkeyp
         ses.close()
     assert len(set(seen.values())) == 1
     # spot checks of the one-pass rules on the single-chunk result
-    assert len(first) == 1 + 2 + 2 + 3 + 1 + 1 + 1 + 400
+    assert len(first) == 1 + 1 + 2 + 2 + 3 + 1 + 1 + 1 + 400     # "f 1 2" (two corners) and "f 1 2 99999" (beyond the file's last vertex) are dropped
     mat = first["material"]
-    assert list(mat[:11]) == [3, 0, 0, 0, 0, 3, 3, 3, 3, 3, 2]   # red = 0, mirror = 1, late = 2 (only once b.mtl was read), fallback = 3: name not
-                                                                 # known yet, "usemtl nosuch", bare "usemtl", "late" before its mtllib
-    assert list(first["shape"][:11]) == [0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2]   # before any o/g; "second" ("first" and "empty" hold no faces: dropped); "third"
-    assert np.array_equal(first["st"][4][:2], np.float32([0.75, 0.125]))   # vt 2, defined after the face that names it
+    assert list(mat[:12]) == [3, 3, 0, 0, 0, 0, 3, 3, 3, 3, 3, 2]   # red = 0, mirror = 1, late = 2 (only once b.mtl was read), fallback = 3: name not
+                                                                    # known yet, "usemtl nosuch", bare "usemtl", "late" before its mtllib
+    assert list(first["shape"][:12]) == [0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2]   # before any o/g; "second" ("first" and "empty" hold no faces: dropped); "third"
+    assert np.array_equal(first["v2"][1], np.float32([1, 1, 0]))            # "f 1 2 4": vertex 4 is defined after the face that names it
+    assert np.array_equal(first["st"][5][:2], np.float32([0.75, 0.125]))    # vt 2, likewise
+    # unit square 1 2 4 3 as "f -4 -3 -1 -2": both diagonals are equally long -> tinyobjloader's `else` branch [0,1,3] [1,2,3]
+    assert np.array_equal(first["v0"][2], np.float32([0, 0, 0])) and np.array_equal(first["v2"][2], np.float32([0, 1, 0]))
+    assert np.array_equal(first["v0"][3], np.float32([1, 0, 0])) and np.array_equal(first["v1"][3], np.float32([1, 1, 0]))
+    # the independent Python reader (oracle/objflat.py) agrees on every triangle and material
+    flat = helpers.objflat.load_obj(obj, helpers.ffi.load_oracle())
+    assert first.tobytes() == flat.triangles.tobytes()
+
+
+@pytest.mark.parametrize("bad", ["f 1 2 0", "f 1/0/1 2/1/1 3/1/1", "f 1 2 -9", "f 1 x 3", "f 1 2 3 # trailing comment"])
+def test_obj_face_statements_that_fail_the_load(bad, lib, workdir):
+    """tinyobjloader's parseTriple / fixIndex return false on index 0 (also what atoi makes of a word that is not a number -- a '#'
+    does not end a face statement) and on a relative index before the first element; LoadObj then fails and the reference refuses the
+    model (loader/obj_loader.cc:91-95)."""
+    d = os.path.join(str(workdir), "badobj"); os.makedirs(d, exist_ok=True)
+    obj = os.path.join(d, "bad.obj")
+    with open(obj, "w") as f:
+        f.write("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1 2 3\n" + bad + "\n")
+    assert not lib.Raylib_LoadOBJModel(obj.encode())
+    with pytest.raises(helpers.objflat.ObjLoadError):
+        helpers.objflat.load_obj(obj, helpers.ffi.load_oracle())
 
 
 def test_chunked_obj_reader_matches_oracle_side_parser_on_a_multi_megabyte_file(lib, oracle, workdir, monkeypatch):
