@@ -14,6 +14,11 @@
  * Environment variables read by the library:
  *   RAYLIB_SEED    default seed (decimal, default 1) when RaylibAMD_SetSeed was not called
  *   RAYLIB_DEVICE  HIP device ordinal to use (default: LOCAL_RANK if set, else 0)
+ *   RAYLIB_NUM_GPUS  N: Raylib_Render (and every whole-frame render) splits the frame's 8x8 cells round-robin over N devices of
+ *                  this process -- devices RAYLIB_DEVICE .. RAYLIB_DEVICE + N - 1, or the list RAYLIB_GPU_MAP="d0,d1,..." (one
+ *                  entry per rank; a device may be named more than once, which puts several ranks on it: tests) -- and gathers
+ *                  the cells on the first device.  The frame is bit-identical to the one-device frame.  Default 1.
+ *   RAYLIB_GATHER  rccl (default: grouped ncclSend / ncclRecv, librccl loaded at run time) | peer (hipMemcpyPeerAsync pushes)
  */
 #ifndef RAYLIB_AMD_H
 #define RAYLIB_AMD_H
@@ -41,7 +46,7 @@ typedef struct RaylibAMDStats {
 	uint32_t bvhDepth;
 	uint64_t waveTrips;       /* bounce-loop trips summed over waves: rays / (64 * waveTrips) = share of lane slots that traced a ray */
 	uint32_t pathsPerWave;    /* schedule of the megakernel: 64 = k_trace (one path per lane), 128/192/256 = k_trace_pool */
-	uint32_t reserved0;
+	uint32_t ranks;           /* logical ranks (devices) that rendered the frame: 1, or RAYLIB_NUM_GPUS for a whole-frame render */
 } RaylibAMDStats;
 
 /* Seed of the per-(pixel, sample) streams of include/raylib_amd_rng.h. */

@@ -62,6 +62,11 @@ bool RenderInternal(const RendererSettings* settings, Scene* scene, Camera* came
 		if (scene->device) { DeviceReleaseScene(scene->device); scene->device = nullptr; }
 		scene->BuildAccel(camera->beginTime, camera->endTime);
 	}
+	if (scene->sky && !g_images.contains(scene->sky)) {
+		// the reference would read freed memory here; a destroyed panorama is treated as none
+		Log("Raylib_Render: the scene's sky panorama was destroyed; rendering without it");
+		scene->sky = nullptr;
+	}
 	RenderRequest req;
 	req.settings = *settings;
 	req.camera = camera->ToDevice();
@@ -222,11 +227,9 @@ void Raylib_SetSkyPanorama(SceneHandle sh, ImageHandle ih)
 {
 	Scene* s = (Scene*)sh;
 	if (!s) return;
+	// reference geom/scene.h keeps the handle and renderer.cc:159-176 reads the image through it at every miss: the panorama can be
+	// set or replaced after Raylib_FinalizeScene and its pixels are those of render time.  Triangles and BVH are not touched.
 	s->sky = (Image*)ih;
-	if (s->finalized) {   // the reference reads the handle at render time; keep that late-binding behaviour
-		if (s->device) { DeviceReleaseScene(s->device); s->device = nullptr; }
-		s->finalized = false; s->Finalize();
-	}
 }
 void Raylib_SetSunIlluminance(SceneHandle sh, float r, float g, float b)
 {
@@ -269,7 +272,7 @@ void Raylib_Render(const RendererSettings* settings, SceneHandle scene, CameraHa
 	img->hostStale = false;
 	if (!RenderInternal(settings, (Scene*)scene, (Camera*)camera, 0, 1, dev, dev ? nullptr : img->rgba.data()))
 		fprintf(stderr, "Raylib_Render: FAILED (no HIP device or invalid arguments); the image was not written\n");
-	else { img->devValid = (dev != nullptr); img->hostStale = (dev != nullptr); }
+	else { img->devValid = (dev != nullptr); img->hostStale = (dev != nullptr); ++img->version; }
 }
 
 int32_t Raylib_Denoise(ImageHandle, int32_t, ImageHandle, ImageHandle, ImageHandle)
@@ -284,6 +287,7 @@ void Raylib_PostProcess(ImageHandle h)
 	if (!DevicePostProcess(*img)) {
 		Log("Raylib_PostProcess: no HIP device, running on the host");
 		PostProcessHost(*img);
+		++img->version;
 	}
 }
 

@@ -109,7 +109,8 @@ struct DSceneView {
 	const DCube* cubes;
 	float sunIlluminance[3];
 	float sunDirection[3];     // normalised
-	int32_t skyTexture;        // -1 = none
+	const float* sky;          // (float4 per texel) the panorama's texels as of the start of this render (row 0 = top); nullptr = none
+	int32_t skyWidth, skyHeight;
 	int32_t hasSun;
 	int32_t numTriangles;
 };

@@ -73,10 +73,13 @@ struct Image {
 	// Raylib_Render / Raylib_PostProcess leave the result on the device and mark the host pixels stale; whoever reads `rgba`
 	// on the host calls SyncHost() first (one read-back when the pixels are asked for, none per render)
 	bool hostStale = false;
+	// bumped whenever the pixels change (reallocation, a render into the image, PostProcess): a scene that uses the image as its
+	// sky panorama re-reads it at the next render, as the reference does through the handle (renderer.cc:159-176)
+	uint64_t version = 1;
 	void SyncHost() const;
 	Image() = default;
 	Image(const Image& o) : width(o.width), height(o.height) { o.SyncHost(); rgba = o.rgba; }
-	Image& operator=(const Image& o) { o.SyncHost(); width = o.width; height = o.height; rgba = o.rgba; devValid = false; hostStale = false; return *this; }
+	Image& operator=(const Image& o) { o.SyncHost(); width = o.width; height = o.height; rgba = o.rgba; devValid = false; hostStale = false; ++version; return *this; }
 	~Image();
 	void Reallocate(uint32_t w, uint32_t h, float r, float g, float b, float a);
 };
@@ -151,8 +154,6 @@ struct Scene {
 	std::vector<HostTriangle> triangles;
 	std::vector<HostMaterial> materials;
 	std::vector<std::shared_ptr<Image>> textures;
-	std::shared_ptr<Image> skyCopy;
-	int32_t skyTexture = -1;
 	BVH bvh;
 	DeviceScene* device = nullptr;    // uploaded lazily at first render
 
@@ -188,6 +189,7 @@ struct RenderRequest {
 	float* outHostRGBA;     // may be null; receives what outDevice would (row-major image or the rank's cells)
 };
 bool DeviceAvailable();
+int DeviceNumRanks();                          // logical ranks (RAYLIB_NUM_GPUS) the library drives from this process; 0 without a device
 float ParseDecimalFloat(const char* token);   // csrc/rl_obj_loader.cc: the OBJ parser's number reader (= strtof, with exact fast paths)
 // Decoders refuse images beyond this many pixels (16384 x 16384), and images whose claimed size the file cannot plausibly hold:
 // a corrupt header must not turn into a multi-gigabyte allocation.
@@ -209,6 +211,5 @@ void DeviceFreePixels(void* p);
 bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out);
 bool DeviceEvalHook(int kind, Scene* sc, const DCamera* cam, int a, int b, const float* in, int n, uint64_t seed, float* out);
 void DeviceReleaseScene(DeviceScene* dev);
-void DeviceShutdown();
 
 } // namespace rl

@@ -33,6 +33,7 @@ void Image::Reallocate(uint32_t w, uint32_t h, float r, float g, float b, float 
 {
 	SyncHost();
 	devValid = false;
+	++version;
 	// reference render/image.cc:29-34: vector::resize keeps existing pixels, new ones get the clear colour
 	width = w; height = h;
 	size_t old = rgba.size() / 4, now = (size_t)w * h;

@@ -31,8 +31,12 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <thread>
+#include <dlfcn.h>
 #include <float.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -901,16 +905,15 @@ template <int STACK, bool PRIMS>
 __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTime, float rayTMin, int* stk, Counters& c)
 {
 	V3 missResult = v3s(0.0f);
-	if (S.skyTexture >= 0) {
+	if (S.sky) {
 		V3 dir = normalize(d);
 		V3 D = v3(dot(ld3(R.m0), dir), dot(ld3(R.m1), dir), dot(ld3(R.m2), dir));
 		float u = rtm::atan2_(D.z, D.x), v = rtm::asin_(D.y);
 		u *= 0.1591f; v *= 0.3183f;
 		u += 0.5f; v += 0.5f;
-		const DTexture T = S.textures[S.skyTexture];
-		int x = (int)(u * (float)(uint32_t)(T.width - 1));
-		int y = (int)(v * (float)(uint32_t)(T.height - 1));
-		float4 px = ((const float4*)S.texels)[T.offset + (uint32_t)(y * T.width + x)];
+		int x = (int)(u * (float)(uint32_t)(S.skyWidth - 1));
+		int y = (int)(v * (float)(uint32_t)(S.skyHeight - 1));
+		float4 px = ((const float4*)S.sky)[(uint32_t)(y * S.skyWidth + x)];
 		c.texels++;
 		missResult = missResult + v3(px.x, px.y, px.z);
 	}
@@ -1347,16 +1350,15 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 __device__ __forceinline__ V3 MissSky(const DSceneView& S, const SkyRot& R, V3 d, Counters& c)
 {
 	V3 missResult = v3s(0.0f);
-	if (S.skyTexture >= 0) {
+	if (S.sky) {
 		V3 dir = normalize(d);
 		V3 D = v3(dot(ld3(R.m0), dir), dot(ld3(R.m1), dir), dot(ld3(R.m2), dir));
 		float u = rtm::atan2_(D.z, D.x), v = rtm::asin_(D.y);
 		u *= 0.1591f; v *= 0.3183f;
 		u += 0.5f; v += 0.5f;
-		const DTexture T = S.textures[S.skyTexture];
-		int x = (int)(u * (float)(uint32_t)(T.width - 1));
-		int y = (int)(v * (float)(uint32_t)(T.height - 1));
-		float4 px = ((const float4*)S.texels)[T.offset + (uint32_t)(y * T.width + x)];
+		int x = (int)(u * (float)(uint32_t)(S.skyWidth - 1));
+		int y = (int)(v * (float)(uint32_t)(S.skyHeight - 1));
+		float4 px = ((const float4*)S.sky)[(uint32_t)(y * S.skyWidth + x)];
 		c.texels++;
 		missResult = missResult + v3(px.x, px.y, px.z);
 	}
@@ -2037,594 +2039,19 @@ k_eval_math(int fn, const float* __restrict__ x, const float* __restrict__ y, in
 	out[i] = r;
 }
 
-// ===========================================================================
-// Host runtime
-// ===========================================================================
-#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
-	Log("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__, __LINE__, #expr); return false; } } while (0)
-
-struct DeviceScene {
-	DNode4* nodes4 = nullptr; uint32_t stackNeed4 = 0;
-	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
-	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
-	DSphere* spheres = nullptr; DCube* cubes = nullptr;
-	DSceneView view;
-	SkyRot skyRot;
-	uint32_t bvhDepth = 0;
-};
-
-namespace {
-
-struct Runtime {
-	bool probed = false, ok = false;
-	int device = 0;
-	int numCUs = 0;
-	hipStream_t stream = nullptr;
-	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-	// reusable work buffers
-	float4* samples = nullptr; size_t samplesBytes = 0;
-	float4* accum = nullptr; size_t accumBytes = 0;
-	float4* image = nullptr; size_t imageBytes = 0;
-	float* pathStack = nullptr; size_t pathStackBytes = 0;
-	unsigned long long* counters = nullptr;
-	unsigned int* jobCounter = nullptr;
-	std::mutex lock;
-};
-Runtime g_rt;
-bool ReadbackLocked(Image& img);   // device copy -> img.rgba; the runtime lock is held by the caller
-
-bool EnsureRuntime()
+// The frame from the ranks' cell buffers (N > 1 behind Raylib_Render): cell c was rendered by rank c % N as its (c / N)-th cell.
+struct ScatterPlan { uint32_t ranks; uint32_t offset[16]; };   // offset[r]: first float4 of rank r's cells in the gather buffer
+__global__ void __launch_bounds__(RL_BLOCK)
+k_scatter_cells(const float4* __restrict__ gather, float4* __restrict__ out, uint32_t width, uint32_t height, uint32_t cellsX, const ScatterPlan plan)
 {
-	Runtime& R = g_rt;
-	if (R.probed) return R.ok;
-	R.probed = true;
-	int count = 0;
-	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
-		Log("raylib(MI355X): no HIP device visible -- Raylib_Render cannot run (there is no CPU fallback)");
-		return false;
-	}
-	int dev = 0;
-	if (const char* e = getenv("RAYLIB_DEVICE")) dev = atoi(e);
-	else if (const char* l = getenv("LOCAL_RANK")) dev = atoi(l);
-	if (dev < 0 || dev >= count) dev = dev % count;
-	HIP_OK(hipSetDevice(dev));
-	hipDeviceProp_t prop;
-	HIP_OK(hipGetDeviceProperties(&prop, dev));
-	R.device = dev;
-	R.numCUs = prop.multiProcessorCount;
-	HIP_OK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
-	for (int i = 0; i < 4; ++i) HIP_OK(hipEventCreate(&R.ev[i]));
-	HIP_OK(hipMalloc(&R.counters, (CNT_COUNT + 24 + RL_TIMELINE_SLOTS) * sizeof(unsigned long long)));
-	HIP_OK(hipMalloc(&R.jobCounter, sizeof(unsigned int)));
-	Log("raylib(MI355X): device %d %s (%s), %d CUs", dev, prop.name, prop.gcnArchName, R.numCUs);
-	R.ok = true;
-	return true;
-}
-
-template <typename T>
-bool Grow(T*& ptr, size_t& have, size_t need)
-{
-	if (need <= have && ptr) return true;
-	if (ptr) { (void)hipFree(ptr); ptr = nullptr; have = 0; }
-	HIP_OK(hipMalloc(&ptr, need));
-	have = need;
-	return true;
-}
-
-template <typename T>
-bool Upload(T*& dst, const T* src, size_t count)
-{
-	size_t bytes = (count ? count : 1) * sizeof(T);
-	HIP_OK(hipMalloc(&dst, bytes));
-	if (count) HIP_OK(hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice));
-	return true;
-}
-
-// Flatten the host scene into device records (leaf order) and upload.
-bool UploadScene(Scene& sc)
-{
-	if (sc.device) return true;
-	DeviceScene* D = new DeviceScene;
-	const size_t n = sc.triangles.size();
-	std::vector<DTriIsect> isect(n);
-	std::vector<DTriShade> shade(n);
-	auto flatten = [&](size_t k0, size_t k1) { for (size_t k = k0; k < k1; ++k) {
-		const HostTriangle& t = sc.triangles[sc.bvh.triOrder[k]];
-		DTriIsect& I = isect[k];
-		const f3 nrm = normalize(cross(t.v1 - t.v0, t.v2 - t.v0));   // geom/triangle.h:34-38
-		const f3 u = t.v1 - t.v0, v = t.v2 - t.v0;                   // geom/triangle.cc:30-31
-		const float uv = dot(u, v), uu = dot(u, u), vv = dot(v, v);  // :34-38
-		const float uvuv = uv * uv, uuvv = uu * vv;                  // :39-40
-		I.v0[0] = t.v0.x; I.v0[1] = t.v0.y; I.v0[2] = t.v0.z;
-		I.n[0] = nrm.x; I.n[1] = nrm.y; I.n[2] = nrm.z;
-		I.v1[0] = t.v1.x; I.v1[1] = t.v1.y; I.v1[2] = t.v1.z;
-		I.v2[0] = t.v2.x; I.v2[1] = t.v2.y; I.v2[2] = t.v2.z;
-		I.uv = uv; I.uu = uu; I.vv = vv; I.denom = uvuv - uuvv;
-		DTriShade& Sh = shade[k];
-		Sh.n0[0] = t.n0.x; Sh.n0[1] = t.n0.y; Sh.n0[2] = t.n0.z;
-		Sh.n1[0] = t.n1.x; Sh.n1[1] = t.n1.y; Sh.n1[2] = t.n1.z;
-		Sh.n2[0] = t.n2.x; Sh.n2[1] = t.n2.y; Sh.n2[2] = t.n2.z;
-		Sh.s0 = t.s0; Sh.t0 = t.t0; Sh.s1 = t.s1; Sh.t1 = t.t1; Sh.s2 = t.s2; Sh.t2 = t.t2;
-		Sh.material = t.material;
-	} };
-	{   // per-triangle records are independent: all host threads for large scenes (10 M triangles: 0.6 s on one thread)
-		unsigned threads = n >= (1u << 17) ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-		if (const char* e = getenv("RAYLIB_BUILD_THREADS")) { int v = atoi(e); if (v > 0 && n >= (1u << 17)) threads = (unsigned)std::min(v, 32); }
-		std::vector<std::thread> pool;
-		const size_t per = (n + threads - 1) / threads;
-		for (unsigned t = 1; t < threads; ++t) { const size_t k0 = std::min(n, t * per), k1 = std::min(n, (t + 1) * per); if (k0 < k1) pool.emplace_back(flatten, k0, k1); }
-		flatten(0, std::min(n, per));
-		for (std::thread& th : pool) th.join();
-	}
-	std::vector<DMaterial> mats(sc.materials.size());
-	for (size_t i = 0; i < mats.size(); ++i) {
-		const HostMaterial& h = sc.materials[i];
-		DMaterial& m = mats[i]; memset(&m, 0, sizeof(m));
-		m.type = h.type;
-		memcpy(m.albedo, h.albedo, 12); m.roughness = h.roughness; m.metallic = h.metallic;
-		memcpy(m.emissive, h.emissive, 12); m.ior = h.ior; memcpy(m.transmission, h.transmission, 12);
-		m.fuzziness = h.fuzziness; memcpy(m.tex, h.tex, 20);
-	}
-	std::vector<DTexture> texs(sc.textures.size());
-	std::vector<float> pool;
-	for (size_t i = 0; i < texs.size(); ++i) {
-		const Image& im = *sc.textures[i];
-		texs[i].offset = (uint32_t)(pool.size() / 4); texs[i].width = (int32_t)im.width; texs[i].height = (int32_t)im.height; texs[i].pad = 0;
-		if (im.hostStale) {   // a rendered image used as a texture / sky: fetch it (the runtime lock is held here)
-			Image& w = const_cast<Image&>(im);
-			if (!ReadbackLocked(w)) Log("UploadScene: texture %zu could not be read back from the device", i);
-			w.hostStale = false;
-		}
-		pool.insert(pool.end(), im.rgba.begin(), im.rgba.end());
-	}
-	// Albedo maps are read through Texture2D::Sample(bSRGB = true): nearest texel, then pow(texel, 2.2) on all four channels
-	// (reference render/texture.cc:44-50, material.cc:383,400) -- four powf per shading event and per alpha-tested candidate.
-	// The power of a texel does not depend on the ray: every texture some material uses as albedo gets a converted copy here
-	// (host powf = the reference's own function, the one csrc/rl_glibc_math.h restates), and the material points at the copy.
-	{
-		std::vector<int32_t> converted(texs.size(), -1);
-		for (DMaterial& m : mats) {
-			if (m.type != MAT_MICROFACET || m.tex[0] < 0 || (size_t)m.tex[0] >= converted.size()) continue;
-			const size_t src = (size_t)m.tex[0];
-			if (converted[src] < 0) {
-				DTexture t = texs[src];
-				const size_t count = (size_t)t.width * t.height * 4, from = (size_t)t.offset * 4;
-				t.offset = (uint32_t)(pool.size() / 4);
-				pool.resize(pool.size() + count);
-				float* dst = pool.data() + (size_t)t.offset * 4; const float* in = pool.data() + from;
-				unsigned threads = count >= (1u << 20) ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-				std::vector<std::thread> workers;
-				const size_t per = (count + threads - 1) / threads;
-				auto run = [dst, in](size_t a, size_t b) { for (size_t i = a; i < b; ++i) dst[i] = powf(in[i], 2.2f); };
-				for (unsigned w = 1; w < threads; ++w) { const size_t a = std::min(count, w * per), b = std::min(count, (w + 1) * per); if (a < b) workers.emplace_back(run, a, b); }
-				run(0, std::min(count, per));
-				for (std::thread& th : workers) th.join();
-				converted[src] = (int32_t)texs.size();
-				texs.push_back(t);
-			}
-			m.tex[0] = converted[src];
-		}
-	}
-	if (!Upload(D->nodes, sc.bvh.nodes.data(), sc.bvh.nodes.size())) return false;
-	if (!sc.bvh.nodes4.empty()) { if (!Upload(D->nodes4, sc.bvh.nodes4.data(), sc.bvh.nodes4.size())) return false; D->stackNeed4 = sc.bvh.stackNeed4; }
-	if (!Upload(D->isect, isect.data(), n)) return false;
-	if (!Upload(D->shade, shade.data(), n)) return false;
-	if (!Upload(D->materials, mats.data(), mats.size())) return false;
-	if (!Upload(D->textures, texs.data(), texs.size())) return false;
-	if (!Upload(D->texels, pool.data(), pool.size())) return false;
-	std::vector<DSphere> dsph(sc.spheres.size());
-	for (size_t i = 0; i < dsph.size(); ++i) {
-		memset(&dsph[i], 0, sizeof(DSphere));
-		dsph[i].center[0] = sc.spheres[i].center.x; dsph[i].center[1] = sc.spheres[i].center.y; dsph[i].center[2] = sc.spheres[i].center.z;
-		dsph[i].radius = sc.spheres[i].radius; dsph[i].material = sc.spheres[i].material;
-	}
-	std::vector<DCube> dcub(sc.cubes.size());
-	for (size_t i = 0; i < dcub.size(); ++i) {
-		memset(&dcub[i], 0, sizeof(DCube));
-		const HostCube& h = sc.cubes[i];
-		dcub[i].minBounds[0] = h.minBounds.x; dcub[i].minBounds[1] = h.minBounds.y; dcub[i].minBounds[2] = h.minBounds.z; dcub[i].timeStartMove = h.timeStartMove;
-		dcub[i].maxBounds[0] = h.maxBounds.x; dcub[i].maxBounds[1] = h.maxBounds.y; dcub[i].maxBounds[2] = h.maxBounds.z; dcub[i].material = h.material;
-		dcub[i].velocity[0] = h.velocity.x; dcub[i].velocity[1] = h.velocity.y; dcub[i].velocity[2] = h.velocity.z;
-	}
-	if (!Upload(D->spheres, dsph.data(), dsph.size())) return false;
-	if (!Upload(D->cubes, dcub.data(), dcub.size())) return false;
-	DSceneView& V = D->view;
-	V.nodes = D->nodes; V.nodes4 = D->nodes4; V.isect = D->isect; V.shade = D->shade; V.materials = D->materials;
-	V.textures = D->textures; V.texels = D->texels; V.spheres = D->spheres; V.cubes = D->cubes;
-	V.sunIlluminance[0] = sc.sunIlluminance.x; V.sunIlluminance[1] = sc.sunIlluminance.y; V.sunIlluminance[2] = sc.sunIlluminance.z;
-	V.sunDirection[0] = sc.sunDirection.x; V.sunDirection[1] = sc.sunDirection.y; V.sunDirection[2] = sc.sunDirection.z;
-	V.skyTexture = sc.skyTexture;
-	V.hasSun = !(sc.sunIlluminance.x == 0.0f && sc.sunIlluminance.y == 0.0f && sc.sunIlluminance.z == 0.0f);   // renderer.cc:192
-	V.numTriangles = (int32_t)n;
-	{   // Rotator(yaw = 90).rotate rows, reference geom/transform.cc:47-65 (host libm, as the reference)
-		const float pi_f = (float)3.1415926535897932385;
-		const float ry = 90.0f * pi_f / 180.0f, rp = 0.0f * pi_f / 180.0f, rr = 0.0f * pi_f / 180.0f;
-		const float ch = cosf(ry), sh = sinf(ry), cp = cosf(rp), sp = sinf(rp), cb = cosf(rr), sb = sinf(rr);
-		D->skyRot.m0[0] = ch * cb + sh * sp * sb; D->skyRot.m0[1] = sb * cp; D->skyRot.m0[2] = -sh * cb + ch * sp * sb;
-		D->skyRot.m1[0] = -ch * sb + sh * sp * cb; D->skyRot.m1[1] = cb * cp; D->skyRot.m1[2] = sb * sh + ch * sp * cb;
-		D->skyRot.m2[0] = sh * cp; D->skyRot.m2[1] = -sp; D->skyRot.m2[2] = ch * cp;
-	}
-	D->bvhDepth = sc.bvh.depth;
-	sc.device = D;
-	return true;
-}
-
-typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot, float4*, float*, unsigned long long*, unsigned int*);
-
-// poolK = 0: k_trace (one path per lane); poolK = K: k_trace_pool with 64*K paths per wave
-template <int STACK, bool PRIMS>
-TraceKernel SelectTraceKernel(int& poolK, uint32_t bvhDepth, const DeviceScene* D, bool& shortStack, bool& wide)
-{
-	shortStack = false; wide = false;
-	if constexpr (STACK <= 32 && !PRIMS) {
-		const char* e = getenv("RAYLIB_POOL_SHORT_STACK");
-		// the wide tree: default whenever the scene carries one whose worst-case stack fits; RAYLIB_BVH4=0|1 overrides
-		const char* w = getenv("RAYLIB_BVH4");
-		const bool haveWide = D && D->nodes4 != nullptr && D->stackNeed4 <= 64;
-		const bool wantWide = haveWide && (w ? atoi(w) != 0 : true);
-		if (poolK == 2 && wantWide) {
-			wide = true; shortStack = true;
-			if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, true>; }
-			return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, true>;
-		}
-		if constexpr (STACK == 32) {
-			const bool wantShort = e ? atoi(e) != 0 : bvhDepth <= RL_POOL_SHORT_MAXDEPTH;
-			if (poolK == 2 && e && atoi(e) == 4) { shortStack = true; return k_trace_pool<STACK, PRIMS, 2, 4>; }   // tests: nearly every push overflows
-			if (poolK == 2 && wantShort) { shortStack = true; return k_trace_pool<STACK, PRIMS, 2, RL_POOL_SHORT_LSTACK>; }
-		}
-		if (poolK == 2) return k_trace_pool<STACK, PRIMS, 2>;
-		if (poolK == 3) return k_trace_pool<STACK, PRIMS, 3>;
-		if (poolK == 4) return k_trace_pool<STACK, PRIMS, 4>;
-	}
-	poolK = 0;
-	return k_trace<STACK, PRIMS>;
-}
-
-template <int STACK, bool PRIMS>
-bool LaunchRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
-{
-	Runtime& R = g_rt;
-	DeviceScene* D = sc.device;
-	const RendererSettings& st = req.settings;
-	const uint32_t W = st.viewportWidth, H = st.viewportHeight;
-	const uint32_t cellsX = (W + 7) / 8, cellsY = (H + 7) / 8, numCells = cellsX * cellsY;
-	const uint32_t stride = req.cellStride ? req.cellStride : 1;
-	const uint32_t numLocalCells = req.cellFirst < numCells ? (numCells - req.cellFirst + stride - 1) / stride : 0;
-	const uint32_t numSlots = numLocalCells * 64u;
-	const bool rowMajor = (stride == 1 && req.cellFirst == 0);
-	const uint32_t SPP = (uint32_t)(st.samplesPerPixel > 1 ? st.samplesPerPixel : 1);
-	const bool pathTrace = (st.renderMode == RAYLIB_RENDERMODE_Default);
-
-	DRenderParams P; memset(&P, 0, sizeof(P));
-	P.width = W; P.height = H; P.spp = SPP; P.maxPathLength = st.maxPathLength; P.rayTMin = st.rayTMin;
-	P.renderMode = st.renderMode; P.seed = req.seed; P.cellsX = cellsX; P.cellsY = cellsY;
-	P.cellFirst = req.cellFirst; P.cellStride = stride; P.numLocalCells = numLocalCells;
-	P.rowMajorOutput = rowMajor ? 1u : 0u; P.camera = req.camera;
-	P.seedMixed = raylib_rng_mix64(req.seed);
-	P.magicCellsX = cellsX > 1 ? (uint32_t)(0x100000000ull / cellsX) : 0xFFFFFFFFu;
-
-	const size_t outBytes = rowMajor ? (size_t)W * H * sizeof(float4) : (size_t)numSlots * sizeof(float4);
-	float4* out = (float4*)req.outDevice;
-	if (!out) { if (!Grow(R.image, R.imageBytes, outBytes ? outBytes : 16)) return false; out = R.image; }
-
-	HIP_OK(hipMemsetAsync(R.counters, 0, (CNT_COUNT + 24 + RL_TIMELINE_SLOTS) * sizeof(unsigned long long), R.stream));
-	uint32_t schedulePaths = 1;
-	float traceMs = 0.0f;
-	uint32_t launches = 0;
-	bool lastBatchPending = false;
-	HIP_OK(hipEventRecord(R.ev[0], R.stream));
-	if (numSlots == 0) {
-		// nothing to do for this rank
-	} else if (!pathTrace) {
-		const uint32_t blocks = (numSlots + RL_BLOCK - 1) / RL_BLOCK;
-		hipLaunchKernelGGL((k_aov<STACK, PRIMS>), dim3(blocks), dim3(RL_BLOCK), 0, R.stream, P, D->view, out, R.counters);
-		HIP_OK(hipGetLastError());
-	} else {
-		// sample batches: one launch per <= 16 GiB of sample buffer (288 GB of HBM: few, large launches -- every launch pays its
-		// ramp-up and its tail once; measured on the 298 k-triangle scene at 128 spp: 1 launch 61.3 ms, 2 launches 68.9, 4 launches 90.1)
-		const size_t perSample = (size_t)numSlots * sizeof(float4);
-		size_t capBytes = (size_t)16 << 30;
-		if (const char* e = getenv("RAYLIB_SAMPLE_BUFFER_GIB")) { const int v = atoi(e); if (v > 0) capBytes = (size_t)v << 30; }
-		uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(SPP, capBytes / perSample));
-		if (const char* e = getenv("RAYLIB_SAMPLE_BATCH")) { int v = atoi(e); if (v > 0) batch = std::min<uint32_t>((uint32_t)v, SPP); }
-		if (!Grow(R.samples, R.samplesBytes, perSample * batch)) return false;
-		if (batch < SPP && !Grow(R.accum, R.accumBytes, perSample)) return false;
-		// Scheduling of the megakernel: scenes whose BVH needs the 32-entry stack are traversal-bound and run the pool
-		// schedule (k_trace_pool, 128 paths per wave); the Cornell class (tens of triangles, shading-bound) runs one
-		// path per lane (k_trace).  RAYLIB_POOL=0|2|3|4 overrides.
-		// default: the pool schedule for triangle scenes from RAYLIB_POOL_MIN_TRIS triangles on, else k_trace.  Measured crossover
-		// (tools/gpu_crossover.py, tessellated rooms at 1080p x 16 spp, pool time / k_trace time): 36 triangles 1.07, 144: 0.97,
-		// 324: 0.95, 1296: 0.89, 5184: 0.80, 20736: 0.67.
-		uint32_t minTris = 256; if (const char* e = getenv("RAYLIB_POOL_MIN_TRIS")) minTris = (uint32_t)atoi(e);
-		int poolK = (STACK <= 32 && !PRIMS && sc.triangles.size() >= minTris) ? 2 : 0;
-		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
-		bool shortStack = false, wide = false;
-		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, sc.bvh.depth, D, shortStack, wide);
-		// k_trace walks the 4-wide tree too when the scene has one whose worst-case stack fits this instantiation's LDS stack
-		DSceneView traceView = D->view;
-		if (poolK == 0) {
-			const char* w = getenv("RAYLIB_BVH4");
-			const bool baseWide = !PRIMS && D->nodes4 != nullptr && D->stackNeed4 <= (uint32_t)STACK && (w ? atoi(w) != 0 : true);
-			if (!baseWide) traceView.nodes4 = nullptr;
-			wide = baseWide;
-		}
-		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
-		schedulePaths = pathsPerThread;
-		int blocksPerCU = 0;
-		{   // asked once per kernel (the runtime lock is held)
-			static std::map<const void*, int> known;
-			auto it = known.find((const void*)traceKernel);
-			if (it == known.end()) {
-				HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, traceKernel, RL_BLOCK, 0));
-				known[(const void*)traceKernel] = blocksPerCU;
-			} else blocksPerCU = it->second;
-		}
-		if (blocksPerCU < 1) blocksPerCU = 1;
-		if (const char* e = getenv("RAYLIB_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) blocksPerCU = v; }
-		const int depthSlots = st.maxPathLength > 1 ? st.maxPathLength : 1;
-		for (uint32_t s0 = 0; s0 < SPP; s0 += batch) {
-			const uint32_t cnt = std::min(batch, SPP - s0);
-			P.sampleBegin = s0; P.sampleCount = cnt;
-			P.magicSamples = cnt > 1 ? (uint32_t)(0x100000000ull / cnt) : 0xFFFFFFFFu;
-			const uint64_t jobs64 = (uint64_t)numLocalCells * cnt * 64u;
-			if (jobs64 > 0xFFFFFF00ull) { Log("Raylib_Render: job count overflow"); return false; }
-			P.numJobs = (uint32_t)jobs64;
-			uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)R.numCUs * blocksPerCU, (jobs64 + RL_BLOCK * pathsPerThread - 1) / (RL_BLOCK * pathsPerThread));
-			if (blocks < 1) blocks = 1;
-			P.stackStride = blocks * RL_BLOCK * pathsPerThread;
-			{   // jobs per global atomic: ~1/16 of a wave's share, rounded to a multiple of 64 (one cell at one sample), 64..1024.
-				// Measured on the slice one of 8 ranks renders of the 1080p x 64 spp Cornell frame (16.6 M jobs): 64 -> 4.10 ms,
-				// 128 -> 3.62, 256 -> 3.45, 512 -> 3.53, 1024 -> 4.07; on the whole frame 1024 is best (64 -> 33.6 ms: the atomic saturates).
-				const uint64_t waves = (uint64_t)blocks * (RL_BLOCK / 64);
-				uint64_t chunk = ((jobs64 / (waves * 16)) + 32) & ~63ull;
-				if (const char* e = getenv("RAYLIB_JOB_CHUNK")) chunk = (uint64_t)atoi(e);
-				P.jobChunk = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, chunk));
-			}
-			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
-			HIP_OK(hipMemsetAsync(R.jobCounter, 0, sizeof(unsigned int), R.stream));
-			HIP_OK(hipEventRecord(R.ev[2], R.stream));
-			hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
-			                   P, traceView, D->skyRot, R.samples, R.pathStack, R.counters, R.jobCounter);
-			HIP_OK(hipGetLastError());
-			HIP_OK(hipEventRecord(R.ev[3], R.stream));
-			const uint32_t rblocks = (numSlots + RL_BLOCK - 1) / RL_BLOCK;
-			hipLaunchKernelGGL(k_resolve, dim3(rblocks), dim3(RL_BLOCK), 0, R.stream,
-			                   P, R.samples, R.accum, out, (int)(s0 == 0), (int)(s0 + cnt >= SPP));
-			HIP_OK(hipGetLastError());
-			++launches;
-			if (s0 + cnt < SPP) {   // the event pair is reused by the next batch; the last batch's pair is read after the one final sync
-				HIP_OK(hipEventSynchronize(R.ev[3]));
-				float ms = 0.0f;
-				HIP_OK(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]));
-				traceMs += ms;
-			} else lastBatchPending = true;
-		}
-	}
-	// one host synchronisation per render: end event, counters and (if asked for) the image are queued behind the kernels
-	HIP_OK(hipEventRecord(R.ev[1], R.stream));
-	unsigned long long cnt[CNT_COUNT + 24];
-	HIP_OK(hipMemcpyAsync(cnt, R.counters, sizeof(cnt), hipMemcpyDeviceToHost, R.stream));
-	if (req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, outBytes, hipMemcpyDeviceToHost, R.stream));
-	HIP_OK(hipStreamSynchronize(R.stream));
-	if (lastBatchPending) {
-		float ms = 0.0f;
-		HIP_OK(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]));
-		traceMs += ms;
-	}
-	float totalMs = 0.0f;
-	HIP_OK(hipEventElapsedTime(&totalMs, R.ev[0], R.ev[1]));
-
-	stats.rays = cnt[CNT_RAYS]; stats.nodesVisited = cnt[CNT_NODES]; stats.trisTested = cnt[CNT_TRIS];
-	stats.shadedHits = cnt[CNT_SHADED]; stats.texFetches = cnt[CNT_TEXELS]; stats.cameraSamples = cnt[CNT_SAMPLES];
-	stats.waveTrips = cnt[CNT_TRIPS];
-	stats.pathsPerWave = 64u * schedulePaths; stats.reserved0 = 0;
-#ifdef RL_DIAG_TIMELINE
-	if (getenv("RAYLIB_PRINT_STAMPS")) {
-		std::vector<unsigned long long> tl(RL_TIMELINE_SLOTS);
-		HIP_OK(hipMemcpy(tl.data(), R.counters + CNT_COUNT + 24, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-		std::vector<double> st, ex, en;
-		unsigned long long t0 = ~0ull;
-		for (int w = 0; w < 8192; ++w) if (tl[w] && tl[w] < t0) t0 = tl[w];
-		for (int w = 0; w < 8192; ++w) if (tl[w]) { st.push_back((tl[w] - t0) * 0.01); if (tl[8192 + w]) ex.push_back((tl[8192 + w] - t0) * 0.01); en.push_back((tl[16384 + w] - t0) * 0.01); }
-		auto pct = [](std::vector<double>& v, double q) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
-		Log("timeline (us from the first wave's start; last launch, %d waves): start p50 %.1f max %.1f | queue seen empty min %.1f p50 %.1f max %.1f | end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f",
-			(int)st.size(), pct(st, 0.5), pct(st, 1.0), pct(ex, 0.0), pct(ex, 0.5), pct(ex, 1.0), pct(en, 0.0), pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), pct(en, 1.0));
-	}
-#endif
-	if (getenv("RAYLIB_PRINT_STAMPS")) {
-		const double tot = (double)(cnt[CNT_COUNT] + cnt[CNT_COUNT + 1] + cnt[CNT_COUNT + 2] + cnt[CNT_COUNT + 3]);
-		Log("wave steps: node %llu (lane steps %llu, eff %.3f)  tri %llu (lane %llu, eff %.3f)  leaf rounds %llu  trips %llu", cnt[CNT_COUNT + 4], cnt[CNT_NODES], cnt[CNT_NODES] / (64.0 * cnt[CNT_COUNT + 4] + 1), cnt[CNT_COUNT + 5], cnt[CNT_TRIS], cnt[CNT_TRIS] / (64.0 * cnt[CNT_COUNT + 5] + 1), cnt[CNT_COUNT + 6], cnt[CNT_TRIPS]);
-		if (tot > 0) Log("shade split (of all): surface+material %.3f scatter %.3f emit+store %.3f", cnt[CNT_COUNT + 8] / tot, cnt[CNT_COUNT + 9] / tot, cnt[CNT_COUNT + 10] / tot);
-		if (tot > 0) Log("microfacet split (of all): setup %.3f beckmann sample %.3f brdf+pdf %.3f | newton wave iters %llu lane iters %llu (eff %.3f) | microfacet wave calls %llu lanes %llu (eff %.3f)", cnt[CNT_COUNT + 12] / tot, cnt[CNT_COUNT + 13] / tot, cnt[CNT_COUNT + 14] / tot, cnt[CNT_COUNT + 16], cnt[CNT_COUNT + 17], cnt[CNT_COUNT + 17] / (64.0 * cnt[CNT_COUNT + 16] + 1), cnt[CNT_COUNT + 18], cnt[CNT_COUNT + 19], cnt[CNT_COUNT + 19] / (64.0 * cnt[CNT_COUNT + 18] + 1));
-		if (tot > 0) Log("phase shares (shader clock): refill %.3f traverse %.3f shade %.3f fold %.3f", cnt[CNT_COUNT] / tot, cnt[CNT_COUNT + 1] / tot, cnt[CNT_COUNT + 2] / tot, cnt[CNT_COUNT + 3] / tot);
-	}
-	uint64_t px = 0;
-	for (uint32_t k = 0; k < numLocalCells; ++k) {
-		const uint32_t cell = req.cellFirst + k * stride, cx = cell % cellsX, cy = cell / cellsX;
-		px += (uint64_t)std::min(8u, W - cx * 8) * std::min(8u, H - cy * 8);
-	}
-	stats.pixels = px;
-	stats.kernelMs = totalMs; stats.traceKernelMs = pathTrace ? traceMs : totalMs; stats.traceLaunches = pathTrace ? launches : 1;
-	stats.numNodes = (uint32_t)sc.bvh.nodes.size(); stats.numTriangles = (uint32_t)sc.triangles.size(); stats.bvhDepth = sc.bvh.depth;
-	return true;
-}
-
-} // namespace
-
-bool DeviceAvailable()
-{
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	return EnsureRuntime();
-}
-
-bool DeviceRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
-{
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	const auto t0 = std::chrono::steady_clock::now();
-	if (!EnsureRuntime()) return false;
-	HIP_OK(hipSetDevice(g_rt.device));
-	if (!UploadScene(sc)) return false;
-	bool ok;
-	const bool prims = !sc.spheres.empty() || !sc.cubes.empty();
-	if (sc.bvh.depth <= 16 && !prims) ok = LaunchRender<16, false>(sc, req, stats);
-	else if (sc.bvh.depth <= 32) ok = prims ? LaunchRender<32, true>(sc, req, stats) : LaunchRender<32, false>(sc, req, stats);
-	else if (sc.bvh.depth <= 64) ok = prims ? LaunchRender<64, true>(sc, req, stats) : LaunchRender<64, false>(sc, req, stats);
-	else { Log("Raylib_Render: BVH depth %u exceeds the traversal stack (64)", sc.bvh.depth); ok = false; }
-	stats.wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-	return ok;
-}
-
-bool DeviceClosestHit(Scene& sc, const float* rays, int32_t n, float tMin, void* outHits)
-{
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	if (!EnsureRuntime()) return false;
-	HIP_OK(hipSetDevice(g_rt.device));
-	if (!UploadScene(sc)) return false;
-	if (n <= 0) return true;
-	float* dRays = nullptr; DHitOut* dOut = nullptr;
-	HIP_OK(hipMalloc(&dRays, (size_t)n * 6 * sizeof(float)));
-	HIP_OK(hipMalloc(&dOut, (size_t)n * sizeof(DHitOut)));
-	HIP_OK(hipMemcpy(dRays, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
-	const uint32_t blocks = ((uint32_t)n + RL_BLOCK - 1) / RL_BLOCK;
-	if (sc.bvh.depth <= 32) hipLaunchKernelGGL((k_closest_hit<32, true>), dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, sc.device->view, dRays, n, tMin, dOut);
-	else hipLaunchKernelGGL((k_closest_hit<64, true>), dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, sc.device->view, dRays, n, tMin, dOut);
-	HIP_OK(hipGetLastError());
-	HIP_OK(hipStreamSynchronize(g_rt.stream));
-	HIP_OK(hipMemcpy(outHits, dOut, (size_t)n * sizeof(DHitOut), hipMemcpyDeviceToHost));
-	(void)hipFree(dRays); (void)hipFree(dOut);
-	return true;
-}
-
-// kind 0: scatter (in 16 / out 16 floats per record, a = material), 1: camera rays (in 2 / out 7), 2: texture (in 2 / out 4, a = texture, b = sRGB)
-bool DeviceEvalHook(int kind, Scene* sc, const DCamera* cam, int a, int b, const float* in, int n, uint64_t seed, float* out)
-{
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	if (!EnsureRuntime()) return false;
-	HIP_OK(hipSetDevice(g_rt.device));
-	if (sc && !UploadScene(*sc)) return false;
-	if (n <= 0) return true;
-	const int inW = kind == 0 ? 16 : 2, outW = kind == 0 ? 16 : (kind == 1 ? 7 : 4);
-	float *din = nullptr, *dout = nullptr;
-	HIP_OK(hipMalloc(&din, (size_t)n * inW * 4)); HIP_OK(hipMalloc(&dout, (size_t)n * outW * 4));
-	HIP_OK(hipMemcpy(din, in, (size_t)n * inW * 4, hipMemcpyHostToDevice));
-	const dim3 grid(((uint32_t)n + RL_BLOCK - 1) / RL_BLOCK), block(RL_BLOCK);
-	if (kind == 0) hipLaunchKernelGGL(k_eval_scatter, grid, block, 0, g_rt.stream, sc->device->view, a, din, n, (unsigned long long)seed, dout);
-	else if (kind == 1) hipLaunchKernelGGL(k_eval_camera, grid, block, 0, g_rt.stream, *cam, din, n, (unsigned long long)seed, dout);
-	else hipLaunchKernelGGL(k_eval_texture, grid, block, 0, g_rt.stream, sc->device->view, a, b, din, n, dout);
-	HIP_OK(hipGetLastError());
-	HIP_OK(hipStreamSynchronize(g_rt.stream));
-	HIP_OK(hipMemcpy(out, dout, (size_t)n * outW * 4, hipMemcpyDeviceToHost));
-	(void)hipFree(din); (void)hipFree(dout);
-	return true;
-}
-
-bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out)
-{
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	if (!EnsureRuntime()) return false;
-	HIP_OK(hipSetDevice(g_rt.device));
-	if (n <= 0) return true;
-	float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-	HIP_OK(hipMalloc(&dx, (size_t)n * 4)); HIP_OK(hipMalloc(&dout, (size_t)n * 4));
-	HIP_OK(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
-	if (y) { HIP_OK(hipMalloc(&dy, (size_t)n * 4)); HIP_OK(hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice)); }
-	hipLaunchKernelGGL(k_eval_math, dim3(((uint32_t)n + RL_BLOCK - 1) / RL_BLOCK), dim3(RL_BLOCK), 0, g_rt.stream, fn, dx, dy, n, dout);
-	HIP_OK(hipGetLastError());
-	HIP_OK(hipStreamSynchronize(g_rt.stream));
-	HIP_OK(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
-	(void)hipFree(dx); (void)hipFree(dout); if (dy) (void)hipFree(dy);
-	return true;
-}
-
-void* DeviceImagePixels(Image& img)
-{
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	if (!EnsureRuntime()) return nullptr;
-	const size_t need = (size_t)img.width * img.height * sizeof(float4);
-	if (need == 0) return nullptr;
-	if (img.devPixels && img.devBytes >= need) return img.devPixels;
-	if (img.devPixels) { (void)hipFree(img.devPixels); img.devPixels = nullptr; img.devBytes = 0; }
-	if (hipMalloc(&img.devPixels, need) != hipSuccess) { img.devPixels = nullptr; return nullptr; }
-	img.devBytes = need;
-	img.devValid = false;
-	return img.devPixels;
-}
-
-bool DeviceReadback(Image& img)
-{
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	return ReadbackLocked(img);
-}
-namespace {
-bool ReadbackLocked(Image& img)
-{
-	const size_t n = (size_t)img.width * img.height;
-	if (n == 0) return true;
-	if (!g_rt.ok || !img.devPixels || !img.devValid || img.devBytes < n * sizeof(float4)) return false;
-	HIP_OK(hipSetDevice(g_rt.device));
-	img.rgba.resize(n * 4);
-	HIP_OK(hipMemcpyAsync(img.rgba.data(), img.devPixels, n * sizeof(float4), hipMemcpyDeviceToHost, g_rt.stream));
-	HIP_OK(hipStreamSynchronize(g_rt.stream));
-	return true;
-}
-} // namespace
-
-void DeviceFreePixels(void* p)
-{
-	if (!p) return;
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	if (g_rt.ok) (void)hipFree(p);
-}
-
-// Image2D::PostProcess (reference render/image.cc:44-103) on the device: k_pp_max finds the white point
-// (max is exact in any order), k_pp_map applies extended Reinhard on luminance, the clamp and gamma 1/2.2
-// with glibc's exact powf.  Bit-identical to the host statement of the same function.
-bool DevicePostProcess(Image& img)
-{
-	const size_t n = (size_t)img.width * img.height;
-	if (n == 0) return true;
-	float4* px = (float4*)DeviceImagePixels(img);
-	if (!px) return false;
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	HIP_OK(hipSetDevice(g_rt.device));
-	if (!img.devValid) HIP_OK(hipMemcpyAsync(px, img.rgba.data(), n * sizeof(float4), hipMemcpyHostToDevice, g_rt.stream));   // (never stale here: stale implies devValid)
-	unsigned int one; { float f = 1.0f; memcpy(&one, &f, 4); }
-	HIP_OK(hipMemcpyAsync(g_rt.jobCounter, &one, sizeof(one), hipMemcpyHostToDevice, g_rt.stream));
-	const uint32_t blocks = (uint32_t)std::min<size_t>((n + RL_BLOCK - 1) / RL_BLOCK, 2048);
-	hipLaunchKernelGGL(k_pp_max, dim3(blocks), dim3(RL_BLOCK), 0, g_rt.stream, px, n, g_rt.jobCounter);
-	HIP_OK(hipGetLastError());
-	hipLaunchKernelGGL(k_pp_map, dim3((uint32_t)((n + RL_BLOCK - 1) / RL_BLOCK)), dim3(RL_BLOCK), 0, g_rt.stream, px, n, g_rt.jobCounter);
-	HIP_OK(hipGetLastError());
-	float white = 1.0f;
-	HIP_OK(hipMemcpyAsync(&white, g_rt.jobCounter, 4, hipMemcpyDeviceToHost, g_rt.stream));
-	HIP_OK(hipStreamSynchronize(g_rt.stream));
-	img.devValid = true;
-	img.hostStale = true;   // read back when the pixels are asked for (Image::SyncHost)
-	Log("Max white luminance: %f", white);
-	return true;
-}
-
-void DeviceReleaseScene(DeviceScene* D)
-{
-	if (!D) return;
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	(void)hipFree(D->nodes); if (D->nodes4) (void)hipFree(D->nodes4); (void)hipFree(D->isect); (void)hipFree(D->shade);
-	(void)hipFree(D->materials); (void)hipFree(D->textures); (void)hipFree(D->texels); (void)hipFree(D->spheres); (void)hipFree(D->cubes);
-	delete D;
-}
-
-void DeviceShutdown()
-{
-	std::lock_guard<std::mutex> lk(g_rt.lock);
-	Runtime& R = g_rt;
-	if (!R.ok) return;
-	(void)hipFree(R.samples); (void)hipFree(R.accum); (void)hipFree(R.image); (void)hipFree(R.pathStack);
-	(void)hipFree(R.counters); (void)hipFree(R.jobCounter);
-	R.samples = R.accum = R.image = nullptr; R.pathStack = nullptr; R.counters = nullptr; R.jobCounter = nullptr;
-	R.samplesBytes = R.accumBytes = R.imageBytes = R.pathStackBytes = 0;
-	for (int i = 0; i < 4; ++i) if (R.ev[i]) (void)hipEventDestroy(R.ev[i]);
-	if (R.stream) (void)hipStreamDestroy(R.stream);
-	R.stream = nullptr; R.ok = false; R.probed = false;
+	const size_t i = (size_t)blockIdx.x * RL_BLOCK + threadIdx.x;
+	if (i >= (size_t)width * height) return;
+	const uint32_t x = (uint32_t)(i % width), y = (uint32_t)(i / width);
+	const uint32_t cell = (y >> 3) * cellsX + (x >> 3);
+	const uint32_t rank = cell % plan.ranks, local = cell / plan.ranks;
+	out[i] = gather[plan.offset[rank] + local * 64u + ((y & 7u) << 3) + (x & 7u)];
 }
 
 } // namespace rl
+
+#include "rl_runtime.inl"

@@ -86,12 +86,6 @@ void Scene::Finalize()
 		else if (e->kind == PRIM_CUBE) { HostCube c; c.minBounds = e->minBounds; c.maxBounds = e->maxBounds; c.timeStartMove = e->timeStartMove; c.velocity = e->velocity; c.material = mat; cubes.push_back(c); }
 		else { HostTriangle t = e->tri; t.material = mat; t.shape = shapeBase++; triangles.push_back(t); }
 	}
-	skyTexture = -1;
-	if (sky) {
-		skyCopy = std::make_shared<Image>(*sky);
-		skyTexture = (int32_t)textures.size();
-		textures.push_back(skyCopy);
-	}
 	hasMovingCubes = false;
 	for (const HostCube& c : cubes) if (c.velocity.x != 0.0f || c.velocity.y != 0.0f || c.velocity.z != 0.0f) hasMovingCubes = true;
 	if (!BuildAccel(0.0f, 0.0f)) {

@@ -28,7 +28,7 @@ class Stats(C.Structure):
                 ("shadedHits", C.c_uint64), ("texFetches", C.c_uint64), ("cameraSamples", C.c_uint64),
                 ("pixels", C.c_uint64), ("kernelMs", C.c_double), ("traceKernelMs", C.c_double), ("wallMs", C.c_double),
                 ("traceLaunches", C.c_uint32), ("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("bvhDepth", C.c_uint32),
-                ("waveTrips", C.c_uint64), ("pathsPerWave", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("waveTrips", C.c_uint64), ("pathsPerWave", C.c_uint32), ("ranks", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
