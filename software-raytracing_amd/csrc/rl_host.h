@@ -185,6 +185,7 @@ struct RenderRequest {
 	DCamera camera;
 	uint64_t seed;
 	uint32_t cellFirst, cellStride;
+	bool cellMajor = false; // the rank's cells back to back even when it owns every cell (one rank going through the gather path)
 	void* outDevice;        // may be null
 	float* outHostRGBA;     // may be null; receives what outDevice would (row-major image or the rank's cells)
 };

@@ -448,7 +448,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 	const uint32_t stride = req.cellStride ? req.cellStride : 1;
 	const uint32_t numLocalCells = req.cellFirst < numCells ? (numCells - req.cellFirst + stride - 1) / stride : 0;
 	const uint32_t numSlots = numLocalCells * 64u;
-	const bool rowMajor = (stride == 1 && req.cellFirst == 0);
+	const bool rowMajor = (stride == 1 && req.cellFirst == 0 && !req.cellMajor);
 	const uint32_t SPP = (uint32_t)(st.samplesPerPixel > 1 ? st.samplesPerPixel : 1);
 	const bool pathTrace = (st.renderMode == RAYLIB_RENDERMODE_Default);
 	pend.ctx = &R; pend.pathTrace = pathTrace;
@@ -653,7 +653,7 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		RankCtx& C = *R.ranks[(size_t)r];
 		HIP_OK(hipSetDevice(C.device));
 		RenderRequest q = req;
-		q.cellFirst = (uint32_t)r; q.cellStride = (uint32_t)N; q.outHostRGBA = nullptr;
+		q.cellFirst = (uint32_t)r; q.cellStride = (uint32_t)N; q.cellMajor = true; q.outHostRGBA = nullptr;
 		const size_t bytes = (size_t)local[(size_t)r] * 64 * sizeof(float4);
 		float4* dst = R.gather + plan.offset[r];
 		if (remote[(size_t)r]) { if (!Grow(C.cells, C.cellsBytes, std::max<size_t>(16, bytes))) return false; q.outDevice = C.cells; }
