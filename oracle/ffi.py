@@ -155,6 +155,9 @@ class Checker:
             lib.oracle_get_counters.argtypes = [C.c_void_p, C.POINTER(OracleCounters)]
             lib.oracle_material_from_mtl.argtypes = [C.POINTER(C.c_float)] * 4 + [C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p]
             lib.oracle_postprocess.argtypes = [C.POINTER(C.c_float), C.c_int64]
+            lib.oracle_write_obj.restype = C.c_int32
+            lib.oracle_write_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32]
         else:
             lib.ref_render_native.argtypes = [C.c_void_p, C.POINTER(FlatCamera), C.POINTER(FlatSettings), C.POINTER(C.c_float)]
             lib.ref_is_seeded.restype = C.c_int32
@@ -260,6 +263,17 @@ class Checker:
         out = np.zeros(1, MAT_DTYPE)
         self.lib.oracle_material_from_mtl(*[_fp(a) for a in arrs], Ns, Ni, illum, Pr, Pm, int(has_map_kd), out.ctypes.data)
         return out[0]
+
+    def write_obj(self, path, mtl_name, tri, uv, normal, owner, objects, threads=None):
+        """OBJ text of a triangle list (raylib_amd.scenes.build_arrays' arrays) in the format scenes.write_obj_text prints."""
+        tri = np.ascontiguousarray(tri, np.float32); uv = np.ascontiguousarray(uv, np.float32)
+        normal = np.ascontiguousarray(normal, np.float32); owner = np.ascontiguousarray(owner, np.int32)
+        names = (C.c_char_p * len(objects))(*[o[0].encode() for o in objects])
+        mats = (C.c_char_p * len(objects))(*[o[1].encode() for o in objects])
+        ok = self.lib.oracle_write_obj(path.encode(), mtl_name.encode(), len(tri), _fp(tri), _fp(uv), _fp(normal),
+                                       owner.ctypes.data_as(C.POINTER(C.c_int32)), names, mats, threads or min(32, os.cpu_count() or 1))
+        if ok != 1:
+            raise IOError("oracle_write_obj failed: " + path)
 
     def postprocess(self, rgba):
         rgba = np.ascontiguousarray(rgba, np.float32).copy()

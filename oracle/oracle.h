@@ -22,6 +22,8 @@ typedef struct OracleCounters {
 	uint64_t hitsOutsideOwnBox; /* triangle hits accepted although the ray fails the box test of the triangle's own AABB (reachability depends on the tree) */
 } OracleCounters;
 
+/* buildSeed != 0: the reference's BVH construction (random axis per node, drawn from the stream keyed by buildSeed);
+ * buildSeed == 0: a median-split tree built in n log n -- for multi-million-triangle scenes' windows (see BuildBVHFast). */
 void*   oracle_scene_create(const FlatSceneDesc* desc, uint64_t buildSeed);
 void    oracle_scene_destroy(void* scene);
 void    oracle_render(void* scene, const FlatCamera* cam, const FlatSettings* st, uint64_t seed,
@@ -45,6 +47,9 @@ void    oracle_material_from_mtl(const float Kd[3], const float Ks[3], const flo
                                  int32_t hasMapKd, FlatMaterial* out);
 /* Image2D::PostProcess (reference render/image.cc:44-103), in place on n RGBA pixels. */
 void    oracle_postprocess(float* rgba, int64_t numPixels);
+/* Test-scene utility: OBJ text of a triangle list in the format of raylib_amd/scenes.py, written by `threads` host threads. */
+int32_t oracle_write_obj(const char* path, const char* mtlName, int64_t numTris, const float* tri, const float* uv, const float* normal,
+                         const int32_t* owner, const char* const* objectNames, const char* const* objectMaterials, int32_t threads);
 
 #ifdef __cplusplus
 }

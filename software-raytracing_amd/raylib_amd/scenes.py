@@ -103,65 +103,108 @@ def cornell_objects(tall_material=MIRROR, short_material=WHITE):
 
 
 def _tessellate(quad, k):
-    """Split a quad into k*k cells -> list of triangles (3x3 arrays) with UVs (3x2)."""
+    """Split a quad into k*k cells -> (2*k*k, 3, 3) float64 positions and (2*k*k, 3, 2) float64 UVs, cell by cell (row j, column i),
+    two triangles per cell: (a, b, c), (a, c, d)."""
     p0, p1, p2, p3 = [quad[i].astype(np.float64) for i in range(4)]
-    tris = []
+    j, i = np.mgrid[0:k, 0:k]
+    u0, u1, v0, v1 = (i / k).ravel(), ((i + 1) / k).ravel(), (j / k).ravel(), ((j + 1) / k).ravel()
 
     def P(u, v):
+        u, v = u[:, None], v[:, None]
         return ((1 - u) * (1 - v)) * p0 + (u * (1 - v)) * p1 + (u * v) * p2 + ((1 - u) * v) * p3
 
-    for j in range(k):
-        for i in range(k):
-            u0, u1, v0, v1 = i / k, (i + 1) / k, j / k, (j + 1) / k
-            a, b, c, d = P(u0, v0), P(u1, v0), P(u1, v1), P(u0, v1)
-            tris.append((np.array([a, b, c]), np.array([[u0, v0], [u1, v0], [u1, v1]])))
-            tris.append((np.array([a, c, d]), np.array([[u0, v0], [u1, v1], [u0, v1]])))
-    return tris
+    a, b, c, d = P(u0, v0), P(u1, v0), P(u1, v1), P(u0, v1)
+    tri = np.empty((k * k, 2, 3, 3), np.float64)
+    tri[:, 0, 0], tri[:, 0, 1], tri[:, 0, 2] = a, b, c
+    tri[:, 1, 0], tri[:, 1, 1], tri[:, 1, 2] = a, c, d
+    uv = np.empty((k * k, 2, 3, 2), np.float64)
+    uv[:, 0, 0] = np.stack([u0, v0], 1); uv[:, 0, 1] = np.stack([u1, v0], 1); uv[:, 0, 2] = np.stack([u1, v1], 1)
+    uv[:, 1, 0] = np.stack([u0, v0], 1); uv[:, 1, 1] = np.stack([u1, v1], 1); uv[:, 1, 2] = np.stack([u0, v1], 1)
+    return tri.reshape(-1, 3, 3), uv.reshape(-1, 3, 2)
+
+
+def build_arrays(objects, tess=1, displace_fraction=0.0, displace_seed=7, room=((-1, 1), (0, 2), (-1, 1))):
+    """The scene as arrays, in file order: positions (N, 3, 3) float32, UVs (N, 3, 2) float32, flat normals (N, 3) float32 and the
+    object number of every triangle (N,), plus [(name, material)] per object.  These ARE the numbers write_obj prints (with 9
+    significant digits, which a float32 survives), so a flat scene built from them is what any conforming reader makes of the file."""
+    tris, uvs, owner, meta = [], [], [], []
+    for oi, (name, material, quads) in enumerate(objects):
+        meta.append((name, material))
+        for quad in quads:
+            t, uv = _tessellate(quad, tess)
+            tris.append(t); uvs.append(uv); owner.append(np.full(len(t), oi, np.int32))
+    tri = np.concatenate(tris).astype(np.float32)
+    uv = np.concatenate(uvs).astype(np.float32)
+    owner = np.concatenate(owner)
+    n = len(tri)
+    if displace_fraction > 0:
+        # One stream of uniform doubles, consumed triangle by triangle: one draw decides whether the triangle moves, a moved one
+        # takes three more for its new place inside the room (keeps its size and facing).
+        rng = np.random.RandomState(displace_seed)
+        R = rng.random_sample(4 * n)
+        flags = (R < displace_fraction).tobytes()      # one byte per draw: "a triangle that starts here moves"
+        at = np.empty(n, np.int64)
+        pos = 0
+        starts = []
+        for k in range(n):
+            starts.append(pos)
+            pos += 4 if flags[pos] else 1
+        at[:] = starts
+        del starts
+        moved = R[at] < displace_fraction
+        m = np.nonzero(moved)[0]
+        lo = np.array([r[0] + 0.05 for r in room]); hi = np.array([r[1] - 0.05 for r in room])
+        target = (lo + (hi - lo) * np.stack([R[at[m] + 1], R[at[m] + 2], R[at[m] + 3]], 1)).astype(np.float32)
+        centre = tri[m].mean(axis=1)
+        tri[m] = (tri[m] - centre[:, None, :] + target[:, None, :]).astype(np.float32)
+    e1 = tri[:, 1].astype(np.float64) - tri[:, 0]
+    e2 = tri[:, 2].astype(np.float64) - tri[:, 0]
+    nrm = np.cross(e1, e2)
+    length = np.sqrt(np.einsum("ij,ij->i", nrm, nrm))
+    nrm = (nrm / np.maximum(length, 1e-30)[:, None]).astype(np.float32)
+    return dict(tri=tri, uv=uv, normal=nrm, owner=owner, objects=meta)
 
 
 def write_obj(path, objects, mtl_text, tess=1, with_normals=True, with_uvs=True,
               displace_fraction=0.0, displace_seed=7, room=((-1, 1), (0, 2), (-1, 1)), extra_mtl=""):
     """Write <path>.obj and <path>.mtl; return the .obj path and the triangle count."""
     base = os.path.splitext(path)[0]
-    mtl_name = os.path.basename(base) + ".mtl"
-    rng = np.random.RandomState(displace_seed)
-    n_tri = 0
-    vi = 1
-    with open(base + ".obj", "w") as f:
-        f.write("# synthetic scene (raylib_amd.scenes)\nmtllib %s\n" % mtl_name)
-        for name, material, quads in objects:
-            f.write("o %s\nusemtl %s\n" % (name, material))
-            for quad in quads:
-                for tri, uv in _tessellate(quad, tess):
-                    tri = tri.astype(np.float32)
-                    if displace_fraction > 0 and rng.rand() < displace_fraction:
-                        # move this triangle to a random place inside the room (keeps its size and facing)
-                        centre = tri.mean(axis=0)
-                        target = np.array([rng.uniform(lo + 0.05, hi - 0.05) for lo, hi in room], np.float32)
-                        tri = (tri - centre + target).astype(np.float32)
-                    n = np.cross(tri[1].astype(np.float64) - tri[0], tri[2].astype(np.float64) - tri[0])
-                    n = (n / max(np.linalg.norm(n), 1e-30)).astype(np.float32)
-                    for p in tri:
-                        f.write("v %s %s %s\n" % (_f(p[0]), _f(p[1]), _f(p[2])))
-                    if with_uvs:
-                        for t in uv:
-                            f.write("vt %s %s\n" % (_f(t[0]), _f(t[1])))
-                    if with_normals:
-                        f.write("vn %s %s %s\n" % (_f(n[0]), _f(n[1]), _f(n[2])))
-                    idx = []
-                    for c in range(3):
-                        s = str(vi + c)
-                        if with_uvs or with_normals:
-                            s += "/" + (str(vi + c) if with_uvs else "")
-                        if with_normals:
-                            s += "/" + str((vi - 1) // 3 + 1)
-                        idx.append(s)
-                    f.write("f %s\n" % " ".join(idx))
-                    vi += 3
-                    n_tri += 1
+    A = build_arrays(objects, tess, displace_fraction, displace_seed, room)
+    write_obj_text(base + ".obj", A, os.path.basename(base) + ".mtl", with_normals, with_uvs)
     with open(base + ".mtl", "w") as f:
         f.write(mtl_text + extra_mtl)
-    return base + ".obj", n_tri
+    return base + ".obj", len(A["tri"])
+
+
+def write_obj_text(obj_path, A, mtl_name, with_normals=True, with_uvs=True):
+    """The OBJ text of build_arrays' scene: per triangle three `v`, (three `vt`), (one `vn`) and one `f`; `o` / `usemtl` per object."""
+    tri, uv, nrm, owner = A["tri"].astype(np.float64), A["uv"].astype(np.float64), A["normal"].astype(np.float64), A["owner"]
+    out = ["# synthetic scene (raylib_amd.scenes)\nmtllib %s\n" % mtl_name]
+    last = -1
+    tl, ul, nl, ol = tri.tolist(), uv.tolist(), nrm.tolist(), owner.tolist()
+    for k in range(len(tl)):
+        if ol[k] != last:
+            last = ol[k]
+            out.append("o %s\nusemtl %s\n" % A["objects"][last])
+        vi = 3 * k + 1
+        for p in tl[k]:
+            out.append("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+        if with_uvs:
+            for t in ul[k]:
+                out.append("vt %.9g %.9g\n" % (t[0], t[1]))
+        if with_normals:
+            out.append("vn %.9g %.9g %.9g\n" % (nl[k][0], nl[k][1], nl[k][2]))
+        idx = []
+        for c in range(3):
+            w = str(vi + c)
+            if with_uvs or with_normals:
+                w += "/" + (str(vi + c) if with_uvs else "")
+            if with_normals:
+                w += "/" + str(k + 1)
+            idx.append(w)
+        out.append("f %s\n" % " ".join(idx))
+    with open(obj_path, "w") as f:
+        f.write("".join(out))
 
 
 # ---------------------------------------------------------------------------------

@@ -77,6 +77,38 @@ def session_for_case(lib, name, tmpdir):
                                 sky_image=scenes.sky_panorama() if c["sky"] else None)
 
 
+def big_scene(path, objects, mtl_text, oracle, tess, displace_fraction=0.0, sun=(0, 0, 0), sun_dir=(0.0, -1.0, -0.5)):
+    """A large synthetic scene for the BASELINE-size tests: the arrays of scenes.build_arrays, written as OBJ text by the checker
+    library's multi-threaded writer (the Python writer needs minutes for millions of triangles; same format, same digits), and the
+    flat scene the arrays ARE -- every float32 survives its 9 printed digits -- for the oracle.  The caller checks that the product
+    loaded exactly this flat scene.  Returns (obj path, FlatScene)."""
+    A = scenes.build_arrays(objects, tess, displace_fraction)
+    base = os.path.splitext(path)[0]
+    oracle.write_obj(base + ".obj", os.path.basename(base) + ".mtl", A["tri"], A["uv"], A["normal"], A["owner"], A["objects"])
+    with open(base + ".mtl", "w") as f:
+        f.write(mtl_text)
+    mtl = objflat.parse_mtl(base + ".mtl")
+    names = [m["name"] for m in mtl]
+    mats = np.zeros(len(mtl) + 1, ffi.MAT_DTYPE)
+    for i, m in enumerate(mtl):
+        mats[i] = oracle.material_from_mtl(m["Kd"], m["Ks"], m["Ke"], m["Tf"], m["Ns"], m["Ni"], m["illum"], m["Pr"], m["Pm"], bool(m["map_Kd"]))
+        for k in ("texAlbedo", "texNormal", "texRoughness", "texMetallic", "texEmissive"):
+            mats[i][k] = -1
+    mats[-1]["type"] = ffi.MAT_LAMBERTIAN; mats[-1]["albedo"] = (0.5, 0.5, 0.5)
+    for k in ("texAlbedo", "texNormal", "texRoughness", "texMetallic", "texEmissive"):
+        mats[-1][k] = -1
+    n = len(A["tri"])
+    tris = np.zeros(n, ffi.TRI_DTYPE)
+    tris["v0"], tris["v1"], tris["v2"] = A["tri"][:, 0], A["tri"][:, 1], A["tri"][:, 2]
+    tris["n0"] = tris["n1"] = tris["n2"] = A["normal"]
+    tris["st"] = A["uv"].reshape(n, 6)
+    per_object = np.array([names.index(m) if m in names else len(mtl) for _, m in A["objects"]], np.int32)
+    tris["material"] = per_object[A["owner"]]
+    tris["shape"] = A["owner"]
+    flat = ffi.FlatScene(tris, mats, num_shapes=len(A["objects"]), sun_illuminance=sun, sun_direction=sun_dir)
+    return base + ".obj", flat
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -87,6 +119,36 @@ def same(a, b):
     0xFFC00000, the GPU 0x7FC00000.)"""
     a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
     return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+def l2(a, b):
+    """RMS per-pixel L2 distance over the pixels that are finite on both sides (NaN must meet NaN: `helpers.same`)."""
+    d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
+    d = d[np.isfinite(d).all(-1)]
+    return float(np.sqrt((d * d).sum(-1).mean())) if len(d) else 0.0
+
+
+def frac_bit_equal(a, b):
+    return float((bits(a[..., :3]) == bits(b[..., :3])).all(-1).mean())
+
+
+
+def window_mismatches_without_a_tie(oracle, scene, cam, st, img, x0, y0, size):
+    """Compare a window with the oracle; a pixel may differ only if one of its samples met two surfaces at exactly the same t
+    (there the reference's own answer depends on its randomly shaped BVH; the oracle counts such events, the device breaks the tie
+    by the lower triangle slot).  Returns (pixels equal, pixels differing with a tie, pixels differing WITHOUT one)."""
+    want = oracle.render_region(scene, cam, st, x0, y0, size, size, seed=1)
+    got = img[y0:y0 + size, x0:x0 + size]
+    e = same(got[..., :3], want[..., :3]).all(-1)
+    tied = untied = 0
+    for (py, px) in zip(*np.nonzero(~e)):
+        oracle.render_region(scene, cam, st, x0 + int(px), y0 + int(py), 1, 1, seed=1)
+        cn = oracle.counters(scene)
+        if cn["closest_hit_ties"] > 0 or cn["hits_outside_own_box"] > 0:
+            tied += 1
+        else:
+            untied += 1
+    return int(e.sum()), tied, untied, l2(got, want)
 
 
 def random_rays(n, seed, extent=4.0):

@@ -50,34 +50,7 @@ def assert_same_outside_ties(img, want, ties, what):
     assert eq.all(), "%s: %d of %d non-tie pixels differ (L2 %.3e)" % (what, (~eq).any(-1).sum(), len(eq), l2(img, want))
 
 
-def l2(a, b):
-    """RMS per-pixel L2 distance over the pixels that are finite on both sides (NaN must meet NaN: `helpers.same`)."""
-    d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
-    d = d[np.isfinite(d).all(-1)]
-    return float(np.sqrt((d * d).sum(-1).mean())) if len(d) else 0.0
-
-
-def frac_bit_equal(a, b):
-    return float((bits(a[..., :3]) == bits(b[..., :3])).all(-1).mean())
-
-
-
-def window_mismatches_without_a_tie(oracle, scene, cam, st, img, x0, y0, size):
-    """Compare a window with the oracle; a pixel may differ only if one of its samples met two surfaces at exactly the same t
-    (there the reference's own answer depends on its randomly shaped BVH; the oracle counts such events, the device breaks the tie
-    by the lower triangle slot).  Returns (pixels equal, pixels differing with a tie, pixels differing WITHOUT one)."""
-    want = oracle.render_region(scene, cam, st, x0, y0, size, size, seed=1)
-    got = img[y0:y0 + size, x0:x0 + size]
-    e = helpers.same(got[..., :3], want[..., :3]).all(-1)
-    tied = untied = 0
-    for (py, px) in zip(*np.nonzero(~e)):
-        oracle.render_region(scene, cam, st, x0 + int(px), y0 + int(py), 1, 1, seed=1)
-        cn = oracle.counters(scene)
-        if cn["closest_hit_ties"] > 0 or cn["hits_outside_own_box"] > 0:
-            tied += 1
-        else:
-            untied += 1
-    return int(e.sum()), tied, untied, l2(got, want)
+from helpers import l2, frac_bit_equal, window_mismatches_without_a_tie   # noqa: E402
 
 
 def golden(name):
@@ -466,32 +439,6 @@ def test_full_size_pool_schedule_bit_identical(full_size, monkeypatch):
     ses, img, _ = full_size
     monkeypatch.setenv("RAYLIB_POOL", "2")
     assert np.array_equal(bits(ses.render(1920, 1080, 64)), bits(img))
-
-
-def test_configs2_size_scene_all_schedules_agree(gpu_lib, workdir, monkeypatch):
-    """BASELINE configs[2]-size scene (298 k triangles, sun, 1080p; 2 spp to keep the suite short): the default schedule
-    (pool, 19-entry LDS stack), the pool with the whole stack in LDS and the one-path-per-lane kernel give the same bits
-    and the same ray / shading counts.  (Windows of this scene against the CPU oracle: tests/scale/gpu_big.py.)"""
-    from raylib_amd import binding
-    d = os.path.join(str(workdir), "c2"); os.makedirs(d, exist_ok=True)
-    obj, n = helpers.scenes.cornell(os.path.join(d, "c2.obj"), tess=137, displace_fraction=0.2)
-    assert n > 290000
-    cam = helpers.scenes.CONFIG_CAMERAS["breakfast"]
-    ses = binding.SceneSession(gpu_lib, obj, cam["origin"], cam["look_at"], cam["fov"], 1920 / 1080, sun=cam["sun"], sun_dir=cam["sun_dir"])
-    img = ses.render(1920, 1080, 2)
-    st = ses.stats().as_dict()
-    assert st["pathsPerWave"] == 128 and 16 < st["bvhDepth"] <= 24
-    assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
-    for env in (dict(RAYLIB_POOL="0"), dict(RAYLIB_POOL_SHORT_STACK="0")):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        other = ses.render(1920, 1080, 2)
-        so = ses.stats().as_dict()
-        for k in env:
-            monkeypatch.delenv(k)
-        assert np.array_equal(bits(other), bits(img)), env
-        assert so["rays"] == st["rays"] and so["shadedHits"] == st["shadedHits"] and so["cameraSamples"] == st["cameraSamples"], env
-    ses.close()
 
 
 def test_bench_multi_rank_frame_assembly_on_one_gpu():
