@@ -3,9 +3,13 @@
 
 A "step" is one full frame of BASELINE.json's configs[1]: synthetic Cornell box
 (36 triangles), 1920x1080, 64 spp, maxPathLength 5, fixed RNG seed, scene resident
-in HBM.  With N ranks (one process per GPU) the 8x8-pixel cells of the frame are
-dealt round-robin to the ranks, each rank renders its cells into device memory, and
-one RCCL gather per frame brings them to rank 0 (strong scaling: total work fixed).
+in HBM.  At N = 1 the timed call is Raylib_Render itself -- the reference's entry point
+(raylib/raylib.cc:231-239), frame left resident in HBM -- and the frame it produced is
+checked, outside the timed region, against windows rendered by the reference build
+(tests/golden/bench_windows.npz).  With N ranks (one process per GPU) the 8x8-pixel cells
+of the frame are dealt round-robin to the ranks, each rank renders its cells into device
+memory (RaylibAMD_RenderDevice), and one RCCL gather per frame brings them to rank 0
+(strong scaling: total work fixed).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -27,6 +31,10 @@ os.environ.setdefault("RAYLIB_QUIET", "1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+# wave64 VALU instructions per cycle per SIMD-32 at saturation: 0.5 (2 cycles each; MI355X_MICROARCH.md constants table, and measured on
+# the bench box by tools/valu_calib.hip: 944 G wave-instructions/s over 1024 SIMDs at the ~1.9 GHz the chip holds under that load)
+VALU_CYCLES_PER_WAVE_INST = 2.0
+NUM_SIMDS = 256 * 4
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -135,6 +143,7 @@ def main():
         plan = tiling.torch_scatter_plan(w, h, world, dev) if rank == 0 else None
     else:
         mine = torch.zeros(w * h * 4, dtype=torch.float32, device=dev)
+        boundary_image = lib.Raylib_CreateImage(w, h)       # what a front-end hands to Raylib_Render
 
     stats = binding.Stats()
     acc = dict(rays=0, trace_ms=0.0, launches=0, bytes=0, nodes=0, tris=0, shaded=0, texels=0, samples=0, kernel_ms=0.0)
@@ -151,9 +160,12 @@ def main():
             if pending[k] is not None:
                 pending[k].wait()                             # the gather that read this buffer two frames ago ...
                 torch.cuda.current_stream().synchronize()     # ... is complete before the library's stream overwrites it (returns at once in steady state)
-        ok = lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(out.data_ptr()))
-        if ok != 1:
-            raise SystemExit("RaylibAMD_RenderDevice failed")
+        if distributed:
+            ok = lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(out.data_ptr()))
+            if ok != 1:
+                raise SystemExit("RaylibAMD_RenderDevice failed")
+        else:
+            lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, boundary_image)    # the boundary itself; the frame stays in HBM
         if distributed:
             if share:
                 host = out.cpu()
@@ -206,7 +218,42 @@ def main():
     else:
         total_rays, total_samples = float(acc["rays"]), float(acc["samples"])
 
+    def golden_windows(frame_hw4):
+        """The timed frame against windows of the same frame rendered by the REAL reference build (tests/golden/gen_golden.py ->
+        bench_windows.npz: data; only windows in which no sample met two surfaces at exactly the same t).  Bit for bit."""
+        import numpy as np
+        path = os.path.join(ROOT, "tests", "golden", "bench_windows.npz")
+        if not os.path.exists(path):
+            return None
+        g = np.load(path)
+        if args.workload + "_pos" not in g.files:
+            return None
+        pos, px = g[args.workload + "_pos"], g[args.workload + "_px"]
+        bad = 0
+        for (x0, y0), want in zip(pos, px):
+            got = frame_hw4[y0:y0 + 16, x0:x0 + 16]
+            bad += int((np.ascontiguousarray(got[..., :3]).view(np.uint32) != np.ascontiguousarray(want[..., :3]).view(np.uint32)).any(-1).sum())
+        n = len(pos) * 256
+        return ("%d / %d pixels of %d reference-rendered windows bit-identical" % (n - bad, n, len(pos))) if bad == 0 else \
+               ("MISMATCH: %d of %d pixels of the reference-rendered windows differ" % (bad, n))
+
     frame_check = None
+    boundary = None
+    if not distributed:
+        # outside the timed region: (1) the frame the LAST timed Raylib_Render call produced, read back through the reference's own
+        # accessor and compared with the reference build's pixels; (2) the same K steps through the device-pointer entry, for comparison
+        import numpy as np
+        host = np.zeros(w * h * 3, np.float32)
+        lib.Raylib_DumpImageData(boundary_image, host.ctypes.data_as(C.POINTER(C.c_float)))
+        frame_check = golden_windows(host.reshape(h, w, 3))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            if lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, 0, 1, C.c_void_p(mine.data_ptr())) != 1:
+                raise SystemExit("RaylibAMD_RenderDevice failed")
+        torch.cuda.synchronize()
+        boundary = {"timed_entry": "Raylib_Render", "raylib_render_ms_per_step": elapsed / args.steps * 1e3,
+                    "render_device_ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3}
     if distributed and rank == 0:
         # outside the timed region: the frame assembled from the ranks' cells against this rank's own render of the whole frame
         torch.cuda.synchronize()
@@ -214,6 +261,9 @@ def main():
         if lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, 0, 1, C.c_void_p(whole.data_ptr())) == 1:
             same = bool(torch.equal(whole.view(torch.int32), frame.reshape(-1).view(torch.int32)))
             frame_check = "assembled frame bit-identical to a one-GPU render" if same else "MISMATCH between the assembled frame and a one-GPU render"
+            gw = golden_windows(frame.reshape(h, w, 4).cpu().numpy())
+            if gw is not None:
+                frame_check += "; " + gw
         lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(mines[0].data_ptr()))   # stats of a timed-style call again
 
     if rank == 0:
@@ -221,17 +271,37 @@ def main():
         avg_launch_ms = acc["trace_ms"] / launches
         bytes_per_launch = acc["bytes"] / launches
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        # Hardware counters cannot be read from inside this process: `traffic` and the VALU figures are REPLAYED from the committed
+        # rocprofv3 --pmc passes of this same command (tools/pmc_profile.sh -> tools/pmc_traffic.py -> profiles/pmc_traffic.json),
+        # rescaled to this run's launch time where they are rates.  traffic_source says so in the line.
         traffic = None
         valu = None
+        hbm_measured = None
+        bound = "unknown (no PMC passes committed for this workload)"
+        traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(args.workload)
                 if rec and world == 1:
                     traffic = rec["hbm_bytes_per_launch"]
-                    # what actually binds this kernel (same PMC passes): VALU issue and the share of lanes doing work
-                    valu = {"busy_fraction": rec.get("valu_busy_fraction"), "lane_utilisation": rec.get("valu_lane_utilisation"),
-                            "insts_per_launch": rec.get("valu_insts_per_launch")}
+                    traffic_source = "replayed from profiles/pmc_traffic.json (%s)" % rec.get("round", "rocprofv3 --pmc passes of this workload")
+                    hbm_measured = traffic / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else None
+                    # VALU issue: wave-level VALU instructions x 2 cycles / (SIMDs x the launch's cycles), and the share of lanes doing work
+                    cycles = rec.get("cycles_per_launch")
+                    busy = (VALU_CYCLES_PER_WAVE_INST * rec["valu_insts_per_launch"] / NUM_SIMDS / cycles) if cycles else rec.get("valu_busy_fraction")
+                    valu = {"busy_fraction": busy, "lane_utilisation": rec.get("valu_lane_utilisation"),
+                            "insts_per_launch": rec.get("valu_insts_per_launch"), "cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST,
+                            "wave_wait_fraction": rec.get("wave_wait_fraction"), "waves_per_simd": rec.get("waves_per_simd")}
+                    hbm_frac = (hbm_measured or 0.0) / HBM_PEAK_GBS
+                    # what binds: the larger of the two utilisations -- and neither when both are low (then the waves are waiting on
+                    # each other's latencies: too few of them per SIMD to fill the issue slots)
+                    if hbm_frac >= 0.6 and hbm_frac >= (busy or 0.0):
+                        bound = "hbm"
+                    elif (busy or 0.0) >= 0.75:
+                        bound = "valu-issue"
+                    else:
+                        bound = "latency (VALU issue %.0f %%, HBM %.0f %% of peak: neither saturated)" % (100 * (busy or 0.0), 100 * hbm_frac)
             except Exception:
                 traffic = None
         out = {
@@ -250,9 +320,13 @@ def main():
             "config": {"workload": args.workload, "scene_triangles": ntris, "width": w, "height": h, "spp": wl["spp"],
                        "max_path_length": wl["max_path"], "seed": 1, "tiling": "8x8 cells round-robin over %d rank(s)" % world,
                        "rays_per_step": total_rays / args.steps, "camera_samples_per_step": total_samples / args.steps,
-                       "frame_check": frame_check},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "frame_check": frame_check, "boundary": boundary},
+            # achieved / peak / frac: ALGORITHMIC bytes per launch over the launch time against the HBM peak, as SURVEY 8(d) defines the
+            # figure.  On a cache-resident scene those bytes are served by L1 / L2, not HBM: hbm_measured_* is what the memory system
+            # really moved (PMC), `bound` names what the counters say binds the kernel.
+            "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "hbm_measured_gbs": hbm_measured, "hbm_measured_frac": (hbm_measured / HBM_PEAK_GBS) if hbm_measured else None,
                          "kernel": "k_trace" if stats.pathsPerWave <= 64 else "k_trace_pool", "paths_per_wave": int(stats.pathsPerWave), "avg_launch_ms": avg_launch_ms, "launches": acc["launches"],
                          "algorithmic_bytes_per_launch": bytes_per_launch, "valu": valu,
                          "note": "rank 0's launches; algorithmic bytes = 64 B x (BVH nodes + triangle records + shading records) + 16 B x (texels + pixels)"},
@@ -262,6 +336,8 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
 
+    if not distributed:
+        lib.Raylib_DestroyImage(boundary_image)
     ses.close()
     if distributed:
         dist.barrier()

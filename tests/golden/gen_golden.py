@@ -74,6 +74,34 @@ def main(only=None):
         np.savez_compressed(os.path.join(HERE, "config0.npz"), mode0_256x256_spp4=img)
         print("config0 done", img.shape, float(img[..., :3].mean()))
 
+    # ---- windows of bench.py's timed frames (its N = 1 frame check reads this file; it is data, the oracle is not involved there) ----
+    if want("bench_windows"):
+        out = {}
+        for wl, gen, kw, camname, w, h, spp, wins in (
+                ("cornell_1080p_64spp", scenes.cornell, {}, "cornell", 1920, 1080, 64, ((952, 536), (700, 300), (1100, 800), (0, 0), (860, 200), (600, 500), (1300, 600), (1000, 900), (800, 750), (1200, 250))),
+                ("breakfast_300k_1080p_128spp", scenes.cornell, dict(tess=91, displace_fraction=0.2), "breakfast", 1920, 1080, 128,
+                 ((952, 536), (760, 340), (1150, 700), (800, 650), (1100, 380), (300, 300), (1000, 560), (900, 420), (1050, 640)))):
+            c = scenes.CONFIG_CAMERAS[camname]
+            obj, _ = gen(os.path.join(tmp, wl + ".obj"), **kw)
+            flat = objflat.load_obj(obj, orc, sun_illuminance=c["sun"], sun_direction=c["sun_dir"])
+            sr, so = ref.scene_create(flat, BUILD_SEED), orc.scene_create(flat, BUILD_SEED)
+            cam = ffi.make_camera(c["origin"], c["look_at"], c["fov"], w / h)
+            st = ffi.make_settings(w, h, spp)
+            pos, px = [], []
+            for (x0, y0) in wins:
+                a = ref.render_region(sr, cam, st, x0, y0, 16, 16, seed=SEED)
+                b = orc.render_region(so, cam, st, x0, y0, 16, 16, seed=SEED)
+                cn = orc.counters(so)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+                # only windows in which no sample met two surfaces at exactly the same t: there the reference has ONE answer
+                if cn["closest_hit_ties"] == 0 and cn["hits_outside_own_box"] == 0:
+                    pos.append((x0, y0)); px.append(a)
+                else:
+                    print("   window", x0, y0, "of", wl, "left out:", cn["closest_hit_ties"], "ties")
+            out[wl + "_pos"] = np.asarray(pos, np.int32); out[wl + "_px"] = np.asarray(px, np.float32)
+            print("bench windows", wl, len(pos), "of", len(wins))
+        np.savez_compressed(os.path.join(HERE, "bench_windows.npz"), **out)
+
     if only is not None and not (want("procedural") or want("kat") or want("soup")):
         return
     # ---- procedural scene: spheres, a moving cube, Metal / DiffuseLight / Dielectric / Mirror -----------------------
