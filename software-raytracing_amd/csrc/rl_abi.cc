@@ -497,6 +497,7 @@ uint64_t RaylibAMD_SceneBVHHash(SceneHandle sh)
 	feed(s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(DNode));
 	feed(s->bvh.triOrder.data(), s->bvh.triOrder.size() * sizeof(uint32_t));
 	feed(s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(DNode4));
+	feed(s->bvh.nodes4q.data(), s->bvh.nodes4q.size() * sizeof(DNode4Q));
 	return h;
 }
 void RaylibAMD_CameraExport(CameraHandle h, float out[19])

@@ -247,9 +247,54 @@ inline int32_t leafRef(uint32_t first, uint32_t kind, uint32_t count) { return ~
 // Leaf references keep the first primitive slot in 25 bits (DNode, rl_device.h): more primitives than that cannot be addressed.
 bool BVHCapacityOk(size_t numPrimitives) { return numPrimitives < ((size_t)1 << 25); }
 
+// nodes4 -> nodes4q (DNode4Q, rl_device.h).  Every decision is made in double, where origin + q * step is exact, so "the grid
+// box contains the float box" holds exactly.
+static void QuantizeWide(BVH& out)
+{
+	out.nodes4q.assign(out.nodes4.size(), DNode4Q());
+	auto run = [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) {
+		const DNode4& n = out.nodes4[i];
+		DNode4Q q; memset(&q, 0, sizeof(q));
+		uint32_t exps = 0;
+		for (int a = 0; a < 3; ++a) {
+			float lo = FLT_MAX, hi = -FLT_MAX;
+			for (int k = 0; k < 4; ++k) if (n.child[k] != DNODE_EMPTY) { lo = std::min(lo, n.lo[a][k]); hi = std::max(hi, n.hi[a][k]); }
+			if (!(lo <= hi)) { lo = hi = 0.0f; }
+			q.origin[a] = lo;
+			// the smallest power of two whose 255 steps span the node
+			const double extent = (double)hi - (double)lo;
+			int e = 1;   // biased exponent; 1 = 2^-126, the smallest normal
+			if (extent > 0.0) { int x; (void)frexp(extent / 255.0, &x); e = std::max(1, std::min(254, x + 127)); }   // 2^x >= extent / 255
+			double step = ldexp(1.0, e - 127);
+			while (255.0 * step < extent && e < 254) { ++e; step *= 2.0; }
+			exps |= (uint32_t)e << (8 * a);
+			for (int k = 0; k < 4; ++k) {
+				if (n.child[k] == DNODE_EMPTY) { q.qlo[a] |= 255u << (8 * k); continue; }   // inverted: lower 255, upper 0
+				double l = floor(((double)n.lo[a][k] - (double)lo) / step), h = ceil(((double)n.hi[a][k] - (double)lo) / step);
+				l = std::max(0.0, std::min(255.0, l)); h = std::max(0.0, std::min(255.0, h));
+				while (l > 0.0 && (double)lo + l * step > (double)n.lo[a][k]) l -= 1.0;
+				while (h < 255.0 && (double)lo + h * step < (double)n.hi[a][k]) h += 1.0;
+				q.qlo[a] |= (uint32_t)l << (8 * k);
+				q.qhi[a] |= (uint32_t)h << (8 * k);
+			}
+		}
+		q.exps = exps;
+		for (int k = 0; k < 4; ++k) q.child[k] = n.child[k];
+		out.nodes4q[i] = q;
+	} };
+	const size_t n = out.nodes4.size();
+	unsigned threads = n >= (1u << 16) ? std::max(1u, std::min(32u, std::thread::hardware_concurrency())) : 1u;
+	if (const char* e = getenv("RAYLIB_BUILD_THREADS")) { int v = atoi(e); if (v > 0 && n >= (1u << 16)) threads = (unsigned)std::min(v, 32); }
+	std::vector<std::thread> pool;
+	const size_t per = (n + threads - 1) / threads;
+	for (unsigned t = 1; t < threads; ++t) { const size_t a = std::min(n, t * per), b = std::min(n, (t + 1) * per); if (a < b) pool.emplace_back(run, a, b); }
+	run(0, std::min(n, per));
+	for (std::thread& th : pool) th.join();
+}
+
 void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 {
-	out.nodes.clear(); out.nodes4.clear(); out.stackNeed4 = 0; out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
+	out.nodes.clear(); out.nodes4.clear(); out.nodes4q.clear(); out.stackNeed4 = 0; out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
 	const uint32_t n = (uint32_t)prims.size();
 	Box empty; empty.mn = F3(FLT_MAX, FLT_MAX, FLT_MAX); empty.mx = F3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
 
@@ -424,7 +469,8 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 			out.nodes4[it.slot] = nd;
 		}
 		out.stackNeed4 = needMax;
-	} else { out.nodes4.clear(); out.stackNeed4 = 0; }
+		QuantizeWide(out);
+	} else { out.nodes4.clear(); out.nodes4q.clear(); out.stackNeed4 = 0; }
 }
 
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris)
@@ -497,6 +543,19 @@ bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris)
 		}
 		if ((size_t)it.ref >= bvh.nodes4.size()) return false;
 		const DNode4& n = bvh.nodes4[it.ref];
+		{   // the grid node: same children, every grid box around its float box, 255 steps at most
+			if (bvh.nodes4q.size() != bvh.nodes4.size()) return false;
+			const DNode4Q& q = bvh.nodes4q[it.ref];
+			for (int k = 0; k < 4; ++k) {
+				if (q.child[k] != n.child[k]) return false;
+				if (n.child[k] == DNODE_EMPTY) continue;
+				for (int a = 0; a < 3; ++a) {
+					const double step = ldexp(1.0, (int)((q.exps >> (8 * a)) & 255u) - 127);
+					const double lo = (double)q.origin[a] + (double)((q.qlo[a] >> (8 * k)) & 255u) * step, hi = (double)q.origin[a] + (double)((q.qhi[a] >> (8 * k)) & 255u) * step;
+					if (!(lo <= (double)n.lo[a][k] && hi >= (double)n.hi[a][k])) return false;
+				}
+			}
+		}
 		int nk = 0;
 		for (int k = 0; k < 4; ++k) if (n.child[k] != DNODE_EMPTY) ++nk;
 		if (nk < 2 && !(it.ref == 0 && nk >= 1)) return false;

@@ -36,6 +36,29 @@ struct alignas(128) DNode4 {
 };
 static_assert(sizeof(DNode4) == 128, "DNode4");
 
+// The same node on an 8-bit grid, 64 B (half an L2 line; large scenes wait on node data, and this halves the lines a step touches).
+// Child k's box along axis a is [origin[a] + qlo_a,k * step_a, origin[a] + qhi_a,k * step_a], step_a = 2^(e_a - 127): the grid is
+// anchored at the minimum corner of the node's own box, lower planes are rounded down and upper planes up, so a child's grid box
+// CONTAINS its float box.  The closest hit does not depend on how tight a box is (candidate rule, rl_render.hip OwnBoxPass): the
+// image stays bit-identical.  exps: byte a = e_a, the biased exponent of a float (step_a = as_float(e_a << 23)).
+// qlo[a] / qhi[a]: byte k = child k.  An unused child has child[k] == DNODE_EMPTY (and an inverted grid box).
+struct alignas(64) DNode4Q {
+	float origin[3]; uint32_t exps;
+	uint32_t qlo[3]; uint32_t pad0;
+	uint32_t qhi[3]; uint32_t pad1;
+	int32_t child[4];
+};
+static_assert(sizeof(DNode4Q) == 64, "DNode4Q");
+// which of the two the kernels walk (a build-time switch so that both can be timed: make variant EXTRA=-DRL_Q4=0)
+#ifndef RL_Q4
+#define RL_Q4 1
+#endif
+#if RL_Q4
+typedef DNode4Q DWide;
+#else
+typedef DNode4 DWide;
+#endif
+
 // Triangle intersection record, 64 B.  The reference tests ray vs plane, then
 // barycentrics from dot products of edge vectors (geom/triangle.cc:18-58); all
 // ray-independent terms of that formula are precomputed here with the reference's
@@ -99,7 +122,7 @@ struct DCamera {
 
 struct DSceneView {
 	const DNode* nodes;
-	const DNode4* nodes4;      // nullptr unless the scene carries the wide tree
+	const DWide* nodes4;       // nullptr unless the scene carries the wide tree
 	const DTriIsect* isect;
 	const DTriShade* shade;
 	const DMaterial* materials;

@@ -444,35 +444,74 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 	return best.tri >= 0;
 }
 
+// ---- one step on the wide tree: entry distances t0..t3 (INFINITY: not entered) of the four children of S.nodes4[cur] ----
+// RL_Q4 (default): the 64-byte grid node (DNode4Q).  The planes are never decoded: with A = step * inv and B = (origin - o) * inv
+// per axis, plane q's parameter is fma(q, A, B) -- one v_cvt_f32_ubyte and one v_fma per plane, four 16-byte loads per lane instead
+// of seven.  The fused form rounds differently from the reference's (bound - o) * inv, by at most (|B| + 255 |A|) * 2^-23 in
+// absolute terms (cancellation when the ray starts inside the node); four times that bound widens every slab -- near planes earlier,
+// far planes later.  A box test only has to be conservative (the candidate rule decides what counts as a hit), so the image does
+// not change.  A zero direction component (inv = +-inf) would turn the fused form into inf - inf: inv is clamped to +-1e30 for the
+// box tests, which keeps the "no constraint while the origin lies between the planes" meaning and errs towards visiting.
+#if RL_Q4
+__device__ __forceinline__ V3 ClampInv(V3 inv)
+{
+	// only infinities: a finite reciprocal, however large, scales its axis' parameters exactly as the reference's arithmetic does
+	return v3(isinf(inv.x) ? copysignf(1e30f, inv.x) : inv.x, isinf(inv.y) ? copysignf(1e30f, inv.y) : inv.y, isinf(inv.z) ? copysignf(1e30f, inv.z) : inv.z);
+}
+#define RL_WIDE_STEP(S_, cur_, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
+	const float4* np_ = (const float4*)((S_).nodes4 + (cur_)); \
+	const float4 h0_ = np_[0]; const uint4 l_ = ((const uint4*)np_)[1]; const uint4 u_ = ((const uint4*)np_)[2]; \
+	const int4 ch = ((const int4*)np_)[3]; \
+	const uint32_t ex_ = __float_as_uint(h0_.w); \
+	const float Ax_ = __uint_as_float((ex_ & 0xffu) << 23) * (inv_).x, Ay_ = __uint_as_float(((ex_ >> 8) & 0xffu) << 23) * (inv_).y, Az_ = __uint_as_float(((ex_ >> 16) & 0xffu) << 23) * (inv_).z; \
+	const float Bx_ = (h0_.x - (o_).x) * (inv_).x, By_ = (h0_.y - (o_).y) * (inv_).y, Bz_ = (h0_.z - (o_).z) * (inv_).z; \
+	const float Ex_ = __builtin_fmaf(255.0f, fabsf(Ax_), fabsf(Bx_)) * 4.76837158e-7f, Ey_ = __builtin_fmaf(255.0f, fabsf(Ay_), fabsf(By_)) * 4.76837158e-7f, Ez_ = __builtin_fmaf(255.0f, fabsf(Az_), fabsf(Bz_)) * 4.76837158e-7f; \
+	const float Bnx_ = Bx_ - Ex_, Bfx_ = Bx_ + Ex_, Bny_ = By_ - Ey_, Bfy_ = By_ + Ey_, Bnz_ = Bz_ - Ez_, Bfz_ = Bz_ + Ez_; \
+	const uint32_t nX_ = (nx_) ? u_.x : l_.x, fX_ = (nx_) ? l_.x : u_.x, nY_ = (ny_) ? u_.y : l_.y, fY_ = (ny_) ? l_.y : u_.y, nZ_ = (nz_) ? u_.z : l_.z, fZ_ = (nz_) ? l_.z : u_.z; \
+	const float tMinL_ = (tMin_), tmxL_ = (tmx_), widenL_ = (widen_); \
+	float t0, t1, t2, t3; \
+	RL_QSLAB(0, t0) RL_QSLAB(8, t1) RL_QSLAB(16, t2) RL_QSLAB(24, t3)
+#define RL_QSLAB(sh, tk) { \
+	float tn = tMinL_, tf = tmxL_; \
+	tn = fmaxf(tn, __builtin_fmaf((float)((nX_ >> sh) & 0xffu), Ax_, Bnx_)); tf = fminf(tf, __builtin_fmaf((float)((fX_ >> sh) & 0xffu), Ax_, Bfx_)); \
+	tn = fmaxf(tn, __builtin_fmaf((float)((nY_ >> sh) & 0xffu), Ay_, Bny_)); tf = fminf(tf, __builtin_fmaf((float)((fY_ >> sh) & 0xffu), Ay_, Bfy_)); \
+	tn = fmaxf(tn, __builtin_fmaf((float)((nZ_ >> sh) & 0xffu), Az_, Bnz_)); tf = fminf(tf, __builtin_fmaf((float)((fZ_ >> sh) & 0xffu), Az_, Bfz_)); \
+	tk = (tf * widenL_ < tn) ? INFINITY : tn; }
+#else
+#define ClampInv(inv) (inv)
+#define RL_WIDE_STEP(S_, cur_, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
+	const float4* np_ = (const float4*)((S_).nodes4 + (cur_)); \
+	const float4 lox_ = np_[0], loy_ = np_[1], loz_ = np_[2], hix_ = np_[3], hiy_ = np_[4], hiz_ = np_[5]; \
+	const int4 ch = ((const int4*)np_)[6]; \
+	const float4 nX_ = (nx_) ? hix_ : lox_, fX_ = (nx_) ? lox_ : hix_; \
+	const float4 nY_ = (ny_) ? hiy_ : loy_, fY_ = (ny_) ? loy_ : hiy_; \
+	const float4 nZ_ = (nz_) ? hiz_ : loz_, fZ_ = (nz_) ? loz_ : hiz_; \
+	const float tMinL_ = (tMin_), tmxL_ = (tmx_), widenL_ = (widen_); const V3 oL_ = (o_), invL_ = (inv_); \
+	float t0, t1, t2, t3; \
+	RL_FSLAB(x, t0) RL_FSLAB(y, t1) RL_FSLAB(z, t2) RL_FSLAB(w, t3)
+#define RL_FSLAB(k, tk) { \
+	float tn = tMinL_, tf = tmxL_; \
+	tn = fmaxf(tn, (nX_.k - oL_.x) * invL_.x); tf = fminf(tf, (fX_.k - oL_.x) * invL_.x); \
+	tn = fmaxf(tn, (nY_.k - oL_.y) * invL_.y); tf = fminf(tf, (fY_.k - oL_.y) * invL_.y); \
+	tn = fmaxf(tn, (nZ_.k - oL_.z) * invL_.z); tf = fminf(tf, (fZ_.k - oL_.z) * invL_.z); \
+	tk = (tf * widenL_ < tn) ? INFINITY : tn; }
+#endif
+
 // The same closest-hit search on the BVH4 (DNode4): four slab tests per step, hit children ordered by entry distance.
 template <int STACK, bool ANYHIT, bool PRIMS>
 __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c)
 {
 	c.rays++;
-	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-	const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+	const V3 invb = ClampInv(v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));   // for the box tests (the candidate rule divides again: exact, and rare)
+	const bool nx = invb.x < 0.0f, ny = invb.y < 0.0f, nz = invb.z < 0.0f;
 	best.t = INFINITY; best.tri = -1; best.a = 0.0f; best.b = 0.0f;
 	int sp = 0, cur = 0;
 	const int DONE = 0x7fffffff;
 	for (;;) {
 		while (cur >= 0 && cur != DONE) {
-			const float4* np = (const float4*)(S.nodes4 + cur);
-			const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
-			const int4 ch = ((const int4*)np)[6];
-			c.nodes += 2;
+			c.nodes += RL_Q4 ? 1 : 2;   // 64-byte records fetched
 			const float tmx = fminf(best.t, FLT_MAX);
-			const float4 nX = nx ? hix : lox, fX = nx ? lox : hix;
-			const float4 nY = ny ? hiy : loy, fY = ny ? loy : hiy;
-			const float4 nZ = nz ? hiz : loz, fZ = nz ? loz : hiz;
-			float t0, t1, t2, t3;
-			#define RL_SLAB4B(k, tk) { \
-				float tn = tMin, tf = tmx; \
-				tn = fmaxf(tn, (nX.k - o.x) * inv.x); tf = fminf(tf, (fX.k - o.x) * inv.x); \
-				tn = fmaxf(tn, (nY.k - o.y) * inv.y); tf = fminf(tf, (fY.k - o.y) * inv.y); \
-				tn = fmaxf(tn, (nZ.k - o.z) * inv.z); tf = fminf(tf, (fZ.k - o.z) * inv.z); \
-				tk = (tf * RL_BOX_WIDEN < tn) ? INFINITY : tn; }
-			RL_SLAB4B(x, t0) RL_SLAB4B(y, t1) RL_SLAB4B(z, t2) RL_SLAB4B(w, t3)
-			#undef RL_SLAB4B
+			RL_WIDE_STEP(S, cur, o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, t0, t1, t2, t3, ch)
 			int r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
 			if (r0 == DNODE_EMPTY) t0 = INFINITY;
 			if (r1 == DNODE_EMPTY) t1 = INFINITY;
@@ -503,7 +542,7 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 				const float wv = dot(w, T.v), wu = dot(w, T.u);
 				const float pa = (T.uv * wv - T.vv * wu) / T.denom;
 				const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, inv, tMin, t)) {
+				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tMin, t)) {
 					if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 					best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 					if (ANYHIT) return true;
@@ -1269,24 +1308,9 @@ template <int LSTACK, int STACK>
 __device__ __forceinline__ bool NodeStep4(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c)
 {
 	RL_WSTEP(4);
-	const float4* np = (const float4*)(S.nodes4 + T.cur);
-	const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
-	const int4 ch = ((const int4*)np)[6];
-	c.nodes += 2;
+	c.nodes += RL_Q4 ? 1 : 2;   // 64-byte records fetched
 	const float tmx = fminf(T.best.t, FLT_MAX);
-	// near / far planes per axis by the ray's sign, for the four children at once
-	const float4 nX = T.nx ? hix : lox, fX = T.nx ? lox : hix;
-	const float4 nY = T.ny ? hiy : loy, fY = T.ny ? loy : hiy;
-	const float4 nZ = T.nz ? hiz : loz, fZ = T.nz ? loz : hiz;
-	float t0, t1, t2, t3;
-	#define RL_SLAB4(k, tk) { \
-		float tn = tMin, tf = tmx; \
-		tn = fmaxf(tn, (nX.k - T.o.x) * T.inv.x); tf = fminf(tf, (fX.k - T.o.x) * T.inv.x); \
-		tn = fmaxf(tn, (nY.k - T.o.y) * T.inv.y); tf = fminf(tf, (fY.k - T.o.y) * T.inv.y); \
-		tn = fmaxf(tn, (nZ.k - T.o.z) * T.inv.z); tf = fminf(tf, (fZ.k - T.o.z) * T.inv.z); \
-		tk = (tf * RL_POOL_WIDEN < tn) ? INFINITY : tn; }
-	RL_SLAB4(x, t0) RL_SLAB4(y, t1) RL_SLAB4(z, t2) RL_SLAB4(w, t3)
-	#undef RL_SLAB4
+	RL_WIDE_STEP(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)   // T.inv was clamped when the ray was fetched
 	int r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
 	if (r0 == DNODE_EMPTY) t0 = INFINITY;
 	if (r1 == DNODE_EMPTY) t1 = INFINITY;
@@ -1608,6 +1632,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 							T.d = T.anyhit ? -ld3(S.sunDirection) : v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
 							T.rayTime = PRIMS ? pool[F_TIME][slot] : 0.0f;
 							T.inv = v3(FastRcp(T.d.x), FastRcp(T.d.y), FastRcp(T.d.z));
+							if (WIDE) T.inv = ClampInv(T.inv);   // only the grid nodes' fused plane arithmetic wants finite reciprocals; Slab() relies on +-inf / NaN
 							T.nx = T.inv.x < 0.0f; T.ny = T.inv.y < 0.0f; T.nz = T.inv.z < 0.0f;
 							T.best.t = INFINITY; T.best.tri = -1; T.best.a = 0.0f; T.best.b = 0.0f;
 							T.cur = 0; T.sp = 0; T.leafI = 0;

@@ -21,7 +21,7 @@ namespace rl {
 // One physical device's copy of a scene.
 struct DeviceSceneCopy {
 	int device = 0;
-	DNode4* nodes4 = nullptr;
+	DWide* nodes4 = nullptr;
 	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
 	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
 	DSphere* spheres = nullptr; DCube* cubes = nullptr;
@@ -349,7 +349,11 @@ bool UploadScene(Scene& sc)
 		D->copy.push_back(C);
 		bool ok = hipSetDevice(C->device) == hipSuccess;
 		ok = ok && Upload(C->nodes, sc.bvh.nodes.data(), sc.bvh.nodes.size());
+#if RL_Q4
+		if (ok && D->hasNodes4) ok = Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size());
+#else
 		if (ok && D->hasNodes4) ok = Upload(C->nodes4, sc.bvh.nodes4.data(), sc.bvh.nodes4.size());
+#endif
 		ok = ok && Upload(C->isect, isect.data(), n) && Upload(C->shade, shade.data(), n);
 		ok = ok && Upload(C->materials, mats.data(), mats.size()) && Upload(C->textures, texs.data(), texs.size()) && Upload(C->texels, pool.data(), pool.size());
 		ok = ok && Upload(C->spheres, dsph.data(), dsph.size()) && Upload(C->cubes, dcub.data(), dcub.size());

@@ -457,8 +457,29 @@ def test_bench_multi_rank_frame_assembly_on_one_gpu():
     assert len(lines) == 1, out.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["frame_check"] == "assembled frame bit-identical to a one-GPU render"
+    assert d["config"]["frame_check"].startswith("assembled frame bit-identical to a one-GPU render") and "MISMATCH" not in d["config"]["frame_check"]
+    assert "reference-rendered windows bit-identical" in d["config"]["frame_check"]
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_bench_default_run_times_the_boundary_and_checks_the_frame():
+    """`python bench.py` as the driver runs it at N = 1: the timed call is Raylib_Render, and the frame it produced is compared, outside
+    the timed region, with windows the reference build rendered (tests/golden/bench_windows.npz)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RAYLIB_POOL", "RAYLIB_LIB", "BENCH_SHARE_GPU", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["boundary"]["timed_entry"] == "Raylib_Render"
+    assert d["config"]["frame_check"].endswith("reference-rendered windows bit-identical") and "MISMATCH" not in d["config"]["frame_check"]
+    r = d["roofline"]
+    assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_measured_frac", "traffic_source"}
+    if r["valu"] is not None:
+        assert 0.0 < r["valu"]["busy_fraction"] <= 1.0
 
 
 def test_bench_rccl_gather_path_with_one_rank():
@@ -477,7 +498,8 @@ def test_bench_rccl_gather_path_with_one_rank():
     assert len(lines) == 1, out.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
-    assert d["config"]["frame_check"] == "assembled frame bit-identical to a one-GPU render"
+    assert d["config"]["frame_check"].startswith("assembled frame bit-identical to a one-GPU render") and "MISMATCH" not in d["config"]["frame_check"]
+    assert "reference-rendered windows bit-identical" in d["config"]["frame_check"]
 
 
 def test_deferred_readback_reaches_every_host_reader(gpu_lib, workdir):
