@@ -49,14 +49,10 @@ struct alignas(64) DNode4Q {
 	int32_t child[4];
 };
 static_assert(sizeof(DNode4Q) == 64, "DNode4Q");
-// which of the two the kernels walk (a build-time switch so that both can be timed: make variant EXTRA=-DRL_Q4=0)
+// which of the two the POOL schedule walks (a build-time switch so that both can be timed: make variant EXTRA=-DRL_Q4=0);
+// k_trace has both as instantiations and takes the float boxes whenever the scene carries them
 #ifndef RL_Q4
 #define RL_Q4 1
-#endif
-#if RL_Q4
-typedef DNode4Q DWide;
-#else
-typedef DNode4 DWide;
 #endif
 
 // Triangle intersection record, 64 B.  The reference tests ray vs plane, then
@@ -122,7 +118,8 @@ struct DCamera {
 
 struct DSceneView {
 	const DNode* nodes;
-	const DWide* nodes4;       // nullptr unless the scene carries the wide tree
+	const DNode4Q* nodes4;     // the wide tree on the 8-bit grid: what the pool schedule walks (nullptr: the scene has none)
+	const DNode4* nodes4f;     // the wide tree with float boxes: uploaded for small, cache-resident scenes (k_trace), where the grid saves nothing
 	const DTriIsect* isect;
 	const DTriShade* shade;
 	const DMaterial* materials;

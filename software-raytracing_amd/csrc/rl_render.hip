@@ -452,13 +452,12 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 // far planes later.  A box test only has to be conservative (the candidate rule decides what counts as a hit), so the image does
 // not change.  A zero direction component (inv = +-inf) would turn the fused form into inf - inf: inv is clamped to +-1e30 for the
 // box tests, which keeps the "no constraint while the origin lies between the planes" meaning and errs towards visiting.
-#if RL_Q4
 __device__ __forceinline__ V3 ClampInv(V3 inv)
 {
 	// only infinities: a finite reciprocal, however large, scales its axis' parameters exactly as the reference's arithmetic does
 	return v3(isinf(inv.x) ? copysignf(1e30f, inv.x) : inv.x, isinf(inv.y) ? copysignf(1e30f, inv.y) : inv.y, isinf(inv.z) ? copysignf(1e30f, inv.z) : inv.z);
 }
-#define RL_WIDE_STEP(S_, cur_, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
+#define RL_WIDE_STEP_Q(S_, cur_, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
 	const float4* np_ = (const float4*)((S_).nodes4 + (cur_)); \
 	const float4 h0_ = np_[0]; const uint4 l_ = ((const uint4*)np_)[1]; const uint4 u_ = ((const uint4*)np_)[2]; \
 	const int4 ch = ((const int4*)np_)[3]; \
@@ -477,10 +476,8 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 	tn = fmaxf(tn, __builtin_fmaf((float)((nY_ >> sh) & 0xffu), Ay_, Bny_)); tf = fminf(tf, __builtin_fmaf((float)((fY_ >> sh) & 0xffu), Ay_, Bfy_)); \
 	tn = fmaxf(tn, __builtin_fmaf((float)((nZ_ >> sh) & 0xffu), Az_, Bnz_)); tf = fminf(tf, __builtin_fmaf((float)((fZ_ >> sh) & 0xffu), Az_, Bfz_)); \
 	tk = (tf * widenL_ < tn) ? INFINITY : tn; }
-#else
-#define ClampInv(inv) (inv)
-#define RL_WIDE_STEP(S_, cur_, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
-	const float4* np_ = (const float4*)((S_).nodes4 + (cur_)); \
+#define RL_WIDE_STEP_F(S_, cur_, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
+	const float4* np_ = (const float4*)((S_).nodes4f + (cur_)); \
 	const float4 lox_ = np_[0], loy_ = np_[1], loz_ = np_[2], hix_ = np_[3], hiy_ = np_[4], hiz_ = np_[5]; \
 	const int4 ch = ((const int4*)np_)[6]; \
 	const float4 nX_ = (nx_) ? hix_ : lox_, fX_ = (nx_) ? lox_ : hix_; \
@@ -495,24 +492,26 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 	tn = fmaxf(tn, (nY_.k - oL_.y) * invL_.y); tf = fminf(tf, (fY_.k - oL_.y) * invL_.y); \
 	tn = fmaxf(tn, (nZ_.k - oL_.z) * invL_.z); tf = fminf(tf, (fZ_.k - oL_.z) * invL_.z); \
 	tk = (tf * widenL_ < tn) ? INFINITY : tn; }
-#endif
 
 // The same closest-hit search on the BVH4 (DNode4): four slab tests per step, hit children ordered by entry distance.
-template <int STACK, bool ANYHIT, bool PRIMS>
+// FULL: float boxes (S.nodes4f), else the grid nodes (S.nodes4)
+template <int STACK, bool ANYHIT, bool PRIMS, bool FULL>
 __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c)
 {
 	c.rays++;
-	const V3 invb = ClampInv(v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));   // for the box tests (the candidate rule divides again: exact, and rare)
+	V3 invb = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // for the box tests (the candidate rule divides again: exact, and rare)
+	if (!FULL) invb = ClampInv(invb);
 	const bool nx = invb.x < 0.0f, ny = invb.y < 0.0f, nz = invb.z < 0.0f;
 	best.t = INFINITY; best.tri = -1; best.a = 0.0f; best.b = 0.0f;
 	int sp = 0, cur = 0;
 	const int DONE = 0x7fffffff;
 	for (;;) {
 		while (cur >= 0 && cur != DONE) {
-			c.nodes += RL_Q4 ? 1 : 2;   // 64-byte records fetched
+			c.nodes += FULL ? 2 : 1;   // 64-byte records fetched
 			const float tmx = fminf(best.t, FLT_MAX);
-			RL_WIDE_STEP(S, cur, o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, t0, t1, t2, t3, ch)
-			int r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
+			float t0, t1, t2, t3; int r0, r1, r2, r3;
+			if (FULL) { RL_WIDE_STEP_F(S, cur, o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, a0, a1, a2, a3, ch) t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w; }
+			else { RL_WIDE_STEP_Q(S, cur, o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, a0, a1, a2, a3, ch) t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w; }
 			if (r0 == DNODE_EMPTY) t0 = INFINITY;
 			if (r1 == DNODE_EMPTY) t1 = INFINITY;
 			if (r2 == DNODE_EMPTY) t2 = INFINITY;
@@ -940,7 +939,7 @@ __device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rn
 struct SkyRot { float m0[3], m1[3], m2[3]; };   // Rotator(yaw 90).rotate rows, computed on the host (renderer.cc:166-168)
 
 // Miss shader: sky panorama + sun (reference render/renderer.cc:155-199)
-template <int STACK, bool PRIMS>
+template <int STACK, bool PRIMS, bool FULL>
 __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTime, float rayTMin, int* stk, Counters& c)
 {
 	V3 missResult = v3s(0.0f);
@@ -958,7 +957,7 @@ __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V
 	}
 	if (S.hasSun) {
 		HitRec tmp;
-		const bool occluded = (!PRIMS && S.nodes4) ? Traverse4<STACK, true, PRIMS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c)
+		const bool occluded = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, true, PRIMS, FULL>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c)
 		                                           : Traverse<STACK, true, PRIMS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c);
 		if (!occluded) missResult = missResult + ld3(S.sunIlluminance);
 	}
@@ -994,7 +993,8 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 #define RL_TRACE_MIN_WAVES 4   /* 4 waves per SIMD = 4 workgroups per CU: caps the kernel at 128 VGPRs */
 #endif
 // PRIMS: the scene holds spheres / cubes (their leaf and shading code is compiled out of the triangle-only variant)
-template <int STACK, bool PRIMS>
+// FULL: the wide tree, if the launch carries one, has float boxes (S.nodes4f) -- small scenes; else grid nodes (S.nodes4)
+template <int STACK, bool PRIMS, bool FULL>
 __global__ void __launch_bounds__(RL_BLOCK, (STACK <= 32 ? RL_TRACE_MIN_WAVES : 2))
 k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
         float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
@@ -1083,7 +1083,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 							if (sunQuick) {
 								c.rays++; c.nodes++;   // the closest-hit query this replaces fetches the root node and stops
 								DSceneView Sq = S; Sq.hasSun = 0;
-								V3 L = MissShader<STACK, PRIMS>(Sq, R, o, d, rayTime, P.rayTMin, stk, c);
+								V3 L = MissShader<STACK, PRIMS, FULL>(Sq, R, o, d, rayTime, P.rayTMin, stk, c);
 								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
 								samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
 								active = false;
@@ -1106,7 +1106,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 		const bool doTrace = active && depth < P.maxPathLength;   // renderer.cc:120-123 otherwise
 		bool hit = false;
 		// the 4-wide tree when the launch carries it (triangle scenes; half the steps: 24.6 -> 22.4 ms on the Cornell frame)
-		if (doTrace) hit = (!PRIMS && S.nodes4) ? Traverse4<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
+		if (doTrace) hit = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, false, PRIMS, FULL>(S, o, d, rayTime, P.rayTMin, h, stk, c) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
 		RL_STAMP(1);
 		if (active) {
 			bool done = false;
@@ -1139,7 +1139,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				}
 				RL_SUBSTAMP(2);
 			} else {
-				L = MissShader<STACK, PRIMS>(S, R, o, d, rayTime, P.rayTMin, stk, c);
+				L = MissShader<STACK, PRIMS, FULL>(S, R, o, d, rayTime, P.rayTMin, stk, c);
 				done = true;
 			}
 			RL_STAMP(2);
@@ -1310,7 +1310,11 @@ __device__ __forceinline__ bool NodeStep4(const DSceneView& S, Trav& T, float tM
 	RL_WSTEP(4);
 	c.nodes += RL_Q4 ? 1 : 2;   // 64-byte records fetched
 	const float tmx = fminf(T.best.t, FLT_MAX);
-	RL_WIDE_STEP(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)   // T.inv was clamped when the ray was fetched
+#if RL_Q4
+	RL_WIDE_STEP_Q(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)   // T.inv was clamped when the ray was fetched
+#else
+	RL_WIDE_STEP_F(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)
+#endif
 	int r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
 	if (r0 == DNODE_EMPTY) t0 = INFINITY;
 	if (r1 == DNODE_EMPTY) t1 = INFINITY;
@@ -1632,7 +1636,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 							T.d = T.anyhit ? -ld3(S.sunDirection) : v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
 							T.rayTime = PRIMS ? pool[F_TIME][slot] : 0.0f;
 							T.inv = v3(FastRcp(T.d.x), FastRcp(T.d.y), FastRcp(T.d.z));
-							if (WIDE) T.inv = ClampInv(T.inv);   // only the grid nodes' fused plane arithmetic wants finite reciprocals; Slab() relies on +-inf / NaN
+							if (WIDE && RL_Q4) T.inv = ClampInv(T.inv);   // only the grid nodes' fused plane arithmetic wants finite reciprocals; Slab() relies on +-inf / NaN
 							T.nx = T.inv.x < 0.0f; T.ny = T.inv.y < 0.0f; T.nz = T.inv.z < 0.0f;
 							T.best.t = INFINITY; T.best.tri = -1; T.best.a = 0.0f; T.best.b = 0.0f;
 							T.cur = 0; T.sp = 0; T.leafI = 0;

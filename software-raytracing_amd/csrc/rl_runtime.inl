@@ -21,7 +21,7 @@ namespace rl {
 // One physical device's copy of a scene.
 struct DeviceSceneCopy {
 	int device = 0;
-	DWide* nodes4 = nullptr;
+	DNode4Q* nodes4 = nullptr; DNode4* nodes4f = nullptr;
 	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
 	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
 	DSphere* spheres = nullptr; DCube* cubes = nullptr;
@@ -220,7 +220,7 @@ void FreeCopy(DeviceSceneCopy* C)
 {
 	if (!C) return;
 	(void)hipSetDevice(C->device);
-	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); (void)hipFree(C->isect); (void)hipFree(C->shade);
+	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4f) (void)hipFree(C->nodes4f); (void)hipFree(C->isect); (void)hipFree(C->shade);
 	(void)hipFree(C->materials); (void)hipFree(C->textures); (void)hipFree(C->texels); (void)hipFree(C->spheres); (void)hipFree(C->cubes);
 	if (C->sky) (void)hipFree(C->sky);
 	delete C;
@@ -349,17 +349,17 @@ bool UploadScene(Scene& sc)
 		D->copy.push_back(C);
 		bool ok = hipSetDevice(C->device) == hipSuccess;
 		ok = ok && Upload(C->nodes, sc.bvh.nodes.data(), sc.bvh.nodes.size());
-#if RL_Q4
-		if (ok && D->hasNodes4) ok = Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size());
-#else
-		if (ok && D->hasNodes4) ok = Upload(C->nodes4, sc.bvh.nodes4.data(), sc.bvh.nodes4.size());
-#endif
+		// the grid nodes for the pool schedule; the float-box nodes for scenes small enough to stay in the caches (k_trace's class),
+		// where the grid's extra arithmetic buys nothing (Cornell frame: 22.8 ms on float boxes, 23.8 ms on the grid)
+		const bool wantFull = D->hasNodes4 && (!RL_Q4 || sc.triangles.size() < 4096);
+		if (ok && D->hasNodes4 && RL_Q4) ok = Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size());
+		if (ok && wantFull) ok = Upload(C->nodes4f, sc.bvh.nodes4.data(), sc.bvh.nodes4.size());
 		ok = ok && Upload(C->isect, isect.data(), n) && Upload(C->shade, shade.data(), n);
 		ok = ok && Upload(C->materials, mats.data(), mats.size()) && Upload(C->textures, texs.data(), texs.size()) && Upload(C->texels, pool.data(), pool.size());
 		ok = ok && Upload(C->spheres, dsph.data(), dsph.size()) && Upload(C->cubes, dcub.data(), dcub.size());
 		if (!ok) { Log("UploadScene: device %d could not take the scene", C->device); FreeScene(D); return false; }   // nothing of a failed upload is left behind
 		DSceneView& V = C->view;
-		V.nodes = C->nodes; V.nodes4 = C->nodes4; V.isect = C->isect; V.shade = C->shade; V.materials = C->materials;
+		V.nodes = C->nodes; V.nodes4 = C->nodes4; V.nodes4f = C->nodes4f; V.isect = C->isect; V.shade = C->shade; V.materials = C->materials;
 		V.textures = C->textures; V.texels = C->texels; V.spheres = C->spheres; V.cubes = C->cubes;
 		V.sunIlluminance[0] = sc.sunIlluminance.x; V.sunIlluminance[1] = sc.sunIlluminance.y; V.sunIlluminance[2] = sc.sunIlluminance.z;
 		V.sunDirection[0] = sc.sunDirection.x; V.sunDirection[1] = sc.sunDirection.y; V.sunDirection[2] = sc.sunDirection.z;
@@ -408,7 +408,7 @@ TraceKernel SelectTraceKernel(int& poolK, const DeviceScene* D, bool& shortStack
 		const char* e = getenv("RAYLIB_POOL_SHORT_STACK");
 		// the wide tree: default whenever the scene carries one whose worst-case stack fits; RAYLIB_BVH4=0|1 overrides
 		const char* w = getenv("RAYLIB_BVH4");
-		const bool haveWide = D && D->hasNodes4 && D->stackNeed4 <= 64;
+		const bool haveWide = D && D->hasNodes4 && D->stackNeed4 <= 64;   // (the pool's node format is a build-time choice: RL_Q4)
 		const bool wantWide = haveWide && (w ? atoi(w) != 0 : true);
 		if (poolK == 2 && wantWide) {
 			wide = true; shortStack = true;
@@ -425,7 +425,7 @@ TraceKernel SelectTraceKernel(int& poolK, const DeviceScene* D, bool& shortStack
 		if (poolK == 4) return k_trace_pool<STACK, PRIMS, 4>;
 	}
 	poolK = 0;
-	return k_trace<STACK, PRIMS>;
+	return nullptr;   // k_trace: the caller picks the instantiation for the node format the scene carries
 }
 
 // What EnqueueRender leaves for FinishRender: everything is queued on the rank's stream, nothing has been waited for.
@@ -496,14 +496,21 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 		int poolK = (STACK <= 32 && !PRIMS && sc.triangles.size() >= minTris) ? 2 : 0;
 		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
 		bool shortStack = false, wide = false;
-		const TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, DS, shortStack, wide);
-		// k_trace walks the 4-wide tree too when the scene has one whose worst-case stack fits this instantiation's LDS stack
+		TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, DS, shortStack, wide);
+		// k_trace walks the 4-wide tree too when the scene has one whose worst-case stack fits this instantiation's LDS stack:
+		// on float boxes if the scene carries them (small scenes), else on the grid nodes
 		DSceneView traceView = D->view;
+#if !RL_Q4
+		traceView.nodes4 = nullptr;
+#endif
 		if (poolK == 0) {
 			const char* w = getenv("RAYLIB_BVH4");
 			const bool baseWide = !PRIMS && DS->hasNodes4 && DS->stackNeed4 <= (uint32_t)STACK && (w ? atoi(w) != 0 : true);
-			if (!baseWide) traceView.nodes4 = nullptr;
+			if (!baseWide) { traceView.nodes4 = nullptr; traceView.nodes4f = nullptr; }
 			wide = baseWide;
+			const bool full = traceView.nodes4f != nullptr;
+			if (full) traceView.nodes4 = nullptr;
+			traceKernel = full ? (TraceKernel)k_trace<STACK, PRIMS, true> : (TraceKernel)k_trace<STACK, PRIMS, false>;
 		}
 		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
 		pend.schedulePaths = pathsPerThread;
