@@ -1475,6 +1475,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 	for (int p = 0; p < K; ++p) { stRng[p] = 0; stOut[p] = 0; stDepth[p] = 0; stActive[p] = false; pool[F_TRI][p * 64 + lane] = __int_as_float(Q_EMPTY); }
 	uint32_t chunkNext = 0, chunkEnd = 0;
 	bool globalDone = false, exhausted = false;   // wave-uniform
+	uint32_t surviveQ8 = 256u;                    // share of freshly generated camera samples that reached a pool slot, x 256 (wave-uniform)
 	// traversal state of the ray this lane is tracing; survives trips (a straggler keeps going while the rest of the pool is shaded)
 	bool busy = false;
 	int mySlot = 0;
@@ -1540,8 +1541,17 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 				}
 				const uint32_t avail = chunkEnd - chunkNext;
 				if (avail == 0) { exhausted = true; break; }
-				const uint32_t take = min(min(64u, nFree - filled), avail);
-				bool alive = false;
+				// How many camera samples to generate this round.  A sample that misses the scene's root box is finished right here and
+				// fills no slot; where most do (a camera outside the model: 90 % in the configs[2] stand-in) asking for exactly as many
+				// samples as there are free slots fills a tenth of them per round.  So the round asks for more -- free slots / the share
+				// that survived lately -- and, if more survive than fit, keeps the first `room` survivors and hands the jobs behind the
+				// last one kept back to the queue (chunkNext only advances past the lanes that were committed: the same jobs come
+				// round again, same pixel, same stream).  Nothing is written or counted for a lane before it is committed.
+				const uint32_t room = nFree - filled;
+				uint32_t want = room;
+				if (surviveQ8 < 230u) want = min(64u, (room * 256u) / max(24u, surviveQ8 + (surviveQ8 >> 3)));   // a little under 1 / survival rate
+				const uint32_t take = min(min(64u, max(room, want)), avail);
+				bool alive = false, quick = false;   // quick: decided by the root test (sample written at commit)
 				V3 o = v3s(0.0f), d = v3s(0.0f);
 				float rayTime = 0.0f;
 				Rng g; g.s.state = 0;
@@ -1562,26 +1572,40 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 						CameraRay(P.camera, u, v, g, o, d, rayTime);
 						outIndex = j.sample * numSlots + j.slot;
 						alive = true;
-						c.samples++;
-						if (P.maxPathLength <= 0) {
-							samples[outIndex] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);   // renderer.cc:120-123
-							alive = false;
-						} else if (RootMiss(S, o, d, P.rayTMin)) {
+						if (P.maxPathLength <= 0) { alive = false; quick = true; }   // renderer.cc:120-123
+						else if (RootMiss(S, o, d, P.rayTMin)) {
 							// cannot hit anything: sky lookup plus (with a sun) one occlusion query that may be decided at the root too
 							const bool sunQuick = !S.hasSun || RootMiss(S, o, -ld3(S.sunDirection), P.rayTMin);
-							if (sunQuick) {
-								c.rays++; c.nodes++;
-								V3 L = MissSky(S, R, d, c);
-								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
-								samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
-								alive = false;
-							}
+							if (sunQuick) { alive = false; quick = true; }
 						}
 					}
 				}
-				chunkNext += take;
-				const unsigned long long am = __ballot(alive);
-				const uint32_t n = (uint32_t)__popcll(am);
+				unsigned long long am = __ballot(alive);
+				uint32_t n = (uint32_t)__popcll(am);
+				uint32_t commit = take;                    // lanes [0, commit) are this round's samples
+				if (n > room) {
+					// the lane of the (room + 1)-th survivor: everything from there on goes back to the queue
+					const unsigned long long over = __ballot(alive && (uint32_t)__popcll(am & laneLt) == room);
+					commit = (uint32_t)__ffsll((long long)over) - 1u;
+					if (lane >= commit) { alive = false; quick = false; }
+					am = __ballot(alive);
+					n = room;
+				}
+				{   // survival rate of the committed samples, 8-bit fixed point, smoothed over the last few rounds
+					const uint32_t rate = commit ? (n * 256u) / commit : 256u;
+					surviveQ8 = (surviveQ8 * 3u + rate + 2u) >> 2;
+				}
+				if (lane < commit && (alive || quick)) c.samples++;
+				if (quick) {
+					if (P.maxPathLength <= 0) samples[outIndex] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+					else {
+						c.rays++; c.nodes++;
+						V3 L = MissSky(S, R, d, c);
+						if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
+						samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+					}
+				}
+				chunkNext += commit;
 				if (n == 0) continue;
 				if (alive) {
 					// the r-th surviving ray goes to the (filled + r)-th free slot; the fields a traversal fills in later carry
