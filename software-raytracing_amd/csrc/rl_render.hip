@@ -1229,11 +1229,13 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #ifndef RL_POOL_MAXBLOCKS
 #define RL_POOL_MAXBLOCKS 4   /* workgroups per CU the pool kernel is compiled for (register budget 512 / (4 * blocks) per lane) */
 #endif
+// Re-tuned in round 2 on the grid nodes (tools/gpu_variants.py, tools/gpu_scenes_time.py; 40 / 40 / 52 before): 298 k scene 51.9 ->
+// 50.9 ms, colonnade 481 -> 471 ms, 2.36 M 156 -> 154 ms, 10.1 M 463 -> 460 ms.  (Cut 24: colonnade 458 but 2.36 M 159; cut 16: 459 / 163.)
 #ifndef RL_POOL_CUT_EXH
-#define RL_POOL_CUT_EXH 40   /* the same once the job queue is empty */
+#define RL_POOL_CUT_EXH 32   /* the same once the job queue is empty */
 #endif
 #ifndef RL_POOL_CUT
-#define RL_POOL_CUT 40    /* with the pool handed out: shade once no more than this many lanes still traverse */
+#define RL_POOL_CUT 32    /* with the pool handed out: shade once no more than this many lanes still traverse */
 #endif
 #ifndef RL_POOL_WNODE
 #define RL_POOL_WNODE 4   /* relative cost of a node step and a primitive step in the vote */
@@ -1244,7 +1246,7 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #define RL_POOL_WLEAF4 5
 #endif
 #ifndef RL_POOL_KEEP
-#define RL_POOL_KEEP 52   /* leave the traversal loop to fetch new rays when no more than this many lanes still traverse */
+#define RL_POOL_KEEP 58   /* leave the traversal loop to fetch new rays when no more than this many lanes still traverse */
 #endif
 
 __device__ __forceinline__ void WaveLdsSync()
