@@ -133,6 +133,7 @@ struct DSceneView {
 	int32_t skyWidth, skyHeight;
 	int32_t hasSun;
 	int32_t numTriangles;
+	int32_t numNodes4, numMaterials;   // for the LDS-resident copy of a small scene (k_trace<..., LDS>)
 };
 
 // Counters written by the kernels (one 64-bit atomic per wave and counter at exit).

@@ -183,13 +183,40 @@ __device__ __forceinline__ Mat LoadMat(const DSceneView& S, int i)
 }
 
 // ---------------------------------------------------------------------------
+// A scene small enough lives in LDS for the duration of a k_trace workgroup (<= 32 wide nodes, <= 128 triangles, <= 32 materials:
+// the Cornell class): the BVH2 root, the float-box wide nodes, both triangle record arrays and the material table, 23 KB at fixed
+// offsets (float4 units) so that every access is a ds_read_b128 with an immediate offset.  Every dependent fetch of a bounce --
+// three to six node steps, the triangle records, the shading record, the material -- then costs an LDS round trip instead of a trip
+// through the vector memory pipeline (TA / L1 / L2), which sixteen waves per CU keep busy with 64-address gathers.
+#define RL_LDS_ROOT   0
+#define RL_LDS_NODES  4
+#define RL_LDS_MAXNODES 32
+#define RL_LDS_ISECT  (RL_LDS_NODES + RL_LDS_MAXNODES * 8)
+#define RL_LDS_MAXTRIS 128
+#define RL_LDS_SHADE  (RL_LDS_ISECT + RL_LDS_MAXTRIS * 4)
+#define RL_LDS_MATS   (RL_LDS_SHADE + RL_LDS_MAXTRIS * 4)
+#define RL_LDS_MAXMATS 32
+#define RL_LDS_TOTAL  (RL_LDS_MATS + RL_LDS_MAXMATS * 5)
+
+__device__ __forceinline__ Mat MatFrom(const float4* p)
+{
+	float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+	Mat m;
+	m.type = __float_as_int(a.x); m.albedo = v3(a.y, a.z, a.w);
+	m.roughness = b.x; m.metallic = b.y; m.emissive = v3(b.z, b.w, c.x);
+	m.ior = c.y; m.transmission = v3(c.z, c.w, d.x); m.fuzz = d.y;
+	m.tex0 = __float_as_int(d.z); m.tex1 = __float_as_int(d.w);
+	m.tex2 = __float_as_int(e.x); m.tex3 = __float_as_int(e.y); m.tex4 = __float_as_int(e.z);
+	return m;
+}
+
+// ---------------------------------------------------------------------------
 // Closest hit on the flat BVH2.
 struct HitRec { float t, a, b; int tri; };   // tri: triangle slot, or (kind << 28) | index for sphere (1) / cube (2, with the face in a)
 
 struct Tri { V3 v0, n, v1, v2, u, v; float uv, uu, vv, denom; };
-__device__ __forceinline__ Tri LoadTri(const DSceneView& S, int i)
+__device__ __forceinline__ Tri TriFrom(const float4* p)
 {
-	const float4* p = (const float4*)(S.isect + i);
 	float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
 	Tri t;
 	t.v0 = v3(q0.x, q0.y, q0.z); t.n = v3(q0.w, q1.x, q1.y);
@@ -198,11 +225,11 @@ __device__ __forceinline__ Tri LoadTri(const DSceneView& S, int i)
 	t.uv = q3.x; t.uu = q3.y; t.vv = q3.z; t.denom = q3.w;
 	return t;
 }
+__device__ __forceinline__ Tri LoadTri(const DSceneView& S, int i) { return TriFrom((const float4*)(S.isect + i)); }
 
 struct Shade { V3 n0, n1, n2; float s0, t0, s1, t1, s2, t2; int material; };
-__device__ __forceinline__ Shade LoadShade(const DSceneView& S, int i)
+__device__ __forceinline__ Shade ShadeFrom(const float4* p)
 {
-	const float4* p = (const float4*)(S.shade + i);
 	float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
 	Shade s;
 	s.n0 = v3(q0.x, q0.y, q0.z); s.n1 = v3(q0.w, q1.x, q1.y); s.n2 = v3(q1.z, q1.w, q2.x);
@@ -210,6 +237,7 @@ __device__ __forceinline__ Shade LoadShade(const DSceneView& S, int i)
 	s.material = __float_as_int(q3.w);
 	return s;
 }
+__device__ __forceinline__ Shade LoadShade(const DSceneView& S, int i) { return ShadeFrom((const float4*)(S.shade + i)); }
 
 // MicrofacetMaterial::AlphaTest for a candidate (reference render/material.cc:397-404 via geom/triangle.cc:48-54).
 // Returns bit 0 = passes, bit 1 = a texel was fetched.  Out of line: only leaves flagged as textured reach it.
@@ -284,11 +312,12 @@ __device__ __forceinline__ bool Slab(float mnx, float mny, float mnz, float mxx,
 __device__ __forceinline__ float FastRcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // First traversal step only: true when the ray misses both child boxes of the root node.
-__device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float tMin)
+template <bool LDS = false>
+__device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float tMin, const float4* sm = nullptr)
 {
 	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 	const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-	const float4* np = (const float4*)(S.nodes);
+	const float4* np = LDS ? sm + RL_LDS_ROOT : (const float4*)(S.nodes);
 	const float4 q0 = np[0], q1 = np[1], q2 = np[2];
 	const int4 k = ((const int4*)np)[3];
 	float tl, tr;
@@ -476,8 +505,8 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 	tn = fmaxf(tn, __builtin_fmaf((float)((nY_ >> sh) & 0xffu), Ay_, Bny_)); tf = fminf(tf, __builtin_fmaf((float)((fY_ >> sh) & 0xffu), Ay_, Bfy_)); \
 	tn = fmaxf(tn, __builtin_fmaf((float)((nZ_ >> sh) & 0xffu), Az_, Bnz_)); tf = fminf(tf, __builtin_fmaf((float)((fZ_ >> sh) & 0xffu), Az_, Bfz_)); \
 	tk = (tf * widenL_ < tn) ? INFINITY : tn; }
-#define RL_WIDE_STEP_F(S_, cur_, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
-	const float4* np_ = (const float4*)((S_).nodes4f + (cur_)); \
+#define RL_WIDE_STEP_F(np_expr, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
+	const float4* np_ = (np_expr); \
 	const float4 lox_ = np_[0], loy_ = np_[1], loz_ = np_[2], hix_ = np_[3], hiy_ = np_[4], hiz_ = np_[5]; \
 	const int4 ch = ((const int4*)np_)[6]; \
 	const float4 nX_ = (nx_) ? hix_ : lox_, fX_ = (nx_) ? lox_ : hix_; \
@@ -495,8 +524,8 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 
 // The same closest-hit search on the BVH4 (DNode4): four slab tests per step, hit children ordered by entry distance.
 // FULL: float boxes (S.nodes4f), else the grid nodes (S.nodes4)
-template <int STACK, bool ANYHIT, bool PRIMS, bool FULL>
-__device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c)
+template <int STACK, bool ANYHIT, bool PRIMS, bool FULL, bool LDS = false>
+__device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c, const float4* sm = nullptr)
 {
 	c.rays++;
 	V3 invb = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // for the box tests (the candidate rule divides again: exact, and rare)
@@ -510,7 +539,7 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 			c.nodes += FULL ? 2 : 1;   // 64-byte records fetched
 			const float tmx = fminf(best.t, FLT_MAX);
 			float t0, t1, t2, t3; int r0, r1, r2, r3;
-			if (FULL) { RL_WIDE_STEP_F(S, cur, o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, a0, a1, a2, a3, ch) t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w; }
+			if (FULL) { RL_WIDE_STEP_F((LDS ? sm + RL_LDS_NODES + cur * 8 : (const float4*)(S.nodes4f + cur)), o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, a0, a1, a2, a3, ch) t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w; }
 			else { RL_WIDE_STEP_Q(S, cur, o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, a0, a1, a2, a3, ch) t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w; }
 			if (r0 == DNODE_EMPTY) t0 = INFINITY;
 			if (r1 == DNODE_EMPTY) t1 = INFINITY;
@@ -532,7 +561,7 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 			const int count = (int)(code & 7u) + 1;
 			const bool alpha = (code & 8u) != 0;
 			for (int i = 0; i < count; ++i) {
-				const Tri T = LoadTri(S, first + i);
+				const Tri T = LDS ? TriFrom(sm + RL_LDS_ISECT + (first + i) * 4) : LoadTri(S, first + i);
 				c.tris++;
 				const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
 				if (!(t >= tMin && t <= FLT_MAX && (t < best.t || (t == best.t && first + i < best.tri)))) continue;
@@ -562,15 +591,15 @@ struct Surf { float t; V3 p, n; float U, V; V3 tangent, bitangent; };
 
 // HitResult for the winning primitive (reference geom/triangle.cc:43-47, geom/sphere.cc:19-41, geom/cube.cc:24-38)
 // + the tangent frame (geom/hit.cc:6-18).  Returns the material index.
-template <bool PRIMS>
-__device__ __forceinline__ int BuildSurface(const DSceneView& S, V3 o, V3 d, const HitRec& h, Surf& s, bool basis, Counters& c)
+template <bool PRIMS, bool LDS = false>
+__device__ __forceinline__ int BuildSurface(const DSceneView& S, V3 o, V3 d, const HitRec& h, Surf& s, bool basis, Counters& c, const float4* sm = nullptr)
 {
 	int material;
 	s.t = h.t;
 	s.p = o + h.t * d;
 	const uint32_t kind = PRIMS ? (((uint32_t)h.tri) >> 28) : 0u;
 	if (kind == 0u) {
-		const Shade sh = LoadShade(S, h.tri);
+		const Shade sh = LDS ? ShadeFrom(sm + RL_LDS_SHADE + h.tri * 4) : LoadShade(S, h.tri);
 		c.shaded++;
 		const float a = h.a, b = h.b;
 		s.n = normalize((1 - a - b) * sh.n0 + a * sh.n1 + b * sh.n2);
@@ -939,8 +968,8 @@ __device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rn
 struct SkyRot { float m0[3], m1[3], m2[3]; };   // Rotator(yaw 90).rotate rows, computed on the host (renderer.cc:166-168)
 
 // Miss shader: sky panorama + sun (reference render/renderer.cc:155-199)
-template <int STACK, bool PRIMS, bool FULL>
-__device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTime, float rayTMin, int* stk, Counters& c)
+template <int STACK, bool PRIMS, bool FULL, bool LDS = false>
+__device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTime, float rayTMin, int* stk, Counters& c, const float4* sm = nullptr)
 {
 	V3 missResult = v3s(0.0f);
 	if (S.sky) {
@@ -957,7 +986,7 @@ __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V
 	}
 	if (S.hasSun) {
 		HitRec tmp;
-		const bool occluded = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, true, PRIMS, FULL>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c)
+		const bool occluded = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, true, PRIMS, FULL, LDS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c, sm)
 		                                           : Traverse<STACK, true, PRIMS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c);
 		if (!occluded) missResult = missResult + ld3(S.sunIlluminance);
 	}
@@ -994,12 +1023,23 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 #endif
 // PRIMS: the scene holds spheres / cubes (their leaf and shading code is compiled out of the triangle-only variant)
 // FULL: the wide tree, if the launch carries one, has float boxes (S.nodes4f) -- small scenes; else grid nodes (S.nodes4)
-template <int STACK, bool PRIMS, bool FULL>
+// LDS (with FULL, triangle scenes within the RL_LDS_MAX* limits): the scene's records are copied to LDS at the start and read from there
+template <int STACK, bool PRIMS, bool FULL, bool LDS = false>
 __global__ void __launch_bounds__(RL_BLOCK, (STACK <= 32 ? RL_TRACE_MIN_WAVES : 2))
 k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
         float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
 	__shared__ int s_stack[STACK * RL_BLOCK];
+	__shared__ float4 s_scene[LDS ? RL_LDS_TOTAL : 1];
+	const float4* sm = s_scene;
+	if (LDS) {
+		const uint32_t nN = (uint32_t)S.numNodes4 * 8u, nT = (uint32_t)S.numTriangles * 4u, nM = (uint32_t)S.numMaterials * 5u;
+		for (uint32_t i = threadIdx.x; i < 4u; i += RL_BLOCK) s_scene[RL_LDS_ROOT + i] = ((const float4*)S.nodes)[i];
+		for (uint32_t i = threadIdx.x; i < nN; i += RL_BLOCK) s_scene[RL_LDS_NODES + i] = ((const float4*)S.nodes4f)[i];
+		for (uint32_t i = threadIdx.x; i < nT; i += RL_BLOCK) { s_scene[RL_LDS_ISECT + i] = ((const float4*)S.isect)[i]; s_scene[RL_LDS_SHADE + i] = ((const float4*)S.shade)[i]; }
+		for (uint32_t i = threadIdx.x; i < nM; i += RL_BLOCK) s_scene[RL_LDS_MATS + i] = ((const float4*)S.materials)[i];
+		__syncthreads();
+	}
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t gtid = blockIdx.x * RL_BLOCK + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u;
@@ -1075,15 +1115,15 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 						outIndex = j.sample * numSlots + j.slot;
 						active = true;
 						c.samples++;
-						if (P.maxPathLength > 0 && RootMiss(S, o, d, P.rayTMin)) {
+						if (P.maxPathLength > 0 && RootMiss<LDS>(S, o, d, P.rayTMin, sm)) {
 							// The camera ray cannot hit anything.  Its miss shader (renderer.cc:155-199) is the sky lookup plus,
 							// with a sun, one occlusion query from the ray origin; if that shadow ray misses the root too, the
 							// whole sample is decided here.
-							const bool sunQuick = !S.hasSun || RootMiss(S, o, -ld3(S.sunDirection), P.rayTMin);
+							const bool sunQuick = !S.hasSun || RootMiss<LDS>(S, o, -ld3(S.sunDirection), P.rayTMin, sm);
 							if (sunQuick) {
 								c.rays++; c.nodes++;   // the closest-hit query this replaces fetches the root node and stops
 								DSceneView Sq = S; Sq.hasSun = 0;
-								V3 L = MissShader<STACK, PRIMS, FULL>(Sq, R, o, d, rayTime, P.rayTMin, stk, c);
+								V3 L = MissShader<STACK, PRIMS, FULL, LDS>(Sq, R, o, d, rayTime, P.rayTMin, stk, c, sm);
 								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
 								samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
 								active = false;
@@ -1106,7 +1146,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 		const bool doTrace = active && depth < P.maxPathLength;   // renderer.cc:120-123 otherwise
 		bool hit = false;
 		// the 4-wide tree when the launch carries it (triangle scenes; half the steps: 24.6 -> 22.4 ms on the Cornell frame)
-		if (doTrace) hit = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, false, PRIMS, FULL>(S, o, d, rayTime, P.rayTMin, h, stk, c) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
+		if (doTrace) hit = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, false, PRIMS, FULL, LDS>(S, o, d, rayTime, P.rayTMin, h, stk, c, sm) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
 		RL_STAMP(1);
 		if (active) {
 			bool done = false;
@@ -1118,7 +1158,8 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 #ifdef RL_DIAG_STAMPS
 				subLast = __builtin_amdgcn_s_memtime();
 #endif
-				const Mat m = LoadMat(S, BuildSurface<PRIMS>(S, o, d, h, s, true, c));
+				const int mi = BuildSurface<PRIMS, LDS>(S, o, d, h, s, true, c, sm);
+				const Mat m = LDS ? MatFrom(sm + RL_LDS_MATS + mi * 5) : LoadMat(S, mi);
 				RL_SUBSTAMP(0);
 				V3 refl = v3s(0.0f), outD = v3s(0.0f);
 				float pdf = 0.0f, sp = 0.0f;
@@ -1139,7 +1180,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				}
 				RL_SUBSTAMP(2);
 			} else {
-				L = MissShader<STACK, PRIMS, FULL>(S, R, o, d, rayTime, P.rayTMin, stk, c);
+				L = MissShader<STACK, PRIMS, FULL, LDS>(S, R, o, d, rayTime, P.rayTMin, stk, c, sm);
 				done = true;
 			}
 			RL_STAMP(2);
@@ -1315,7 +1356,7 @@ __device__ __forceinline__ bool NodeStep4(const DSceneView& S, Trav& T, float tM
 #if RL_Q4
 	RL_WIDE_STEP_Q(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)   // T.inv was clamped when the ray was fetched
 #else
-	RL_WIDE_STEP_F(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)
+	RL_WIDE_STEP_F((const float4*)(S.nodes4f + T.cur), T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)
 #endif
 	int r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
 	if (r0 == DNODE_EMPTY) t0 = INFINITY;

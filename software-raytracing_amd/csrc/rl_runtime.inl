@@ -366,6 +366,7 @@ bool UploadScene(Scene& sc)
 		V.sky = nullptr; V.skyWidth = V.skyHeight = 0;
 		V.hasSun = !(sc.sunIlluminance.x == 0.0f && sc.sunIlluminance.y == 0.0f && sc.sunIlluminance.z == 0.0f);   // renderer.cc:192
 		V.numTriangles = (int32_t)n;
+		V.numNodes4 = (int32_t)sc.bvh.nodes4.size(); V.numMaterials = (int32_t)mats.size();
 	}
 	HIP_OK(hipSetDevice(g_rt.devices[0]));
 	sc.device = D;
@@ -510,7 +511,14 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 			wide = baseWide;
 			const bool full = traceView.nodes4f != nullptr;
 			if (full) traceView.nodes4 = nullptr;
-			traceKernel = full ? (TraceKernel)k_trace<STACK, PRIMS, true> : (TraceKernel)k_trace<STACK, PRIMS, false>;
+			// the whole scene in LDS when it fits the fixed layout (rl_render.hip RL_LDS_*); RAYLIB_LDS_SCENE=0 keeps it in global memory
+			bool lds = false;
+			if constexpr (STACK == 16 && !PRIMS) {
+				const char* e = getenv("RAYLIB_LDS_SCENE");
+				lds = full && (e ? atoi(e) != 0 : true) && sc.bvh.nodes4.size() <= RL_LDS_MAXNODES && sc.triangles.size() <= RL_LDS_MAXTRIS && sc.materials.size() <= RL_LDS_MAXMATS;
+				if (lds) traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, true>;
+			}
+			if (!lds) traceKernel = full ? (TraceKernel)k_trace<STACK, PRIMS, true> : (TraceKernel)k_trace<STACK, PRIMS, false>;
 		}
 		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
 		pend.schedulePaths = pathsPerThread;
