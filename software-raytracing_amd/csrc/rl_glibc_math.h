@@ -63,11 +63,33 @@ RLM_FN float fabsf_(float x) { return __builtin_fabsf(x); }
 	-0x1.a6f9db6475fcep-5, 0x0p+0, 0x1.338ca9f24f53dp-4, 0x1.476a9543891bap-3, \
 	0x1.e840b4ac4e4d2p-3, 0x1.40645f0c6651cp-2, 0x1.88e9c2c1b9ff8p-2, 0x1.ce0a44eb17bccp-2 }
 
+// Where the per-lane table look-ups go.  Host, and device builds without RLM_LDS_TABLES: constant arrays local to each function
+// (constant memory on the device: a 64-address gather through the vector memory pipeline per call).  Device builds that define
+// RLM_LDS_TABLES before including this header provide `__shared__ double rlm_lds_tab[80]` (INVC, logf LOGC, powf LOGC, exp2f T as
+// bit patterns) filled by rlm_fill_lds_tables() at the start of every kernel that reaches these functions: an LDS read instead.
+#if defined(RLM_LDS_TABLES) && defined(__HIP_DEVICE_COMPILE__)
+#define RLM_DECL_LOGF_TABLES
+#define RLM_DECL_POWF_TABLES
+#define RLM_DECL_EXP2F_TABLE
+#define RLM_INVC(i) rlm_lds_tab[(i)]
+#define RLM_LOGF_LOGC_AT(i) rlm_lds_tab[16 + (i)]
+#define RLM_POWF_LOGC_AT(i) rlm_lds_tab[32 + (i)]
+#define RLM_EXP2F_AT(i) asuint64(rlm_lds_tab[48 + (i)])
+#else
+#define RLM_DECL_LOGF_TABLES const double INVC[16] = RLM_LOG_INVC, LOGC[16] = RLM_LOGF_LOGC;
+#define RLM_DECL_POWF_TABLES const double INVC[16] = RLM_LOG_INVC, LOGC[16] = RLM_POWF_LOGC;
+#define RLM_DECL_EXP2F_TABLE const uint64_t T[32] = RLM_EXP2F_TAB;
+#define RLM_INVC(i) INVC[(i)]
+#define RLM_LOGF_LOGC_AT(i) LOGC[(i)]
+#define RLM_POWF_LOGC_AT(i) LOGC[(i)]
+#define RLM_EXP2F_AT(i) T[(i)]
+#endif
+
 // ---------------------------------------------------------------------------------------
 // expf  (glibc sysdeps/ieee754/flt-32/e_expf.c, non-TOINT path, FMA-contracted)
 RLM_FN float expf_(float x)
 {
-	const uint64_t T[32] = RLM_EXP2F_TAB;
+	RLM_DECL_EXP2F_TABLE
 	const double SHIFT = 0x1.8p+52, InvLn2N = 0x1.71547652b82fep+5;
 	const double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
 	double xd = (double)x;
@@ -84,7 +106,7 @@ RLM_FN float expf_(float x)
 	kd -= SHIFT;
 	double r = fma_(InvLn2N, xd, -kd);
 	double z;
-	uint64_t t = T[ki % 32];
+	uint64_t t = RLM_EXP2F_AT(ki % 32);
 	t += ki << (52 - 5);
 	double s = asdouble(t);
 	z = fma_(C0, r, C1);
@@ -98,7 +120,7 @@ RLM_FN float expf_(float x)
 // logf  (glibc sysdeps/ieee754/flt-32/e_logf.c, FMA-contracted)
 RLM_FN float logf_(float x)
 {
-	const double INVC[16] = RLM_LOG_INVC, LOGC[16] = RLM_LOGF_LOGC;
+	RLM_DECL_LOGF_TABLES
 	const double Ln2 = 0x1.62e42fefa39efp-1;
 	const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
 	uint32_t ix = asuint(x);
@@ -114,7 +136,7 @@ RLM_FN float logf_(float x)
 	int i = (tmp >> (23 - 4)) % 16;
 	int k = (int32_t)tmp >> 23;
 	uint32_t iz = ix - (tmp & (0x1ffu << 23));
-	double invc = INVC[i], logc = LOGC[i];
+	double invc = RLM_INVC(i), logc = RLM_LOGF_LOGC_AT(i);
 	double z = (double)asfloat(iz);
 	double r = fma_(z, invc, -1.0);
 	double y0 = fma_((double)k, Ln2, logc);
@@ -139,8 +161,8 @@ RLM_FN int powf_zeroinfnan(uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000u 
 
 RLM_FN float powf_(float x, float y)
 {
-	const double INVC[16] = RLM_LOG_INVC, LOGC[16] = RLM_POWF_LOGC;
-	const uint64_t T[32] = RLM_EXP2F_TAB;
+	RLM_DECL_POWF_TABLES
+	RLM_DECL_EXP2F_TABLE
 	const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
 	             A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp+0;
 	const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
@@ -179,7 +201,7 @@ RLM_FN float powf_(float x, float y)
 	uint32_t top = tmp & 0xff800000u;
 	uint32_t iz = ix - top;
 	int k = (int32_t)top >> 23;
-	double invc = INVC[i], logc = LOGC[i];
+	double invc = RLM_INVC(i), logc = RLM_POWF_LOGC_AT(i);
 	double z = (double)asfloat(iz);
 	double r = fma_(z, invc, -1.0);
 	double y0 = logc + (double)k;
@@ -201,7 +223,7 @@ RLM_FN float powf_(float x, float y)
 	uint64_t ki = asuint64(kd);
 	kd -= SHIFT;
 	r = ylogx - kd;
-	uint64_t t = T[ki % 32];
+	uint64_t t = RLM_EXP2F_AT(ki % 32);
 	uint64_t ski = ki + sign_bias;
 	t += ski << (52 - 5);
 	double s = asdouble(t);
@@ -575,5 +597,20 @@ RLM_FN float tanf_(float x)
 	float y1 = (float)(dx - (double)y0);
 	return kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
 }
+
+#if defined(RLM_LDS_TABLES) && defined(__HIPCC__)
+// First statement of every kernel that reaches expf_ / logf_ / powf_ (all threads of the block must call it: it ends in a barrier).
+__device__ __forceinline__ void rlm_fill_lds_tables()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const double INVC[16] = RLM_LOG_INVC, LOGF[16] = RLM_LOGF_LOGC, POWF[16] = RLM_POWF_LOGC;
+	const uint64_t T[32] = RLM_EXP2F_TAB;
+	const unsigned i = threadIdx.x;
+	if (i < 16u) { rlm_lds_tab[i] = INVC[i]; rlm_lds_tab[16u + i] = LOGF[i]; rlm_lds_tab[32u + i] = POWF[i]; }
+	if (i < 32u) rlm_lds_tab[48u + i] = asdouble(T[i]);
+	__syncthreads();
+#endif
+}
+#endif
 
 } // namespace rlm

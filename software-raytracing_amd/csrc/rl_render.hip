@@ -26,6 +26,16 @@
 #include <hip/hip_runtime.h>
 
 #include "rl_host.h"
+// the exact-libm tables (rl_glibc_math.h) in LDS: 640 B per workgroup, filled by rlm_fill_lds_tables() at the top of every kernel that
+// evaluates expf / logf / powf.  A microfacet scattering event makes ~16 such look-ups; from constant memory each one is a gather through
+// the vector memory pipeline with a full s_waitcnt behind it.
+#ifndef RL_MATH_TABLES_GLOBAL
+#define RLM_LDS_TABLES 1
+__shared__ double rlm_lds_tab[80];
+#define RL_MATH_PROLOGUE() rlm::rlm_fill_lds_tables()
+#else
+#define RL_MATH_PROLOGUE()
+#endif
 #include "rl_math.h"
 #include "raylib_amd_rng.h"
 
@@ -1029,6 +1039,7 @@ __global__ void __launch_bounds__(RL_BLOCK, (STACK <= 32 ? RL_TRACE_MIN_WAVES : 
 k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
         float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
+	RL_MATH_PROLOGUE();
 	__shared__ int s_stack[STACK * RL_BLOCK];
 	__shared__ float4 s_scene[LDS ? RL_LDS_TOTAL : 1];
 	const float4* sm = s_scene;
@@ -1265,7 +1276,7 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #define Q_MISS     (-7)   /* result of a closest-hit query that hit nothing (distinct from Q_CLOSEST: a straggler may deliver it while the next phase is handing out slots) */
 #define Q_CLEAR    (-8)   /* result of a sun query: nothing in the way */
 #define RL_POOL_WIDEN RL_BOX_WIDEN
-#define RL_POOL_SHORT_LSTACK 19   /* LDS entries of the "short" 32-deep stack: 19 KiB + 20.5 KiB pool = 4 workgroups per CU */
+#define RL_POOL_SHORT_LSTACK 18   /* LDS entries of the "short" 32-deep stack: 18 KiB + 20.5 KiB pool + 640 B of libm tables = 4 workgroups per CU */
 #define RL_POOL_SHORT_MAXDEPTH 24 /* BVH depth up to which the short variant is used (deeper trees overflow too often: measured) */
 #ifndef RL_POOL_MAXBLOCKS
 #define RL_POOL_MAXBLOCKS 4   /* workgroups per CU the pool kernel is compiled for (register budget 512 / (4 * blocks) per lane) */
@@ -1492,6 +1503,7 @@ __global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<LSTACK, PRIMS, K>::kBlocks)
 k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
              float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
+	RL_MATH_PROLOGUE();
 	constexpr int PP = 64 * K;
 	static_assert(LSTACK <= STACK, "the LDS part cannot exceed the stack");
 	__shared__ int s_stack[LSTACK * RL_BLOCK];
@@ -1919,6 +1931,7 @@ template <int STACK, bool PRIMS>
 __global__ void __launch_bounds__(RL_BLOCK)
 k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
+	RL_MATH_PROLOGUE();
 	__shared__ int s_stack[STACK * RL_BLOCK];
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t numSlots = P.numLocalCells * 64u;
@@ -1991,6 +2004,7 @@ template <int STACK, bool PRIMS>
 __global__ void __launch_bounds__(RL_BLOCK)
 k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float tMin, DHitOut* __restrict__ out)
 {
+	RL_MATH_PROLOGUE();
 	__shared__ int s_stack[STACK * RL_BLOCK];
 	int* stk = s_stack + threadIdx.x;
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
@@ -2030,6 +2044,7 @@ k_pp_max(const float4* __restrict__ px, size_t n, unsigned int* __restrict__ whi
 __global__ void __launch_bounds__(RL_BLOCK)
 k_pp_map(float4* __restrict__ px, size_t n, const unsigned int* __restrict__ whiteBits)
 {
+	RL_MATH_PROLOGUE();
 	const size_t i = (size_t)blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;
 	const float maxWhiteLuminance = __uint_as_float(*whiteBits);
@@ -2055,6 +2070,7 @@ k_pp_map(float4* __restrict__ px, size_t n, const unsigned int* __restrict__ whi
 __global__ void __launch_bounds__(RL_BLOCK)
 k_eval_scatter(const DSceneView S, int material, const float* __restrict__ in, int n, unsigned long long seed, float* __restrict__ out)
 {
+	RL_MATH_PROLOGUE();
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;
 	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);
@@ -2089,6 +2105,7 @@ k_eval_scatter(const DSceneView S, int material, const float* __restrict__ in, i
 __global__ void __launch_bounds__(RL_BLOCK)
 k_eval_camera(const DCamera cam, const float* __restrict__ uv, int n, unsigned long long seed, float* __restrict__ out)
 {
+	RL_MATH_PROLOGUE();
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;
 	Rng g; g.s = raylib_rng_begin(seed, (uint32_t)i, 0);
@@ -2101,6 +2118,7 @@ k_eval_camera(const DCamera cam, const float* __restrict__ uv, int n, unsigned l
 __global__ void __launch_bounds__(RL_BLOCK)
 k_eval_texture(const DSceneView S, int tex, int srgb, const float* __restrict__ uv, int n, float* __restrict__ out)
 {
+	RL_MATH_PROLOGUE();
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;
 	const float4 p = TexFetch(S.textures, S.texels, tex, srgb != 0, uv[2 * i], uv[2 * i + 1]);
@@ -2111,6 +2129,7 @@ k_eval_texture(const DSceneView S, int tex, int srgb, const float* __restrict__ 
 __global__ void __launch_bounds__(RL_BLOCK)
 k_eval_math(int fn, const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ out)
 {
+	RL_MATH_PROLOGUE();
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;
 	const float a = x[i], b = y ? y[i] : 0.0f;
