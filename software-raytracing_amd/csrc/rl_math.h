@@ -39,6 +39,10 @@ __device__ __forceinline__ void sincos_signs_(float x, bool* sn, bool* cn) { *sn
 #else
 // Real calls, not inlined: the megakernel evaluates ~40 transcendentals per bounce at ~20 call sites;
 // inlined, k_trace was 72 KB of code against a 64 KB instruction cache shared by two CUs.
+// Except expf and logf (round 2): they are the short ones (~80 instructions with their table in LDS) and the frequent ones (14 of the
+// ~20 transcendentals of a microfacet scattering event), and a call is not free -- the callee starts with s_waitcnt vmcnt(0) lgkmcnt(0)
+// because it cannot know what the caller has in flight, plus the jump, the return and the argument moves.  Measured on the Cornell
+// frame: exp + log inline 21.02 -> 20.05 ms; + acos 20.06; + pow 20.7; everything inline 20.8 (RL_MATH_OUTLINE_EXPLOG=1 restores the calls).
 #ifndef RL_MATH_INLINE
 #define RL_MATH_CALL __device__ __noinline__
 #else
@@ -47,13 +51,26 @@ __device__ __forceinline__ void sincos_signs_(float x, bool* sn, bool* cn) { *sn
 RL_MATH_CALL float sin_(float x)  { return rlm::sinf_(x); }
 RL_MATH_CALL float cos_(float x)  { return rlm::cosf_(x); }
 RL_MATH_CALL float tan_(float x)  { return rlm::tanf_(x); }
+#ifdef RL_MATH_INLINE_ACOS
+__device__ __forceinline__ float acos_(float x) { return rlm::acosf_(x); }
+#else
 RL_MATH_CALL float acos_(float x) { return rlm::acosf_(x); }
+#endif
 RL_MATH_CALL float asin_(float x) { return rlm::asinf_(x); }
 RL_MATH_CALL float atan2_(float y, float x) { return rlm::atan2f_(y, x); }
 RL_MATH_CALL float atan_(float x) { return rlm::atanf_(x); }
+#ifndef RL_MATH_OUTLINE_EXPLOG
+__device__ __forceinline__ float exp_(float x)  { return rlm::expf_(x); }
+__device__ __forceinline__ float log_(float x)  { return rlm::logf_(x); }
+#else
 RL_MATH_CALL float exp_(float x)  { return rlm::expf_(x); }
 RL_MATH_CALL float log_(float x)  { return rlm::logf_(x); }
+#endif
+#ifdef RL_MATH_INLINE_POW
+__device__ __forceinline__ float pow_(float x, float y) { return rlm::powf_(x, y); }
+#else
 RL_MATH_CALL float pow_(float x, float y) { return rlm::powf_(x, y); }
+#endif
 // sinf(x) and cosf(x) of one argument share their range reduction (each result is the separate call's)
 RL_MATH_CALL float2 sincos2_(float x) { float s, c; rlm::sincosf_both(x, &s, &c); return make_float2(s, c); }
 __device__ __forceinline__ void sincos_(float x, float* s, float* c) { const float2 r = sincos2_(x); *s = r.x; *c = r.y; }
