@@ -31,6 +31,15 @@ RLM_FN float asfloat(uint32_t i) { union { uint32_t i; float f; } u; u.i = i; re
 RLM_FN uint64_t asuint64(double f) { union { double f; uint64_t i; } u; u.f = f; return u.i; }
 RLM_FN double asdouble(uint64_t i) { union { uint64_t i; double f; } u; u.i = i; return u.f; }
 RLM_FN double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// A double constant that has to sit in a VGPR pair (gfx9 VALU instructions take one scalar operand; an fma with two constant operands
+// needs the other in vector registers): materialised where it is used.  Left to itself the compiler hoists the two v_mov out of the
+// megakernel's bounce loop, finds no registers for a pair that lives that long, and spills it to scratch -- one scratch reload, a trip
+// through the vector memory pipeline, per inlined call.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RLM_LOCAL_CONST(name, value) double name = (value); asm volatile("" : "+v"(name))
+#else
+#define RLM_LOCAL_CONST(name, value) const double name = (value)
+#endif
 RLM_FN float sqrtf_(float x) { return __builtin_sqrtf(x); }
 RLM_FN float fabsf_(float x) { return __builtin_fabsf(x); }
 
@@ -91,7 +100,8 @@ RLM_FN float expf_(float x)
 {
 	RLM_DECL_EXP2F_TABLE
 	const double SHIFT = 0x1.8p+52, InvLn2N = 0x1.71547652b82fep+5;
-	const double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
+	const double C0 = 0x1.c6af84b912394p-20, C2 = 0x1.62e42ff0c52d6p-6;
+	RLM_LOCAL_CONST(C1, 0x1.ebfce50fac4f3p-13);
 	double xd = (double)x;
 	uint32_t abstop = (asuint(x) >> 20) & 0x7ff;
 	if (abstop >= ((asuint(88.0f) >> 20) & 0x7ff)) {
@@ -122,7 +132,8 @@ RLM_FN float logf_(float x)
 {
 	RLM_DECL_LOGF_TABLES
 	const double Ln2 = 0x1.62e42fefa39efp-1;
-	const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+	const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2;
+	RLM_LOCAL_CONST(A2, -0x1.ffffef20a4123p-2);
 	uint32_t ix = asuint(x);
 	if (ix == 0x3f800000u) return 0.0f;
 	if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {

@@ -655,7 +655,13 @@ __device__ __forceinline__ V3 WorldToLocal(const Surf& s, V3 v) { return v3(dot(
 // ---- microfacet BRDF pieces (reference render/brdf.h, render/material.cc:16-190) ----
 __device__ __forceinline__ float Clampf(float val, float lo, float hi) { return fmaxf(lo, fminf(hi, val)); }
 
-__device__ __noinline__ float ErfInv(float x)
+#ifndef RL_ERFINV_ATTR
+#define RL_ERFINV_ATTR __noinline__
+#endif
+#ifndef RL_ERF_ATTR
+#define RL_ERF_ATTR __noinline__
+#endif
+__device__ RL_ERFINV_ATTR float ErfInv(float x)
 {
 	float w, p;
 	x = Clampf(x, -.99999f, .99999f);
@@ -685,7 +691,7 @@ __device__ __noinline__ float ErfInv(float x)
 	}
 	return p * x;
 }
-__device__ __noinline__ float Erf(float x)
+__device__ RL_ERF_ATTR float Erf(float x)
 {
 	const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f;
 	const float p = 0.3275911f;
