@@ -65,7 +65,16 @@ RAYLIB_RNG_FN RaylibRngStream raylib_rng_begin(uint64_t seed, uint32_t pixelInde
 RAYLIB_RNG_FN uint32_t raylib_rng_next_u32(RaylibRngStream* s)
 {
 	uint64_t old = s->state;
+#if defined(__HIP_DEVICE_COMPILE__)
+	/* same arithmetic; the 64-bit increment is handed to the compiler as two 32-bit immediates it cannot merge, so that it is
+	 * rebuilt where it is used (two moves) instead of being kept in a register pair across the megakernel's loops -- where the
+	 * pool schedule had no registers left for it and reloaded it from scratch memory at every draw */
+	uint32_t inc_lo = 0xF767814Fu, inc_hi = 0x14057B7Eu;
+	asm volatile("" : "+v"(inc_lo), "+v"(inc_hi));
+	s->state = old * 6364136223846793005ull + (((uint64_t)inc_hi << 32) | inc_lo);
+#else
 	s->state = old * 6364136223846793005ull + 1442695040888963407ull;
+#endif
 	uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
 	uint32_t rot = (uint32_t)(old >> 59u);
 	return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));

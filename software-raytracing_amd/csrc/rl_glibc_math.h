@@ -36,7 +36,10 @@ RLM_FN double fma_(double a, double b, double c) { return __builtin_fma(a, b, c)
 // megakernel's bounce loop, finds no registers for a pair that lives that long, and spills it to scratch -- one scratch reload, a trip
 // through the vector memory pipeline, per inlined call.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define RLM_LOCAL_CONST(name, value) double name = (value); asm volatile("" : "+v"(name))
+#define RLM_LOCAL_CONST(name, value) \
+	uint32_t name##_lo = (uint32_t)__builtin_bit_cast(uint64_t, (double)(value)), name##_hi = (uint32_t)(__builtin_bit_cast(uint64_t, (double)(value)) >> 32); \
+	asm volatile("" : "+v"(name##_lo), "+v"(name##_hi)); /* two 32-bit immediates: trivially rematerialisable, never spilled */ \
+	const double name = __builtin_bit_cast(double, ((uint64_t)name##_hi << 32) | name##_lo)
 #else
 #define RLM_LOCAL_CONST(name, value) const double name = (value)
 #endif
