@@ -1166,7 +1166,8 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 		if (doTrace) hit = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, false, PRIMS, FULL, LDS>(S, o, d, rayTime, P.rayTMin, h, stk, c, sm) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
 		RL_STAMP(1);
 		if (active) {
-			bool done = false;
+			bool done = false, store = false;
+			float4 rec0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rec1 = rec0;
 			V3 L = v3s(0.0f);
 			if (!doTrace) {
 				done = true;
@@ -1184,13 +1185,23 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				RL_SUBSTAMP(1);
 				const V3 E = Emitted(S, m, s, c);
 				if (scattered && pdf > 0.0f) {
-					// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
-					float4* st = (float4*)pathStack + ((size_t)depth * P.stackStride + gtid) * 2u;
-					st[0] = make_float4(refl.x, refl.y, refl.z, sp);
-					st[1] = make_float4(pdf, E.x, E.y, E.z);
-					o = s.p; d = outD;
-					depth++;
-					if (depth >= P.maxPathLength) done = true;   // the next TraceScene returns 0 at once (renderer.cc:120-123); L stays 0
+					if (depth + 1 >= P.maxPathLength) {
+						// the next TraceScene returns 0 at once (renderer.cc:120-123): this vertex is the path's last, and its step of the
+						// fold -- radiance = (0 + refl * 0 * sp / pdf) + E, the reference's expression -- is taken from the registers
+						V3 radiance = v3s(0.0f);
+						radiance = radiance + refl * L * sp / pdf;
+						radiance = radiance + E;
+						L = radiance;
+						done = true;
+					} else {
+						// the vertex record (refl, sp | pdf, E) goes to the path stack BEHIND this trip's fold (below): a wave counts loads and
+						// stores in one in-order counter, and a fold that waits for its loads behind this trip's stores waits for their write
+						// acknowledgements too
+						store = true;
+						rec0 = make_float4(refl.x, refl.y, refl.z, sp);
+						rec1 = make_float4(pdf, E.x, E.y, E.z);
+						o = s.p; d = outD;
+					}
 				} else {
 					L = v3s(0.0f) + E;                        // radiance(0) += Emitted, renderer.cc:137,151
 					done = true;
@@ -1240,6 +1251,12 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				}
 				samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
 				active = false;
+			}
+			if (store) {
+				// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
+				float4* st = (float4*)pathStack + ((size_t)depth * P.stackStride + gtid) * 2u;
+				st[0] = rec0; st[1] = rec1;
+				depth++;
 			}
 		}
 		RL_STAMP(3);
