@@ -200,12 +200,18 @@ __device__ __forceinline__ Mat LoadMat(const DSceneView& S, int i)
 // through the vector memory pipeline (TA / L1 / L2), which sixteen waves per CU keep busy with 64-address gathers.
 #define RL_LDS_ROOT   0
 #define RL_LDS_NODES  4
+#ifndef RL_LDS_MAXNODES
 #define RL_LDS_MAXNODES 32
+#endif
 #define RL_LDS_ISECT  (RL_LDS_NODES + RL_LDS_MAXNODES * 8)
+#ifndef RL_LDS_MAXTRIS
 #define RL_LDS_MAXTRIS 128
+#endif
 #define RL_LDS_SHADE  (RL_LDS_ISECT + RL_LDS_MAXTRIS * 4)
 #define RL_LDS_MATS   (RL_LDS_SHADE + RL_LDS_MAXTRIS * 4)
+#ifndef RL_LDS_MAXMATS
 #define RL_LDS_MAXMATS 32
+#endif
 #define RL_LDS_TOTAL  (RL_LDS_MATS + RL_LDS_MAXMATS * 5)
 
 __device__ __forceinline__ Mat MatFrom(const float4* p)
