@@ -135,6 +135,9 @@ RAYLIB_API int32_t RaylibAMD_SceneBVHInfo(SceneHandle scene, uint32_t* outNodes,
 /* The 4-wide collapse of the tree that the pool schedule traverses on large scenes: 0 = the scene has none (fewer than 8 triangles, or
  * analytic primitives), 1 = present and structurally valid (every triangle once, boxes nested, stack bound holds), -1 = invalid. */
 RAYLIB_API int32_t RaylibAMD_SceneBVH4Info(SceneHandle scene, uint32_t* outNodes4, uint32_t* outWorstCaseStack);
+/* The leaf list of a small scene (at most 24 leaves, 108 triangles): what k_trace walks instead of the tree when the scene is LDS-resident.
+ * Returns the number of leaves (0 = the scene has none); the list's validity is part of RaylibAMD_SceneBVH4Info's check. */
+RAYLIB_API int32_t RaylibAMD_SceneLeafListInfo(SceneHandle scene, uint32_t* outMaxTrianglesPerLeaf);
 /* FNV-1a of the flat BVH (node records + leaf order): the multi-threaded build (RAYLIB_BUILD_THREADS, default = host
  * threads, <= 32) must give the tree of the single-threaded one. */
 RAYLIB_API uint64_t RaylibAMD_SceneBVHHash(SceneHandle scene);

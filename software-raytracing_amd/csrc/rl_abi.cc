@@ -488,6 +488,15 @@ int32_t RaylibAMD_SceneBVH4Info(SceneHandle sh, uint32_t* nodes4, uint32_t* stac
 	if (stackNeed) *stackNeed = s->bvh.stackNeed4;
 	return ValidateBVH4(s->bvh, s->triangles) ? 1 : -1;
 }
+int32_t RaylibAMD_SceneLeafListInfo(SceneHandle sh, uint32_t* maxPerLeaf)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized) return 0;
+	int32_t leaves = 0; uint32_t most = 0;
+	for (const DNode4& n : s->bvh.leafList) for (int k = 0; k < 4; ++k) if (n.child[k] != DNODE_EMPTY) { ++leaves; most = std::max(most, (((uint32_t)~n.child[k]) & 7u) + 1u); }
+	if (maxPerLeaf) *maxPerLeaf = most;
+	return leaves;
+}
 uint64_t RaylibAMD_SceneBVHHash(SceneHandle sh)
 {
 	Scene* s = (Scene*)sh;
@@ -498,6 +507,7 @@ uint64_t RaylibAMD_SceneBVHHash(SceneHandle sh)
 	feed(s->bvh.triOrder.data(), s->bvh.triOrder.size() * sizeof(uint32_t));
 	feed(s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(DNode4));
 	feed(s->bvh.nodes4q.data(), s->bvh.nodes4q.size() * sizeof(DNode4Q));
+	feed(s->bvh.leafList.data(), s->bvh.leafList.size() * sizeof(DNode4));
 	return h;
 }
 void RaylibAMD_CameraExport(CameraHandle h, float out[19])

@@ -116,6 +116,11 @@ struct DCamera {
 	float v[3];          float pad2;
 };
 
+// Scenes of at most 4 * RL_LEAFLIST_RECORDS leaves carry a leaf list (rl_bvh.cc; k_trace<..., LDS = 2> walks it instead of the tree).
+#ifndef RL_LEAFLIST_RECORDS
+#define RL_LEAFLIST_RECORDS 6
+#endif
+
 struct DSceneView {
 	const DNode* nodes;
 	const DNode4Q* nodes4;     // the wide tree on the 8-bit grid: what the pool schedule walks (nullptr: the scene has none)
@@ -134,6 +139,8 @@ struct DSceneView {
 	int32_t hasSun;
 	int32_t numTriangles;
 	int32_t numNodes4, numMaterials;   // for the LDS-resident copy of a small scene (k_trace<..., LDS>)
+	const DNode4* leafList;    // scenes of few leaves: the leaves' boxes, four to a record (k_trace<..., LDS = 2>); nullptr = none
+	int32_t numLeafRecords, padLeaf;
 };
 
 // Counters written by the kernels (one 64-bit atomic per wave and counter at exit).

@@ -117,7 +117,11 @@ struct Counters {
 #ifdef RL_DIAG_STAMPS
 #define RL_CSTAMP_BEGIN(c) { __builtin_amdgcn_sched_barrier(0); (c).tLast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #define RL_CSTAMP(c, k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (c).tAcc[k] += now_ - (c).tLast; (c).tLast = now_; __builtin_amdgcn_sched_barrier(0); }
+#if RL_DIAG_STAMPS >= 2   /* wave-step against lane-step counts: global atomics in the inner loops, they distort the clock shares */
 #define RL_WLSTEP(c, kw, kl) { const unsigned long long em_ = __ballot(1); if ((c).diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) { atomicAdd(&(c).diag[CNT_COUNT + kw], 1ull); atomicAdd(&(c).diag[CNT_COUNT + kl], (unsigned long long)__popcll(em_)); } }
+#else
+#define RL_WLSTEP(c, kw, kl)
+#endif
 #else
 #define RL_WLSTEP(c, kw, kl)
 #define RL_CSTAMP_BEGIN(c)
@@ -203,12 +207,16 @@ __device__ __forceinline__ Mat LoadMat(const DSceneView& S, int i)
 #ifndef RL_LDS_MAXNODES
 #define RL_LDS_MAXNODES 32
 #endif
-#define RL_LDS_ISECT  (RL_LDS_NODES + RL_LDS_MAXNODES * 8)
+#ifndef RL_LDS_NSTRIDE
+#define RL_LDS_NSTRIDE 8   /* float4 per node record (8 = packed) */
+#define RL_LDS_TSTRIDE 4   /* float4 per triangle record, both arrays */
+#endif
+#define RL_LDS_ISECT  (RL_LDS_NODES + RL_LDS_MAXNODES * RL_LDS_NSTRIDE)
 #ifndef RL_LDS_MAXTRIS
 #define RL_LDS_MAXTRIS 128
 #endif
-#define RL_LDS_SHADE  (RL_LDS_ISECT + RL_LDS_MAXTRIS * 4)
-#define RL_LDS_MATS   (RL_LDS_SHADE + RL_LDS_MAXTRIS * 4)
+#define RL_LDS_SHADE  (RL_LDS_ISECT + RL_LDS_MAXTRIS * RL_LDS_TSTRIDE)
+#define RL_LDS_MATS   (RL_LDS_SHADE + RL_LDS_MAXTRIS * RL_LDS_TSTRIDE)
 #ifndef RL_LDS_MAXMATS
 #define RL_LDS_MAXMATS 32
 #endif
@@ -328,7 +336,7 @@ __device__ __forceinline__ bool Slab(float mnx, float mny, float mnz, float mxx,
 __device__ __forceinline__ float FastRcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // First traversal step only: true when the ray misses both child boxes of the root node.
-template <bool LDS = false>
+template <int LDS = 0>
 __device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float tMin, const float4* sm = nullptr)
 {
 	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -396,7 +404,7 @@ __device__ __noinline__ float2 CubeHit(const DCube* cubes, int index, V3 o, V3 d
 }
 
 // diagnostic build only: count wave-level steps (first active lane adds 1) next to the lane-level counters
-#ifdef RL_DIAG_STAMPS
+#if defined(RL_DIAG_STAMPS) && RL_DIAG_STAMPS >= 2
 #define RL_WSTEP(k) { const unsigned long long em_ = __ballot(1); if (c.diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) atomicAdd(&c.diag[CNT_COUNT + k], 1ull); }
 #else
 #define RL_WSTEP(k)
@@ -538,11 +546,97 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 	tn = fmaxf(tn, (nZ_.k - oL_.z) * invL_.z); tf = fminf(tf, (fZ_.k - oL_.z) * invL_.z); \
 	tk = (tf * widenL_ < tn) ? INFINITY : tn; }
 
+// A scene of at most 16 leaves (rl_bvh.cc "the leaf list"), resident in LDS: no tree.  Every lane tests the box of every leaf, four to a
+// record, in lockstep -- the same code on the same records for all 64 rays, so the wave pays for 1 walk, not for the union of 64 -- and
+// keeps what it hit as 16 sortable keys (entry distance with the slot number in the 4 low mantissa bits, i.e. rounded DOWN by at most 15
+// ulp: nearer than the truth, so the cut below only comes later; a negative entry distance, possible with a negative rayTMin, counts as 0).  Then it visits its leaves nearest first and stops at the first one that
+// starts behind the best hit -- the order and the cut of a tree walk; the candidates are the same (every leaf whose box the ray meets:
+// a superset of those a tree walk opens), and with the candidate rule and the tie rule of the triangle test the result does not depend on
+// the order.  Measured on the Cornell frame: see DESIGN.md section 2.
+template <bool ANYHIT>
+__device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d, float tMin, HitRec& best, Counters& c, const float4* sm)
+{
+	c.rays++;
+	const V3 invb = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const bool nx = invb.x < 0.0f, ny = invb.y < 0.0f, nz = invb.z < 0.0f;
+	best.t = INFINITY; best.tri = -1; best.a = 0.0f; best.b = 0.0f;
+	uint32_t key[4 * RL_LEAFLIST_RECORDS];
+	// The box test of the list is a filter, not the reference's test (that one is the candidate rule of the triangle test, on the
+	// triangle's own box): it only has to let through every leaf the exact test would.  So the planes are one fma each,
+	// t = plane * inv + c with c = -(o * inv), instead of (plane - o) * inv; c's rounding error, |c| * 2^-24, which the exact form does not
+	// have when plane ~ o, is covered four times over by moving c outwards by |c| * 2^-22 (near planes down, far planes up), and the
+	// relative errors by the same "tf * widen < tn" as every other box test here.  An infinite inv (a zero in d) turns the axis's terms
+	// into NaN or into the harmless infinity, which max / min ignore: the axis then simply does not cull.  And the near / far plane of
+	// an axis is picked by ADDRESS (the record holds lo.x lo.y lo.z hi.x hi.y hi.z, 16 bytes each) instead of by 24 selects per record.
+	const V3 cc = v3(-(o.x * invb.x), -(o.y * invb.y), -(o.z * invb.z));
+	const V3 ce = v3(fabsf(cc.x) * 2.3841858e-7f, fabsf(cc.y) * 2.3841858e-7f, fabsf(cc.z) * 2.3841858e-7f);
+	const V3 cn = cc - ce, cf = cc + ce;
+	const char* recs = (const char*)(sm + RL_LDS_NODES);
+	const uint32_t oNX = nx ? 48u : 0u, oFX = 48u - oNX, oNY = ny ? 64u : 16u, oFY = 80u - oNY, oNZ = nz ? 80u : 32u, oFZ = 112u - oNZ;
+	#pragma unroll
+	for (int g = 0; g < RL_LEAFLIST_RECORDS; ++g) {
+		key[4 * g] = key[4 * g + 1] = key[4 * g + 2] = key[4 * g + 3] = 0xffffffffu;
+		if (g < S.numLeafRecords) {   // the same for every lane
+			c.nodes += 2;             // 64-byte records fetched
+			RL_WSTEP(4);
+			const char* rec = recs + g * (RL_LDS_NSTRIDE * 16);
+			const float4 nX = *(const float4*)(rec + oNX), fX = *(const float4*)(rec + oFX);
+			const float4 nY = *(const float4*)(rec + oNY), fY = *(const float4*)(rec + oFY);
+			const float4 nZ = *(const float4*)(rec + oNZ), fZ = *(const float4*)(rec + oFZ);
+			#define RL_LSLAB(k, slot) { \
+				float tn = tMin, tf = FLT_MAX; \
+				tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = fminf(tf, __builtin_fmaf(fX.k, invb.x, cf.x)); \
+				tn = fmaxf(tn, __builtin_fmaf(nY.k, invb.y, cn.y)); tf = fminf(tf, __builtin_fmaf(fY.k, invb.y, cf.y)); \
+				tn = fmaxf(tn, __builtin_fmaf(nZ.k, invb.z, cn.z)); tf = fminf(tf, __builtin_fmaf(fZ.k, invb.z, cf.z)); \
+				if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(fmaxf(tn, 0.0f)) & ~31u) | (uint32_t)(slot); }
+			RL_LSLAB(x, 4 * g) RL_LSLAB(y, 4 * g + 1) RL_LSLAB(z, 4 * g + 2) RL_LSLAB(w, 4 * g + 3)
+			#undef RL_LSLAB
+		}
+	}
+	uint32_t from = 0u;   // keys below this one are done (keys are distinct: the slot is part of the key)
+	// (One triangle per turn of ONE loop -- a lane picks its next leaf while its neighbours test their next triangle -- was measured too: 9.8
+	// triangle steps per wave and bounce instead of 12 on 16 leaves, but 19.81 ms against 19.42: the pick costs more per turn than it saves.)
+	for (;;) {
+		uint32_t m = 0xffffffffu;
+		#pragma unroll
+		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] >= from ? key[j] : 0xffffffffu);
+		if (m == 0xffffffffu) break;
+		if (best.t * RL_BOX_WIDEN < __uint_as_float(m & ~31u)) break;   // the nearest leaf left starts behind the hit (the slab test's own cut: tf * widen < tn)
+		from = m + 1u;
+		RL_WSTEP(6);
+		const uint32_t j = m & 31u;
+		const int ref = ((const int*)(sm + RL_LDS_NODES + (j >> 2) * RL_LDS_NSTRIDE + 6))[j & 3u];
+		const uint32_t code = (uint32_t)~ref;
+		const int first = (int)(code >> 6);
+		const int count = (int)(code & 7u) + 1;
+		const bool alpha = (code & 8u) != 0;
+		for (int i = 0; i < count; ++i) {
+			const Tri T = TriFrom(sm + RL_LDS_ISECT + (first + i) * RL_LDS_TSTRIDE);
+			c.tris++;
+			RL_WSTEP(5);
+			const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
+			if (!(t >= tMin && t <= FLT_MAX && (t < best.t || (t == best.t && first + i < best.tri)))) continue;
+			const V3 p = o + t * d;
+			const V3 w = p - T.v0;
+			const float wv = dot(w, T.v), wu = dot(w, T.u);
+			const float pa = (T.uv * wv - T.vv * wu) / T.denom;
+			const float pb = (T.uv * wu - T.uu * wv) / T.denom;
+			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tMin, t)) {
+				if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
+				best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
+				if (ANYHIT) return true;
+			}
+		}
+	}
+	return best.tri >= 0;
+}
+
 // The same closest-hit search on the BVH4 (DNode4): four slab tests per step, hit children ordered by entry distance.
 // FULL: float boxes (S.nodes4f), else the grid nodes (S.nodes4)
-template <int STACK, bool ANYHIT, bool PRIMS, bool FULL, bool LDS = false>
+template <int STACK, bool ANYHIT, bool PRIMS, bool FULL, int LDS = 0>
 __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c, const float4* sm = nullptr)
 {
+	if constexpr (LDS == 2) return TraverseLeafList<ANYHIT>(S, o, d, tMin, best, c, sm);
 	c.rays++;
 	V3 invb = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // for the box tests (the candidate rule divides again: exact, and rare)
 	if (!FULL) invb = ClampInv(invb);
@@ -553,9 +647,10 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 	for (;;) {
 		while (cur >= 0 && cur != DONE) {
 			c.nodes += FULL ? 2 : 1;   // 64-byte records fetched
+			RL_WSTEP(4);
 			const float tmx = fminf(best.t, FLT_MAX);
 			float t0, t1, t2, t3; int r0, r1, r2, r3;
-			if (FULL) { RL_WIDE_STEP_F((LDS ? sm + RL_LDS_NODES + cur * 8 : (const float4*)(S.nodes4f + cur)), o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, a0, a1, a2, a3, ch) t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w; }
+			if (FULL) { RL_WIDE_STEP_F((LDS ? sm + RL_LDS_NODES + cur * RL_LDS_NSTRIDE : (const float4*)(S.nodes4f + cur)), o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, a0, a1, a2, a3, ch) t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w; }
 			else { RL_WIDE_STEP_Q(S, cur, o, invb, nx, ny, nz, tMin, tmx, RL_BOX_WIDEN, a0, a1, a2, a3, ch) t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w; }
 			if (r0 == DNODE_EMPTY) t0 = INFINITY;
 			if (r1 == DNODE_EMPTY) t1 = INFINITY;
@@ -576,9 +671,11 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 			const int first = (int)(code >> 6);
 			const int count = (int)(code & 7u) + 1;
 			const bool alpha = (code & 8u) != 0;
+			RL_WSTEP(6);
 			for (int i = 0; i < count; ++i) {
-				const Tri T = LDS ? TriFrom(sm + RL_LDS_ISECT + (first + i) * 4) : LoadTri(S, first + i);
+				const Tri T = LDS ? TriFrom(sm + RL_LDS_ISECT + (first + i) * RL_LDS_TSTRIDE) : LoadTri(S, first + i);
 				c.tris++;
+				RL_WSTEP(5);
 				const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
 				if (!(t >= tMin && t <= FLT_MAX && (t < best.t || (t == best.t && first + i < best.tri)))) continue;
 				const V3 p = o + t * d;
@@ -607,7 +704,7 @@ struct Surf { float t; V3 p, n; float U, V; V3 tangent, bitangent; };
 
 // HitResult for the winning primitive (reference geom/triangle.cc:43-47, geom/sphere.cc:19-41, geom/cube.cc:24-38)
 // + the tangent frame (geom/hit.cc:6-18).  Returns the material index.
-template <bool PRIMS, bool LDS = false>
+template <bool PRIMS, int LDS = 0>
 __device__ __forceinline__ int BuildSurface(const DSceneView& S, V3 o, V3 d, const HitRec& h, Surf& s, bool basis, Counters& c, const float4* sm = nullptr)
 {
 	int material;
@@ -615,7 +712,7 @@ __device__ __forceinline__ int BuildSurface(const DSceneView& S, V3 o, V3 d, con
 	s.p = o + h.t * d;
 	const uint32_t kind = PRIMS ? (((uint32_t)h.tri) >> 28) : 0u;
 	if (kind == 0u) {
-		const Shade sh = LDS ? ShadeFrom(sm + RL_LDS_SHADE + h.tri * 4) : LoadShade(S, h.tri);
+		const Shade sh = LDS ? ShadeFrom(sm + RL_LDS_SHADE + h.tri * RL_LDS_TSTRIDE) : LoadShade(S, h.tri);
 		c.shaded++;
 		const float a = h.a, b = h.b;
 		s.n = normalize((1 - a - b) * sh.n0 + a * sh.n1 + b * sh.n2);
@@ -990,7 +1087,7 @@ __device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rn
 struct SkyRot { float m0[3], m1[3], m2[3]; };   // Rotator(yaw 90).rotate rows, computed on the host (renderer.cc:166-168)
 
 // Miss shader: sky panorama + sun (reference render/renderer.cc:155-199)
-template <int STACK, bool PRIMS, bool FULL, bool LDS = false>
+template <int STACK, bool PRIMS, bool FULL, int LDS = 0>
 __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V3 o, V3 d, float rayTime, float rayTMin, int* stk, Counters& c, const float4* sm = nullptr)
 {
 	V3 missResult = v3s(0.0f);
@@ -1045,8 +1142,9 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 #endif
 // PRIMS: the scene holds spheres / cubes (their leaf and shading code is compiled out of the triangle-only variant)
 // FULL: the wide tree, if the launch carries one, has float boxes (S.nodes4f) -- small scenes; else grid nodes (S.nodes4)
-// LDS (with FULL, triangle scenes within the RL_LDS_MAX* limits): the scene's records are copied to LDS at the start and read from there
-template <int STACK, bool PRIMS, bool FULL, bool LDS = false>
+// LDS (with FULL, triangle scenes within the RL_LDS_MAX* limits): the scene's records are copied to LDS at the start and read from there;
+//     LDS == 2: a scene of <= 16 leaves, walked through its leaf list (TraverseLeafList) instead of its tree
+template <int STACK, bool PRIMS, bool FULL, int LDS = 0>
 __global__ void __launch_bounds__(RL_BLOCK, (STACK <= 32 ? RL_TRACE_MIN_WAVES : 2))
 k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
         float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
@@ -1056,10 +1154,10 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	__shared__ float4 s_scene[LDS ? RL_LDS_TOTAL : 1];
 	const float4* sm = s_scene;
 	if (LDS) {
-		const uint32_t nN = (uint32_t)S.numNodes4 * 8u, nT = (uint32_t)S.numTriangles * 4u, nM = (uint32_t)S.numMaterials * 5u;
+		const uint32_t nN = (uint32_t)(LDS == 2 ? S.numLeafRecords : S.numNodes4) * 8u, nT = (uint32_t)S.numTriangles * 4u, nM = (uint32_t)S.numMaterials * 5u;
 		for (uint32_t i = threadIdx.x; i < 4u; i += RL_BLOCK) s_scene[RL_LDS_ROOT + i] = ((const float4*)S.nodes)[i];
-		for (uint32_t i = threadIdx.x; i < nN; i += RL_BLOCK) s_scene[RL_LDS_NODES + i] = ((const float4*)S.nodes4f)[i];
-		for (uint32_t i = threadIdx.x; i < nT; i += RL_BLOCK) { s_scene[RL_LDS_ISECT + i] = ((const float4*)S.isect)[i]; s_scene[RL_LDS_SHADE + i] = ((const float4*)S.shade)[i]; }
+		for (uint32_t i = threadIdx.x; i < nN; i += RL_BLOCK) s_scene[RL_LDS_NODES + (i >> 3) * RL_LDS_NSTRIDE + (i & 7u)] = ((const float4*)(LDS == 2 ? S.leafList : S.nodes4f))[i];
+		for (uint32_t i = threadIdx.x; i < nT; i += RL_BLOCK) { const uint32_t at = (i >> 2) * RL_LDS_TSTRIDE + (i & 3u); s_scene[RL_LDS_ISECT + at] = ((const float4*)S.isect)[i]; s_scene[RL_LDS_SHADE + at] = ((const float4*)S.shade)[i]; }
 		for (uint32_t i = threadIdx.x; i < nM; i += RL_BLOCK) s_scene[RL_LDS_MATS + i] = ((const float4*)S.materials)[i];
 		__syncthreads();
 	}
@@ -1086,15 +1184,21 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	RL_TIMELINE(0);
 #ifdef RL_DIAG_STAMPS
 	// diagnostic build only: shader-clock time per phase (refill | traverse | shade | fold), summed per wave
-	unsigned long long stampAcc[4] = { 0, 0, 0, 0 }, subAcc[4] = { 0, 0, 0, 0 };
+	unsigned long long stampAcc[4] = { 0, 0, 0, 0 }, subAcc[4] = { 0, 0, 0, 0 }, laneAcc[4] = { 0, 0, 0, 0 }, laneT[4] = { 0, 0, 0, 0 };
 	c.diag = counters;
 	unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 	#define RL_SUBSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); subAcc[k] += now_ - subLast; subLast = now_; __builtin_amdgcn_sched_barrier(0); }
 	unsigned long long subLast = 0;
 	#define RL_STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[k] += now_ - stampLast; stampLast = now_; __builtin_amdgcn_sched_barrier(0); }
+	// lane-weighted: clock x lanes that took part in the phase (k: 0 traverse, 1 shade a hit, 2 miss shader, 3 fold)
+	#define RL_LANESTAMP(k, cond) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); laneAcc[k] += (now_ - laneLast) * (unsigned long long)__popcll(__ballot(cond)); laneT[k] += now_ - laneLast; __builtin_amdgcn_sched_barrier(0); }
+	#define RL_LANEBEGIN() { __builtin_amdgcn_sched_barrier(0); laneLast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+	unsigned long long laneLast = 0;
 #else
 	#define RL_STAMP(k)
 	#define RL_SUBSTAMP(k)
+	#define RL_LANESTAMP(k, cond)
+	#define RL_LANEBEGIN()
 #endif
 
 	for (;;) {
@@ -1165,11 +1269,13 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 		// ---- one bounce for every active lane (TraceScene, reference render/renderer.cc:114-208) ----
 		if (lane == 0) c.trips++;
 		RL_STAMP(0);
+		RL_LANEBEGIN();
 		HitRec h; h.tri = -1;
 		const bool doTrace = active && depth < P.maxPathLength;   // renderer.cc:120-123 otherwise
 		bool hit = false;
 		// the 4-wide tree when the launch carries it (triangle scenes; half the steps: 24.6 -> 22.4 ms on the Cornell frame)
 		if (doTrace) hit = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, false, PRIMS, FULL, LDS>(S, o, d, rayTime, P.rayTMin, h, stk, c, sm) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
+		RL_LANESTAMP(0, doTrace);
 		RL_STAMP(1);
 		if (active) {
 			bool done = false, store = false;
@@ -1179,6 +1285,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				done = true;
 			} else if (hit) {
 				Surf s;
+				RL_LANEBEGIN();
 #ifdef RL_DIAG_STAMPS
 				subLast = __builtin_amdgcn_s_memtime();
 #endif
@@ -1213,12 +1320,16 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 					done = true;
 				}
 				RL_SUBSTAMP(2);
+				RL_LANESTAMP(1, true);
 			} else {
+				RL_LANEBEGIN();
 				L = MissShader<STACK, PRIMS, FULL, LDS>(S, R, o, d, rayTime, P.rayTMin, stk, c, sm);
 				done = true;
+				RL_LANESTAMP(2, true);
 			}
 			RL_STAMP(2);
 			if (done) {
+				RL_LANEBEGIN();
 				// fold back to the camera: radiance = (0 + refl*Li*sp/pdf) + E at every vertex
 #if RL_FOLD_PREFETCH > 0
 				if (depth <= RL_FOLD_PREFETCH) {
@@ -1257,6 +1368,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 				}
 				samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
 				active = false;
+				RL_LANESTAMP(3, true);
 			}
 			if (store) {
 				// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
@@ -1269,7 +1381,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	}
 
 #ifdef RL_DIAG_STAMPS
-	if (lane == 0) for (int k = 0; k < 4; ++k) { atomicAdd(&counters[CNT_COUNT + k], stampAcc[k]); atomicAdd(&counters[CNT_COUNT + 8 + k], subAcc[k]); atomicAdd(&counters[CNT_COUNT + 12 + k], c.tAcc[k]); }
+	if (lane == 0) for (int k = 0; k < 4; ++k) { atomicAdd(&counters[CNT_COUNT + k], stampAcc[k]); atomicAdd(&counters[CNT_COUNT + 8 + k], subAcc[k]); atomicAdd(&counters[CNT_COUNT + 12 + k], c.tAcc[k]); atomicAdd(&counters[CNT_COUNT + 20 + k], laneAcc[k]); if (RL_DIAG_STAMPS < 2) atomicAdd(&counters[CNT_COUNT + 4 + k], laneT[k]); }
 #endif
 	RL_TIMELINE(2);
 	// ---- counters: wave reduction, one atomic per wave and counter ----

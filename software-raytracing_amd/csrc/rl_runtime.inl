@@ -21,7 +21,7 @@ namespace rl {
 // One physical device's copy of a scene.
 struct DeviceSceneCopy {
 	int device = 0;
-	DNode4Q* nodes4 = nullptr; DNode4* nodes4f = nullptr;
+	DNode4Q* nodes4 = nullptr; DNode4* nodes4f = nullptr; DNode4* leafList = nullptr;
 	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
 	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
 	DSphere* spheres = nullptr; DCube* cubes = nullptr;
@@ -220,7 +220,7 @@ void FreeCopy(DeviceSceneCopy* C)
 {
 	if (!C) return;
 	(void)hipSetDevice(C->device);
-	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4f) (void)hipFree(C->nodes4f); (void)hipFree(C->isect); (void)hipFree(C->shade);
+	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4f) (void)hipFree(C->nodes4f); if (C->leafList) (void)hipFree(C->leafList); (void)hipFree(C->isect); (void)hipFree(C->shade);
 	(void)hipFree(C->materials); (void)hipFree(C->textures); (void)hipFree(C->texels); (void)hipFree(C->spheres); (void)hipFree(C->cubes);
 	if (C->sky) (void)hipFree(C->sky);
 	delete C;
@@ -354,6 +354,7 @@ bool UploadScene(Scene& sc)
 		const bool wantFull = D->hasNodes4 && (!RL_Q4 || sc.triangles.size() < 4096);
 		if (ok && D->hasNodes4 && RL_Q4) ok = Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size());
 		if (ok && wantFull) ok = Upload(C->nodes4f, sc.bvh.nodes4.data(), sc.bvh.nodes4.size());
+		if (ok && wantFull && !sc.bvh.leafList.empty()) ok = Upload(C->leafList, sc.bvh.leafList.data(), sc.bvh.leafList.size());
 		ok = ok && Upload(C->isect, isect.data(), n) && Upload(C->shade, shade.data(), n);
 		ok = ok && Upload(C->materials, mats.data(), mats.size()) && Upload(C->textures, texs.data(), texs.size()) && Upload(C->texels, pool.data(), pool.size());
 		ok = ok && Upload(C->spheres, dsph.data(), dsph.size()) && Upload(C->cubes, dcub.data(), dcub.size());
@@ -367,6 +368,7 @@ bool UploadScene(Scene& sc)
 		V.hasSun = !(sc.sunIlluminance.x == 0.0f && sc.sunIlluminance.y == 0.0f && sc.sunIlluminance.z == 0.0f);   // renderer.cc:192
 		V.numTriangles = (int32_t)n;
 		V.numNodes4 = (int32_t)sc.bvh.nodes4.size(); V.numMaterials = (int32_t)mats.size();
+		V.leafList = C->leafList; V.numLeafRecords = C->leafList ? (int32_t)sc.bvh.leafList.size() : 0; V.padLeaf = 0;
 	}
 	HIP_OK(hipSetDevice(g_rt.devices[0]));
 	sc.device = D;
@@ -516,7 +518,11 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 			if constexpr (STACK == 16 && !PRIMS) {
 				const char* e = getenv("RAYLIB_LDS_SCENE");
 				lds = full && (e ? atoi(e) != 0 : true) && sc.bvh.nodes4.size() <= RL_LDS_MAXNODES && sc.triangles.size() <= RL_LDS_MAXTRIS && sc.materials.size() <= RL_LDS_MAXMATS;
-				if (lds) traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, true>;
+				// ... and a scene of few leaves without a tree (rl_bvh.cc "the leaf list"); RAYLIB_LEAF_LIST=0 walks its BVH4 instead
+				const char* f = getenv("RAYLIB_LEAF_LIST");
+				const bool flat = lds && traceView.leafList != nullptr && traceView.numLeafRecords <= RL_LEAFLIST_RECORDS && (f ? atoi(f) != 0 : true);
+				if (flat) traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, 2>;
+				else if (lds) traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, 1>;
 			}
 			if (!lds) traceKernel = full ? (TraceKernel)k_trace<STACK, PRIMS, true> : (TraceKernel)k_trace<STACK, PRIMS, false>;
 		}
@@ -633,6 +639,11 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 		Log("wave steps: node %llu (lane steps %llu, eff %.3f)  tri %llu (lane %llu, eff %.3f)  leaf rounds %llu  trips %llu", cnt[CNT_COUNT + 4], cnt[CNT_NODES], cnt[CNT_NODES] / (64.0 * cnt[CNT_COUNT + 4] + 1), cnt[CNT_COUNT + 5], cnt[CNT_TRIS], cnt[CNT_TRIS] / (64.0 * cnt[CNT_COUNT + 5] + 1), cnt[CNT_COUNT + 6], cnt[CNT_TRIPS]);
 		if (tot > 0) Log("shade split (of all): surface+material %.3f scatter %.3f emit+store %.3f", cnt[CNT_COUNT + 8] / tot, cnt[CNT_COUNT + 9] / tot, cnt[CNT_COUNT + 10] / tot);
 		if (tot > 0) Log("microfacet split (of all): setup %.3f beckmann sample %.3f brdf+pdf %.3f | newton wave iters %llu lane iters %llu (eff %.3f) | microfacet wave calls %llu lanes %llu (eff %.3f)", cnt[CNT_COUNT + 12] / tot, cnt[CNT_COUNT + 13] / tot, cnt[CNT_COUNT + 14] / tot, cnt[CNT_COUNT + 16], cnt[CNT_COUNT + 17], cnt[CNT_COUNT + 17] / (64.0 * cnt[CNT_COUNT + 16] + 1), cnt[CNT_COUNT + 18], cnt[CNT_COUNT + 19], cnt[CNT_COUNT + 19] / (64.0 * cnt[CNT_COUNT + 18] + 1));
+		{
+			static const char* nm[4] = { "traverse", "shade a hit", "miss shader", "fold + store" };
+			for (int k = 0; k < 4; ++k) if (cnt[CNT_COUNT + 4 + k] && cnt[CNT_COUNT + 20 + k])
+				Log("  %-12s clock share %.3f, lanes taking part %.3f (level-1 diagnostic build)", nm[k], cnt[CNT_COUNT + 4 + k] / tot, cnt[CNT_COUNT + 20 + k] / (64.0 * cnt[CNT_COUNT + 4 + k]));
+		}
 		if (tot > 0) Log("phase shares (shader clock): refill %.3f traverse %.3f shade %.3f fold %.3f", cnt[CNT_COUNT] / tot, cnt[CNT_COUNT + 1] / tot, cnt[CNT_COUNT + 2] / tot, cnt[CNT_COUNT + 3] / tot);
 	}
 	return true;

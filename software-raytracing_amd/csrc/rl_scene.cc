@@ -152,10 +152,16 @@ bool Scene::BuildAccel(float t0, float t1)
 		for (DNode& n : bvh.nodes) { patch(n.left); patch(n.right); }
 		for (DNode4& n : bvh.nodes4) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 		for (DNode4Q& n : bvh.nodes4q) for (int k = 0; k < 4; ++k) patch(n.child[k]);
+		for (DNode4& n : bvh.leafList) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 	}
 	Log("Scene finalized: %u triangles, %u BVH nodes, depth %u, SAH cost %.2f (BVH build %.2f s)",
 	    (unsigned)triangles.size(), (unsigned)bvh.nodes.size(), bvh.depth, bvh.sahCost, buildSec);
 	if (!bvh.nodes4.empty()) Log("\twide tree: %u BVH4 nodes, worst-case traversal stack %u entries", (unsigned)bvh.nodes4.size(), bvh.stackNeed4);
+	if (!bvh.leafList.empty()) {
+		unsigned leaves = 0;
+		for (const DNode4& nd : bvh.leafList) for (int k = 0; k < 4; ++k) if (nd.child[k] != DNODE_EMPTY) ++leaves;
+		Log("\tleaf list: %u leaves in %u records (k_trace walks it instead of the tree)", leaves, (unsigned)bvh.leafList.size());
+	}
 	return true;
 }
 

@@ -111,6 +111,7 @@ _EXPORTS = {
     "RaylibAMD_ParseFloat": (C.c_float, [C.c_char_p]),
     "RaylibAMD_ImageSize": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "RaylibAMD_SceneBVH4Info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "RaylibAMD_SceneLeafListInfo": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "RaylibAMD_SceneBVHHash": (C.c_uint64, [C.c_void_p]),
     "RaylibAMD_CameraExport": (None, [C.c_void_p, C.POINTER(C.c_float)]),
     "RaylibAMD_CreateImageFromData": (C.c_void_p, [C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),

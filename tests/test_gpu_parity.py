@@ -385,6 +385,32 @@ def test_full_size_tile_union(full_size, gpu_lib):
     assert np.array_equal(bits(tiling.assemble(1920, 1080, world, bufs)), bits(img))
 
 
+# ---- k_trace's walks of a small scene --------------------------------------------------------
+# A scene of at most 108 triangles is LDS-resident and walked through its leaf list (default); RAYLIB_LEAF_LIST=0 walks its BVH4 in LDS,
+# RAYLIB_LDS_SCENE=0 the BVH4 in global memory, RAYLIB_BVH4=0 the BVH2.  Same bits and the same queries from all four, ties included.
+
+@pytest.mark.parametrize("name", list(helpers.CASES))
+def test_small_scene_walks_agree(name, sessions, gpu_lib, monkeypatch):
+    ses = sessions[name]
+    monkeypatch.setenv("RAYLIB_POOL", "0")
+    has_list = gpu_lib.RaylibAMD_SceneLeafListInfo(ses.scene, None) > 0
+    assert has_list                                         # every fixture scene is that small
+    for mode, spp in ((0, 16), (1, 1), (4, 1)):
+        base = ses.render(64, 64, spp, mode=mode)
+        st0 = ses.stats().as_dict()
+        for env in (dict(RAYLIB_LEAF_LIST="0"), dict(RAYLIB_LDS_SCENE="0"), dict(RAYLIB_BVH4="0")):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            img = ses.render(64, 64, spp, mode=mode)
+            st1 = ses.stats().as_dict()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert helpers.same(img, base).all(), (name, mode, env)
+            assert st0["rays"] == st1["rays"] and st0["cameraSamples"] == st1["cameraSamples"], (name, mode, env)
+            if mode == 0 and "RAYLIB_LEAF_LIST" in env:
+                assert st0["nodesVisited"] != st1["nodesVisited"], "the leaf list was not the walk that ran"
+
+
 # ---- the pool schedule of the megakernel (k_trace_pool) -------------------------------------
 # Scenes whose BVH is deeper than 16 run it by default; RAYLIB_POOL=K forces it (K = 2, 3, 4 -> 128, 192, 256 paths
 # per wave) and RAYLIB_POOL=0 forces the one-path-per-lane schedule.  Every schedule must produce the same bits.

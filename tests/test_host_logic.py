@@ -142,6 +142,26 @@ def test_bvh_builder(lib, workdir):
     lib.Raylib_DestroyScene(sc)
 
 
+def test_small_scenes_carry_a_valid_leaf_list(lib, workdir):
+    """Scenes of at most 108 triangles get the leaf list k_trace walks instead of the tree (rl_bvh.cc): at most 24 leaves of at most 8
+    triangles, every triangle in exactly one of them and inside its box (RaylibAMD_SceneBVH4Info checks that), none for larger scenes."""
+    from raylib_amd import binding
+    cases = [(scenes.cornell, {}, True), (scenes.cutout, {}, True), (scenes.pbr_maps, {}, True),
+             (scenes.cornell, dict(tess=2), False), (scenes.soup, dict(n_tris=100), True), (scenes.soup, dict(n_tris=109), False)]
+    for k, (make, kw, expect) in enumerate(cases):
+        obj, n = make(os.path.join(str(workdir), "ll_%d.obj" % k), **kw)[:2]
+        ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+        most = C.c_uint32()
+        leaves = lib.RaylibAMD_SceneLeafListInfo(ses.scene, C.byref(most))
+        if n >= 8:
+            assert lib.RaylibAMD_SceneBVH4Info(ses.scene, None, None) == 1, (make.__name__, kw)
+        if expect:
+            assert 1 <= leaves <= 24 and 1 <= most.value <= 8 and n <= 108, (make.__name__, kw, n, leaves, most.value)
+        else:
+            assert leaves == 0 and n > 108, (make.__name__, kw, n, leaves)
+        ses.close()
+
+
 def test_bvh_build_is_the_same_tree_for_any_thread_count(lib, workdir, monkeypatch):
     """Above 65536 primitives the build uses every host thread (top levels: parallel binning; sub-trees: tasks);
     the flat tree must be byte-identical to the single-threaded one (traversal order, hence tie behaviour, depends on it)."""

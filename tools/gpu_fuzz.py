@@ -9,13 +9,14 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 d = tempfile.mkdtemp()
 MODES = [dict(RAYLIB_POOL="0"), dict(), dict(RAYLIB_BVH4="0"), dict(RAYLIB_POOL_SHORT_STACK="0"), dict(RAYLIB_BVH4="0", RAYLIB_POOL_SHORT_STACK="4"),
-         dict(RAYLIB_POOL="3", RAYLIB_BVH4="0"), dict(RAYLIB_POOL="2", RAYLIB_SAMPLE_BATCH="1")]
+         dict(RAYLIB_POOL="3", RAYLIB_BVH4="0"), dict(RAYLIB_POOL="2", RAYLIB_SAMPLE_BATCH="1"),
+         dict(RAYLIB_POOL="0", RAYLIB_LEAF_LIST="0"), dict(RAYLIB_POOL="0", RAYLIB_LDS_SCENE="0")]
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 bad = 0
 only = int(os.environ.get("FUZZ_ONLY", "-1"))
 t0 = time.time()
 for case in range(cases):
-    kind = rng.randint(5)
+    kind = rng.randint(int(os.environ.get("FUZZ_KINDS", "6")))   # FUZZ_KINDS=5 reproduces the case list of the runs recorded before the small-soup kind existed
     if kind == 0:
         gen = (scenes.cornell, dict(tess=int(rng.randint(1, 20)), displace_fraction=float(rng.choice([0.0, 0.1, 0.3])),
                                     tall_material=str(rng.choice([scenes.MIRROR, scenes.GLASS, scenes.WHITE])), short_material=str(rng.choice([scenes.WHITE, scenes.GLASS]))))
@@ -25,8 +26,10 @@ for case in range(cases):
         gen = (scenes.cutout, dict(tess=int(rng.randint(1, 12))))
     elif kind == 3:
         gen = (scenes.colonnade, dict(tess=int(rng.randint(1, 4))))
-    else:
+    elif kind == 4:
         gen = (scenes.pbr_maps, dict(tess=int(rng.randint(1, 10)), mtl=scenes.random_pbr_mtl(rng)))
+    else:   # small soups: the LDS-resident class (leaf list up to 108 triangles, BVH4 in LDS up to 128)
+        gen = (scenes.soup, dict(n_tris=int(rng.randint(8, 140)), seed=int(rng.randint(1 << 30)), extent=float(rng.uniform(0.5, 3)), size=float(rng.uniform(0.05, 2.0))))
     sun = (0, 0, 0) if rng.rand() < 0.4 else tuple(float(x) for x in rng.uniform(1, 20, 3))
     sun_dir = tuple(float(x) for x in rng.uniform(-1, 1, 3) * np.array([1, 1, 1]) + np.array([0, -1.2, 0]))
     sky = scenes.sky_panorama() if rng.rand() < 0.4 else None
