@@ -1105,7 +1105,9 @@ __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V
 	}
 	if (S.hasSun) {
 		HitRec tmp;
-		const bool occluded = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, true, PRIMS, FULL, LDS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c, sm)
+		bool occluded;
+		if constexpr (LDS != 0) occluded = Traverse4<STACK, true, PRIMS, FULL, LDS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c, sm);
+		else occluded = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, true, PRIMS, FULL, LDS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c, sm)
 		                                           : Traverse<STACK, true, PRIMS>(S, o, -ld3(S.sunDirection), rayTime, rayTMin, tmp, stk, c);
 		if (!occluded) missResult = missResult + ld3(S.sunIlluminance);
 	}
@@ -1132,6 +1134,14 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 	j.sample = sLocal;
 	j.valid = (j.x < P.width) && (j.y < P.height);
 	return j;
+}
+
+__device__ __forceinline__ void WaveLdsSync()
+{
+	// LDS operations of one wave are executed in issue order; this only stops the compiler from moving LDS
+	// accesses of different lanes' data across the point.
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
 }
 
 // ---------------------------------------------------------------------------
@@ -1181,6 +1191,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	// per wave and bounce was exactly that rate: the kernel ran at the atomic's speed.)
 	uint32_t chunkNext = 0, chunkEnd = 0;
 	bool globalDone = false;
+	uint32_t qCount = 0;   // LDS == 2: camera rays waiting in the wave's queue
 	RL_TIMELINE(0);
 #ifdef RL_DIAG_STAMPS
 	// diagnostic build only: shader-clock time per phase (refill | traverse | shade | fold), summed per wave
@@ -1207,6 +1218,86 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 		// only run the (sun-less) miss shader, so it is finished here and its lane takes another job at
 		// once instead of occupying a lane slot through a whole bounce trip (in a 16:9 Cornell frame
 		// more than half of the camera samples never touch the scene).
+		if constexpr (LDS == 2) {
+			// Leaf-list scenes need no traversal stack, and its LDS (1024 dwords per wave) is a QUEUE of camera rays instead: rays are
+			// generated 64 at a time -- every lane takes a job, the same code for all of them -- the ones that cannot hit anything are finished
+			// on the spot as in the rounds below, the others are written to the queue back to back (ballot + prefix rank), and the idle
+			// lanes take theirs from its end.  The rounds below generate for the idle lanes only: a third of the wave in the first round, then a half
+			// of that (in a 16:9 Cornell frame more than half of the camera samples miss the room), a quarter ... at the cost of a whole wave each time.
+			enum { QCAP = 112, QFIELDS = 9 };   // 9 x 112 dwords <= 1024
+			int* q = s_stack + (threadIdx.x >> 6) * (STACK * 64);
+			const bool need = !active && !exhausted;
+			const unsigned long long needMask = __ballot(need);
+			const uint32_t n = (uint32_t)__popcll(needMask);
+			while (n > 0 && qCount < n && qCount <= QCAP - 64 && !(globalDone && chunkNext >= chunkEnd)) {
+				if (chunkNext >= chunkEnd) {
+					uint32_t base = 0;
+					if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
+					base = __shfl(base, 0);
+					if (base >= P.numJobs) { globalDone = true; RL_TIMELINE(1); break; }
+					chunkNext = base; chunkEnd = min(base + P.jobChunk, P.numJobs);
+				}
+				const uint32_t avail = chunkEnd - chunkNext;
+				bool survive = false;
+				V3 qo = v3s(0.0f), qd = v3s(0.0f); Rng qg; qg.s.state = 0; uint32_t qOut = 0;
+				if (lane < avail) {
+					const JobPixel j = DecodeJob(P, chunkNext + lane);
+					if (j.valid) {
+						// GenerateCell body, reference render/renderer.cc:232-239
+						const uint32_t sm_ = P.sampleBegin + j.sample;
+						qg.s = raylib_rng_begin_mixed(P.seedMixed, j.y * P.width + j.x, sm_);
+						const float imageWidth = (float)P.width, imageHeight = (float)P.height;
+						float u = (float)j.x / imageWidth;
+						float v = (float)j.y / imageHeight;
+						if (sm_ != 0) {
+							u += (Next(qg) - 0.5f) * 2.0f / imageWidth;
+							v += (Next(qg) - 0.5f) * 2.0f / imageHeight;
+						}
+						float qTime;
+						CameraRay(P.camera, u, v, qg, qo, qd, qTime);
+						qOut = j.sample * numSlots + j.slot;
+						c.samples++;
+						survive = true;
+						if (P.maxPathLength > 0 && RootMiss<LDS>(S, qo, qd, P.rayTMin, sm)) {
+							const bool sunQuick = !S.hasSun || RootMiss<LDS>(S, qo, -ld3(S.sunDirection), P.rayTMin, sm);
+							if (sunQuick) {
+								c.rays++; c.nodes++;   // the closest-hit query this replaces fetches the root node and stops
+								DSceneView Sq = S; Sq.hasSun = 0;
+								V3 L = MissShader<STACK, PRIMS, FULL, LDS>(Sq, R, qo, qd, qTime, P.rayTMin, stk, c, sm);
+								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
+								samples[qOut] = make_float4(L.x, L.y, L.z, 1.0f);
+								survive = false;
+							}
+						}
+					}
+				}
+				chunkNext += min(64u, avail);
+				const unsigned long long sv = __ballot(survive);
+				if (survive) {
+					const uint32_t at = qCount + (uint32_t)__popcll(sv & ((1ull << lane) - 1ull));
+					q[0 * QCAP + at] = __float_as_int(qo.x); q[1 * QCAP + at] = __float_as_int(qo.y); q[2 * QCAP + at] = __float_as_int(qo.z);
+					q[3 * QCAP + at] = __float_as_int(qd.x); q[4 * QCAP + at] = __float_as_int(qd.y); q[5 * QCAP + at] = __float_as_int(qd.z);
+					q[6 * QCAP + at] = (int)(uint32_t)qg.s.state; q[7 * QCAP + at] = (int)(uint32_t)(qg.s.state >> 32); q[8 * QCAP + at] = (int)qOut;
+				}
+				qCount += (uint32_t)__popcll(sv);
+				WaveLdsSync();
+			}
+			if (need) {
+				const uint32_t rank = (uint32_t)__popcll(needMask & ((1ull << lane) - 1ull));
+				if (rank < qCount) {
+					const uint32_t at = qCount - 1u - rank;
+					o = v3(__int_as_float(q[0 * QCAP + at]), __int_as_float(q[1 * QCAP + at]), __int_as_float(q[2 * QCAP + at]));
+					d = v3(__int_as_float(q[3 * QCAP + at]), __int_as_float(q[4 * QCAP + at]), __int_as_float(q[5 * QCAP + at]));
+					g.s.state = (uint64_t)(uint32_t)q[6 * QCAP + at] | ((uint64_t)(uint32_t)q[7 * QCAP + at] << 32);
+					outIndex = (uint32_t)q[8 * QCAP + at];
+					rayTime = 0.0f;   // leaf-list scenes are triangle scenes: nothing moves, the ray's time is not read
+					depth = 0;
+					active = true;
+				} else if (globalDone && chunkNext >= chunkEnd) exhausted = true;
+			}
+			qCount -= min(n, qCount);
+			WaveLdsSync();
+		} else
 		for (int round = 0; round < RL_REFILL_ROUNDS; ++round) {
 			const bool need = !active && !exhausted;
 			const unsigned long long mask = __ballot(need);
@@ -1274,7 +1365,10 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 		const bool doTrace = active && depth < P.maxPathLength;   // renderer.cc:120-123 otherwise
 		bool hit = false;
 		// the 4-wide tree when the launch carries it (triangle scenes; half the steps: 24.6 -> 22.4 ms on the Cornell frame)
-		if (doTrace) hit = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, false, PRIMS, FULL, LDS>(S, o, d, rayTime, P.rayTMin, h, stk, c, sm) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
+		if (doTrace) {
+			if constexpr (LDS != 0) hit = Traverse4<STACK, false, PRIMS, FULL, LDS>(S, o, d, rayTime, P.rayTMin, h, stk, c, sm);   // an LDS-resident scene has its wide tree
+			else hit = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, false, PRIMS, FULL, LDS>(S, o, d, rayTime, P.rayTMin, h, stk, c, sm) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
+		}
 		RL_LANESTAMP(0, doTrace);
 		RL_STAMP(1);
 		if (active) {
@@ -1442,13 +1536,6 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #define RL_POOL_KEEP 58   /* leave the traversal loop to fetch new rays when no more than this many lanes still traverse */
 #endif
 
-__device__ __forceinline__ void WaveLdsSync()
-{
-	// LDS operations of one wave are executed in issue order; this only stops the compiler from moving LDS
-	// accesses of different lanes' data across the point.
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-}
 
 struct Trav { V3 o, d, inv; float rayTime; bool nx, ny, nz, anyhit; HitRec best; int cur, sp, leafI; };
 

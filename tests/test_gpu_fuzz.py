@@ -11,14 +11,15 @@ from helpers import ffi, bits, scenes, objflat
 pytestmark = pytest.mark.gpu
 
 
-TIE_BUDGET = {11: 4, 12: 4, 13: 4}   # measured on MI355X in round 2: 0 / 0 / 0 excused pixels of 4 936 / 6 003 / 7 410
+TIE_BUDGET = {11: 4, 12: 4, 13: 4,   # measured on MI355X in round 2: 0 / 0 / 0 excused pixels of 4 936 / 6 003 / 7 410
+              21: 4, 22: 4}          # seeds from 20 on: small soups only (8..127 triangles: the LDS-resident class, walked through the leaf list up to 108)
 
 
 def _l2(a, b):
     return float(np.sqrt(((a[..., :3].astype(np.float64) - b[..., :3]) ** 2).sum(-1)).max())
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
+@pytest.mark.parametrize("seed", [11, 12, 13, 21, 22])
 def test_random_scenes_against_oracle(seed, gpu_lib, oracle, workdir):
     from raylib_amd import binding
     rng = np.random.RandomState(seed)
@@ -26,7 +27,10 @@ def test_random_scenes_against_oracle(seed, gpu_lib, oracle, workdir):
     total = tied = 0
     for case in range(8):
         kind = rng.randint(4)
-        if kind == 0:
+        if seed >= 20:
+            kind = 1
+            obj, n = scenes.soup(os.path.join(d, "f%d.obj" % case), n_tris=int(rng.randint(8, 128)), seed=int(rng.randint(1 << 30)), extent=float(rng.uniform(0.5, 3)), size=float(rng.uniform(0.05, 2.0)))
+        elif kind == 0:
             obj, n = scenes.cornell(os.path.join(d, "f%d.obj" % case), tess=int(rng.randint(1, 9)), displace_fraction=float(rng.choice([0.0, 0.2])),
                                     tall_material=str(rng.choice([scenes.MIRROR, scenes.GLASS, scenes.WHITE])), short_material=str(rng.choice([scenes.WHITE, scenes.GLASS])))
         elif kind == 1:
