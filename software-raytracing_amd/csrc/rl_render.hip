@@ -597,9 +597,12 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 	// (One triangle per turn of ONE loop -- a lane picks its next leaf while its neighbours test their next triangle -- was measured too: 9.8
 	// triangle steps per wave and bounce instead of 12 on 16 leaves, but 19.81 ms against 19.42: the pick costs more per turn than it saves.)
 	for (;;) {
+		// the smallest key >= from, as the smallest (key - from) in unsigned arithmetic: a key below `from` wraps around to more than
+		// 0xffffffff - from, which is where the unused keys (0xffffffff) land
 		uint32_t m = 0xffffffffu;
 		#pragma unroll
-		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] >= from ? key[j] : 0xffffffffu);
+		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] - from);
+		m += from;
 		if (m == 0xffffffffu) break;
 		if (best.t * RL_BOX_WIDEN < __uint_as_float(m & ~31u)) break;   // the nearest leaf left starts behind the hit (the slab test's own cut: tf * widen < tn)
 		from = m + 1u;
