@@ -31,7 +31,7 @@ extern "C" {
 
 typedef struct RaylibAMDStats {
 	uint64_t rays;            /* closest-hit + occlusion queries (reference renderer.cc:129,194,70,79) */
-	uint64_t nodesVisited;    /* 64-byte BVH node records fetched */
+	uint64_t nodesVisited;    /* 64-byte BVH node records fetched (a float-box BVH4 node or a leaf-list record of four boxes counts as two) */
 	uint64_t trisTested;      /* 64-byte triangle intersection records fetched */
 	uint64_t shadedHits;      /* 64-byte triangle shading records fetched */
 	uint64_t texFetches;      /* 16-byte texels fetched */
