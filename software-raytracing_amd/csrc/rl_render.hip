@@ -839,17 +839,24 @@ __device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slo
 	float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * rtm::exp_(-cotThetaI * cotThetaI));
 
 	int it = 0;
+	float invErf = 0.0f;
+	bool converged = false;
+#ifndef RL_NEWTON_UNROLLED
+	#pragma nounroll   /* nine copies of the body are 8 KB of code of which two or three ever run (same time either way, measured) */
+#endif
 	while (++it < 10) {
 		RL_WLSTEP(cn, 16, 17);
 		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
-		float invErf = ErfInv(b);
+		invErf = ErfInv(b);
 		float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * rtm::exp_(-invErf * invErf)) - sample_x;
 		float derivative = normalization * (1 - invErf * tanThetaI);
-		if (fabsf(value) < 1e-5f) break;
+		if (fabsf(value) < 1e-5f) { converged = true; break; }
 		if (value > 0) c = b; else a = b;
 		b -= value / derivative;
 	}
-	*slope_x = ErfInv(b);
+	// the reference evaluates ErfInv(b) once more here (material.cc:163); after the break b is still the argument invErf was computed from,
+	// so the value is in hand -- only a lane that used up its nine iterations has moved b since (a whole ErfInv per scattering event less)
+	*slope_x = converged ? invErf : ErfInv(b);
 	*slope_y = ErfInv(2.0f * fmaxf(U2, (float)1e-6f) - 1.0f);
 }
 // reference render/material.cc:166-190
