@@ -546,13 +546,16 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 	tn = fmaxf(tn, (nZ_.k - oL_.z) * invL_.z); tf = fminf(tf, (fZ_.k - oL_.z) * invL_.z); \
 	tk = (tf * widenL_ < tn) ? INFINITY : tn; }
 
-// A scene of at most 16 leaves (rl_bvh.cc "the leaf list"), resident in LDS: no tree.  Every lane tests the box of every leaf, four to a
-// record, in lockstep -- the same code on the same records for all 64 rays, so the wave pays for 1 walk, not for the union of 64 -- and
-// keeps what it hit as 16 sortable keys (entry distance with the slot number in the 4 low mantissa bits, i.e. rounded DOWN by at most 15
-// ulp: nearer than the truth, so the cut below only comes later; a negative entry distance, possible with a negative rayTMin, counts as 0).  Then it visits its leaves nearest first and stops at the first one that
-// starts behind the best hit -- the order and the cut of a tree walk; the candidates are the same (every leaf whose box the ray meets:
-// a superset of those a tree walk opens), and with the candidate rule and the tie rule of the triangle test the result does not depend on
-// the order.  Measured on the Cornell frame: see DESIGN.md section 2.
+// A scene of at most 4 * RL_LEAFLIST_RECORDS leaves (rl_bvh.cc "the leaf list"), resident in LDS: no tree.  Every lane tests the box of every
+// leaf, four to a record, in lockstep -- the same code on the same records for all 64 rays, so the wave pays for 1 walk, not for the union
+// of 64 -- and keeps what it hit as sortable keys: the entry distance with the slot number in the 5 low mantissa bits, i.e. rounded DOWN by
+// at most 31 ulp (nearer than the truth, so the cut below only comes later; a negative entry distance, possible with a negative rayTMin,
+// counts as 0).  Then it visits its leaves nearest first and stops at the first one that starts behind the best hit -- the order and the cut
+// of a tree walk.  The candidates are every leaf whose box the ray meets: a superset of those a tree walk opens, and with the candidate rule
+// and the tie rule of the triangle test the result does not depend on which superset is tested in which order.  The cut is safe for the
+// same reason every widened box test here is: an accepted hit has t * RL_CANDIDATE_SLACK >= the entry into its triangle's own box (OwnBoxPass),
+// which lies inside the leaf's box, and RL_BOX_WIDEN exceeds RL_CANDIDATE_SLACK by 1e-6 -- four times the rounding of either side.
+// Measured on the Cornell frame: DESIGN.md section 2.
 template <bool ANYHIT>
 __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d, float tMin, HitRec& best, Counters& c, const float4* sm)
 {
