@@ -550,7 +550,7 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 // leaf, four to a record, in lockstep -- the same code on the same records for all 64 rays, so the wave pays for 1 walk, not for the union
 // of 64 -- and keeps what it hit as sortable keys: the entry distance with the slot number in the 5 low mantissa bits, i.e. rounded DOWN by
 // at most 31 ulp (nearer than the truth, so the cut below only comes later; a negative entry distance, possible with a negative rayTMin,
-// counts as 0).  Then it visits its leaves nearest first and stops at the first one that starts behind the best hit -- the order and the cut
+// counts as 0, and the cut is then not taken at all).  Then it visits its leaves nearest first and stops at the first one that starts behind the best hit -- the order and the cut
 // of a tree walk.  The candidates are every leaf whose box the ray meets: a superset of those a tree walk opens, and with the candidate rule
 // and the tie rule of the triangle test the result does not depend on which superset is tested in which order.  The cut is safe for the
 // same reason every widened box test here is: an accepted hit has t * RL_CANDIDATE_SLACK >= the entry into its triangle's own box (OwnBoxPass),
@@ -607,7 +607,9 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] - from);
 		m += from;
 		if (m == 0xffffffffu) break;
-		if (best.t * RL_BOX_WIDEN < __uint_as_float(m & ~31u)) break;   // the nearest leaf left starts behind the hit (the slab test's own cut: tf * widen < tn)
+		// the nearest leaf left starts behind the hit (the slab test's own cut: tf * widen < tn).  Not with a negative rayTMin: the keys hold
+		// max(entry, 0), and a leaf entered behind the origin may still hold a hit nearer (more negative) than a negative best one
+		if (tMin >= 0.0f && best.t * RL_BOX_WIDEN < __uint_as_float(m & ~31u)) break;
 		from = m + 1u;
 		RL_WSTEP(6);
 		const uint32_t j = m & 31u;

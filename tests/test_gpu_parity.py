@@ -395,18 +395,20 @@ def test_small_scene_walks_agree(name, sessions, gpu_lib, monkeypatch):
     monkeypatch.setenv("RAYLIB_POOL", "0")
     has_list = gpu_lib.RaylibAMD_SceneLeafListInfo(ses.scene, None) > 0
     assert has_list                                         # every fixture scene is that small
-    for mode, spp in ((0, 16), (1, 1), (4, 1)):
-        base = ses.render(64, 64, spp, mode=mode)
+    # rayTMin 0 and a negative one too: hits behind the origin are then legal (t >= rayTMin, triangle.cc:37), and the leaf list orders its leaves by
+    # an entry distance it clamps at 0
+    for mode, spp, tmin in ((0, 16, 1e-4), (1, 1, 1e-4), (4, 1, 1e-4), (0, 4, 0.0), (0, 4, -0.25)):
+        base = ses.render(64, 64, spp, mode=mode, tmin=tmin)
         st0 = ses.stats().as_dict()
         for env in (dict(RAYLIB_LEAF_LIST="0"), dict(RAYLIB_LDS_SCENE="0"), dict(RAYLIB_BVH4="0")):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
-            img = ses.render(64, 64, spp, mode=mode)
+            img = ses.render(64, 64, spp, mode=mode, tmin=tmin)
             st1 = ses.stats().as_dict()
             for k in env:
                 monkeypatch.delenv(k)
-            assert helpers.same(img, base).all(), (name, mode, env)
-            assert st0["rays"] == st1["rays"] and st0["cameraSamples"] == st1["cameraSamples"], (name, mode, env)
+            assert helpers.same(img, base).all(), (name, mode, tmin, env)
+            assert st0["rays"] == st1["rays"] and st0["cameraSamples"] == st1["cameraSamples"], (name, mode, tmin, env)
             if mode == 0 and "RAYLIB_LEAF_LIST" in env:
                 assert st0["nodesVisited"] != st1["nodesVisited"], "the leaf list was not the walk that ran"
 
