@@ -38,6 +38,7 @@ for case in range(cases):
     spp, max_path = int(rng.choice([1, 2, 5, 8])), int(rng.choice([1, 2, 5, 9]))
     aperture = 0.0 if rng.rand() < 0.6 else float(rng.uniform(0.01, 0.2))
     seed_val = int(rng.randint(1, 1 << 30))
+    tmin = float(rng.choice([1e-4, 1e-4, 1e-4, 0.0, 1e-2, -0.05])) if os.environ.get("FUZZ_TMIN") else 1e-4   # FUZZ_TMIN=1: also rayTMin 0, 1e-2 and a negative one
     if only >= 0 and case != only: continue
     obj, n = gen[0](os.path.join(d, "f%d.obj" % case), **gen[1])
     ses = binding.SceneSession(lib, obj, origin, (0, 1, -1), float(rng.uniform(30, 80)), w / h, sun=sun, sun_dir=sun_dir, sky_image=sky,
@@ -46,7 +47,7 @@ for case in range(cases):
     ref = None
     for env in MODES:
         for k, v in env.items(): os.environ[k] = v
-        img = ses.render(w, h, spp, max_path=max_path)
+        img = ses.render(w, h, spp, max_path=max_path, tmin=tmin)
         st = ses.stats().as_dict()
         for k in env: del os.environ[k]
         # cut-out scenes run the alpha test on traversal candidates, whose number depends on the order candidates are met in:
