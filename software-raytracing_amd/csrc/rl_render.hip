@@ -1204,7 +1204,9 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	// with ONE atomic and deals them to its lanes itself.  (A returning atomic on one address
 	// saturates near 88 dequeues/us chip-wide -- MI355X_MICROARCH.md "dequeue" -- and one atomic
 	// per wave and bounce was exactly that rate: the kernel ran at the atomic's speed.)
-	uint32_t chunkNext = 0, chunkEnd = 0;
+	// Every wave's FIRST chunk is its own (wave w: jobs [w, w + 1) x jobChunk) and the counter starts behind those (host side): 4096 waves asking the
+	// one counter at the same instant stand in line for ~45 us, which is 2 % of what one of 8 ranks renders of the Cornell frame
+	uint32_t chunkNext = min((blockIdx.x * (RL_BLOCK / 64u) + (threadIdx.x >> 6)) * P.jobChunk, P.numJobs), chunkEnd = min(chunkNext + P.jobChunk, P.numJobs);
 	bool globalDone = false;
 	uint32_t qCount = 0;   // LDS == 2: camera rays waiting in the wave's queue
 	RL_TIMELINE(0);
@@ -1771,7 +1773,9 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 	bool stActive[K];
 	#pragma unroll
 	for (int p = 0; p < K; ++p) { stRng[p] = 0; stOut[p] = 0; stDepth[p] = 0; stActive[p] = false; pool[F_TRI][p * 64 + lane] = __int_as_float(Q_EMPTY); }
-	uint32_t chunkNext = 0, chunkEnd = 0;
+	// Every wave's FIRST chunk is its own (wave w: jobs [w, w + 1) x jobChunk) and the counter starts behind those (host side): 4096 waves asking the
+	// one counter at the same instant stand in line for ~45 us, which is 2 % of what one of 8 ranks renders of the Cornell frame
+	uint32_t chunkNext = min((blockIdx.x * (RL_BLOCK / 64u) + (threadIdx.x >> 6)) * P.jobChunk, P.numJobs), chunkEnd = min(chunkNext + P.jobChunk, P.numJobs);
 	bool globalDone = false, exhausted = false;   // wave-uniform
 	uint32_t surviveQ8 = 256u;                    // share of freshly generated camera samples that reached a pool slot, x 256 (wave-uniform)
 	// traversal state of the ray this lane is tracing; survives trips (a straggler keeps going while the rest of the pool is shaded)

@@ -558,7 +558,10 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				P.jobChunk = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, chunk));
 			}
 			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
-			HIP_OK(hipMemsetAsync(R.jobCounter, 0, sizeof(unsigned int), R.stream));
+			{   // the counter starts behind the waves' own first chunks (rl_render.hip: chunkNext at kernel start)
+				const uint64_t first = (uint64_t)blocks * (RL_BLOCK / 64) * P.jobChunk;
+				HIP_OK(hipMemsetD32Async((hipDeviceptr_t)R.jobCounter, (int)(uint32_t)std::min<uint64_t>(first, 0xFFFFFF00ull), 1, R.stream));
+			}
 			HIP_OK(hipEventRecord(R.ev[2], R.stream));
 			hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
 			                   P, traceView, DS->skyRot, R.samples, R.pathStack, R.counters, R.jobCounter);
