@@ -1162,6 +1162,9 @@ __device__ __forceinline__ void WaveLdsSync()
 // ---------------------------------------------------------------------------
 // The megakernel.  samples: [sampleCount][numLocalCells*64] float4.
 // pathStack: [maxPathLength][stackStride] records of 2 float4 (refl.xyz, sp | pdf, E.xyz).
+#ifndef RL_QUEUE_SHARED_CHUNK
+#define RL_QUEUE_SHARED_CHUNK 1   /* leaf-list kernel: the workgroup's waves share one job chunk (see the refill) */
+#endif
 #ifndef RL_TRACE_MIN_WAVES
 #define RL_TRACE_MIN_WAVES 4   /* 4 waves per SIMD = 4 workgroups per CU: caps the kernel at 128 VGPRs */
 #endif
@@ -1178,6 +1181,16 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	__shared__ int s_stack[STACK * RL_BLOCK];
 	__shared__ float4 s_scene[LDS ? RL_LDS_TOTAL : 1];
 	const float4* sm = s_scene;
+#if RL_QUEUE_SHARED_CHUNK
+	// LDS == 2: the workgroup's four waves draw their batches of 64 jobs from ONE chunk (low word: next job, high word: end of the chunk)
+	__shared__ unsigned long long s_jobs;
+	__shared__ unsigned int s_lock, s_done;
+	if (LDS == 2 && threadIdx.x == 0) {
+		const uint32_t first = min(blockIdx.x * P.jobChunk, P.numJobs);
+		s_jobs = (unsigned long long)first | ((unsigned long long)min(first + P.jobChunk, P.numJobs) << 32);
+		s_lock = 0u; s_done = 0u;
+	}
+#endif
 	if (LDS) {
 		const uint32_t nN = (uint32_t)(LDS == 2 ? S.numLeafRecords : S.numNodes4) * 8u, nT = (uint32_t)S.numTriangles * 4u, nM = (uint32_t)S.numMaterials * 5u;
 		for (uint32_t i = threadIdx.x; i < 4u; i += RL_BLOCK) s_scene[RL_LDS_ROOT + i] = ((const float4*)S.nodes)[i];
@@ -1207,6 +1220,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 	// Every wave's FIRST chunk is its own (wave w: jobs [w, w + 1) x jobChunk) and the counter starts behind those (host side): 4096 waves asking the
 	// one counter at the same instant stand in line for ~45 us, which is 2 % of what one of 8 ranks renders of the Cornell frame
 	uint32_t chunkNext = min((blockIdx.x * (RL_BLOCK / 64u) + (threadIdx.x >> 6)) * P.jobChunk, P.numJobs), chunkEnd = min(chunkNext + P.jobChunk, P.numJobs);
+	if (LDS == 2 && RL_QUEUE_SHARED_CHUNK) chunkNext = chunkEnd = 0;   // there the first chunk is the workgroup's (s_jobs)
 	bool globalDone = false;
 	uint32_t qCount = 0;   // LDS == 2: camera rays waiting in the wave's queue
 	RL_TIMELINE(0);
@@ -1247,6 +1261,41 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 			const unsigned long long needMask = __ballot(need);
 			const uint32_t n = (uint32_t)__popcll(needMask);
 			while (n > 0 && qCount < n && qCount <= QCAP - 64 && !(globalDone && chunkNext >= chunkEnd)) {
+#if RL_QUEUE_SHARED_CHUNK
+				// The next batch of the workgroup's chunk: one LDS atomic.  The chunk is the granule of the GLOBAL job list (one global atomic per
+				// P.jobChunk jobs, as before), the batch the granule of a wave's work: when the list runs dry a wave has at most its batch in
+				// front of it, not a chunk -- the launch's tail shrinks from "one chunk per wave" to "a quarter of one".
+				// Whoever finds the chunk used up takes the lock, asks the global counter and publishes the new chunk; the others wait for it.
+				for (;;) {
+					unsigned long long st = 0ull;
+					if (lane == 0) st = atomicAdd(&s_jobs, 64ull);
+					st = __shfl(st, 0);
+					const uint32_t nx = (uint32_t)st, en = (uint32_t)(st >> 32);
+					if (nx < en) { chunkNext = nx; chunkEnd = min(nx + 64u, en); break; }
+					if (__atomic_load_n(&s_done, __ATOMIC_RELAXED) != 0u) { globalDone = true; chunkNext = chunkEnd = 0; break; }
+					uint32_t won = 0;
+					if (lane == 0) won = atomicCAS(&s_lock, 0u, 1u) == 0u ? 1u : 0u;
+					won = __shfl(won, 0);
+					if (won) {
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+						const unsigned long long cur = __atomic_load_n(&s_jobs, __ATOMIC_RELAXED);
+						if ((uint32_t)cur >= (uint32_t)(cur >> 32) && __atomic_load_n(&s_done, __ATOMIC_RELAXED) == 0u) {   // still used up: nobody refilled it in between
+							uint32_t base = 0;
+							if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
+							base = __shfl(base, 0);
+							if (lane == 0) {
+								if (base >= P.numJobs) __atomic_store_n(&s_done, 1u, __ATOMIC_RELAXED);
+								else __atomic_store_n(&s_jobs, (unsigned long long)base | ((unsigned long long)min(base + P.jobChunk, P.numJobs) << 32), __ATOMIC_RELAXED);
+							}
+						}
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						if (lane == 0) __atomic_store_n(&s_lock, 0u, __ATOMIC_RELAXED);
+					} else {
+						while (__atomic_load_n(&s_lock, __ATOMIC_RELAXED) != 0u) __builtin_amdgcn_s_sleep(2);
+					}
+				}
+				if (globalDone) { RL_TIMELINE(1); break; }
+#else
 				if (chunkNext >= chunkEnd) {
 					uint32_t base = 0;
 					if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
@@ -1254,6 +1303,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 					if (base >= P.numJobs) { globalDone = true; RL_TIMELINE(1); break; }
 					chunkNext = base; chunkEnd = min(base + P.jobChunk, P.numJobs);
 				}
+#endif
 				const uint32_t avail = chunkEnd - chunkNext;
 				bool survive = false;
 				V3 qo = v3s(0.0f), qd = v3s(0.0f); Rng qg; qg.s.state = 0; uint32_t qOut = 0;

@@ -556,10 +556,18 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				uint64_t chunk = ((jobs64 / (waves * 16)) + 32) & ~63ull;
 				if (const char* e = getenv("RAYLIB_JOB_CHUNK")) chunk = (uint64_t)atoi(e);
 				P.jobChunk = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, chunk));
+				// the leaf-list kernel's chunk belongs to a workgroup, whose four waves draw batches of 64 from it (RL_QUEUE_SHARED_CHUNK): four waves' worth,
+				// RAYLIB_JOB_CHUNK_MAX (default 1024) at most
+				if (RL_QUEUE_SHARED_CHUNK && traceKernel == (TraceKernel)k_trace<16, false, true, 2> && !getenv("RAYLIB_JOB_CHUNK")) {
+					uint64_t cap = 1024; if (const char* e = getenv("RAYLIB_JOB_CHUNK_MAX")) cap = (uint64_t)std::max(64, atoi(e));
+					P.jobChunk = (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(256, 4 * chunk));
+				}
 			}
 			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
 			{   // the counter starts behind the waves' own first chunks (rl_render.hip: chunkNext at kernel start)
-				const uint64_t first = (uint64_t)blocks * (RL_BLOCK / 64) * P.jobChunk;
+				// (the leaf-list kernel's first chunks are per workgroup: its waves share one, RL_QUEUE_SHARED_CHUNK)
+				const bool perBlock = RL_QUEUE_SHARED_CHUNK && traceKernel == (TraceKernel)k_trace<16, false, true, 2>;
+				const uint64_t first = (uint64_t)blocks * (perBlock ? 1 : RL_BLOCK / 64) * P.jobChunk;
 				HIP_OK(hipMemsetD32Async((hipDeviceptr_t)R.jobCounter, (int)(uint32_t)std::min<uint64_t>(first, 0xFFFFFF00ull), 1, R.stream));
 			}
 			HIP_OK(hipEventRecord(R.ev[2], R.stream));
