@@ -1129,6 +1129,10 @@ __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V
 	return missResult;
 }
 
+// one path's radiance in the sample buffer: 12 bytes (the buffer is written once and read once per sample: a fourth float would be a quarter more of both)
+struct SampleRGB { float x, y, z; };
+__device__ __forceinline__ SampleRGB make_sample(float x, float y, float z) { SampleRGB s; s.x = x; s.y = y; s.z = z; return s; }
+
 // job -> (local cell, sample, pixel in cell) -> image coordinates
 struct JobPixel { uint32_t x, y, slot, sample; bool valid; };
 __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t job)
@@ -1160,7 +1164,7 @@ __device__ __forceinline__ void WaveLdsSync()
 }
 
 // ---------------------------------------------------------------------------
-// The megakernel.  samples: [sampleCount][numLocalCells*64] float4.
+// The megakernel.  samples: [sampleCount][numLocalCells*64] SampleRGB.
 // pathStack: [maxPathLength][stackStride] records of 2 float4 (refl.xyz, sp | pdf, E.xyz).
 #ifndef RL_QUEUE_SHARED_CHUNK
 #define RL_QUEUE_SHARED_CHUNK 1   /* leaf-list kernel: the workgroup's waves share one job chunk (see the refill) */
@@ -1174,7 +1178,7 @@ __device__ __forceinline__ void WaveLdsSync()
 //     LDS == 2: a scene of <= 16 leaves, walked through its leaf list (TraverseLeafList) instead of its tree
 template <int STACK, bool PRIMS, bool FULL, int LDS = 0>
 __global__ void __launch_bounds__(RL_BLOCK, (STACK <= 32 ? RL_TRACE_MIN_WAVES : 2))
-k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
+k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __restrict__ samples,
         float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
 	RL_MATH_PROLOGUE();
@@ -1332,7 +1336,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 								DSceneView Sq = S; Sq.hasSun = 0;
 								V3 L = MissShader<STACK, PRIMS, FULL, LDS>(Sq, R, qo, qd, qTime, P.rayTMin, stk, c, sm);
 								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
-								samples[qOut] = make_float4(L.x, L.y, L.z, 1.0f);
+								samples[qOut] = make_sample(L.x, L.y, L.z);
 								survive = false;
 							}
 						}
@@ -1410,7 +1414,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 								DSceneView Sq = S; Sq.hasSun = 0;
 								V3 L = MissShader<STACK, PRIMS, FULL, LDS>(Sq, R, o, d, rayTime, P.rayTMin, stk, c, sm);
 								if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
-								samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+								samples[outIndex] = make_sample(L.x, L.y, L.z);
 								active = false;
 							}
 						}
@@ -1527,7 +1531,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __res
 					radiance = radiance + E;
 					L = radiance;
 				}
-				samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+				samples[outIndex] = make_sample(L.x, L.y, L.z);
 				active = false;
 				RL_LANESTAMP(3, true);
 			}
@@ -1795,7 +1799,7 @@ template <int LSTACK, bool PRIMS, int K> struct PoolOcc {
 // WIDE: traverse the BVH4 (S.nodes4) instead of the BVH2
 template <int STACK, bool PRIMS, int K, int LSTACK = STACK, bool WIDE = false>
 __global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<LSTACK, PRIMS, K>::kBlocks))
-k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* __restrict__ samples,
+k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __restrict__ samples,
              float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
 {
 	RL_MATH_PROLOGUE();
@@ -1949,12 +1953,12 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 				}
 				if (lane < commit && (alive || quick)) c.samples++;
 				if (quick) {
-					if (P.maxPathLength <= 0) samples[outIndex] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+					if (P.maxPathLength <= 0) samples[outIndex] = make_sample(0.0f, 0.0f, 0.0f);
 					else {
 						c.rays++; c.nodes++;
 						V3 L = MissSky(S, R, d, c);
 						if (S.hasSun) { c.rays++; c.nodes++; L = L + ld3(S.sunIlluminance); }
-						samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+						samples[outIndex] = make_sample(L.x, L.y, L.z);
 					}
 				}
 				chunkNext += commit;
@@ -2090,7 +2094,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 				}
 				if (done) {
 					L = FoldPath(pathStack, P.stackStride, homeBase + (uint32_t)p * RL_BLOCK, stDepth[p], L);
-					samples[stOut[p]] = make_float4(L.x, L.y, L.z, 1.0f);
+					samples[stOut[p]] = make_sample(L.x, L.y, L.z);
 					stActive[p] = false;
 					pool[F_TRI][slot] = __int_as_float(Q_EMPTY);
 				}
@@ -2155,7 +2159,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 				}
 				if (done) {
 					L = FoldPath(pathStack, P.stackStride, home, depth, L);
-					samples[outIndex] = make_float4(L.x, L.y, L.z, 1.0f);
+					samples[outIndex] = make_sample(L.x, L.y, L.z);
 					pool[F_TRI][slot] = __int_as_float(Q_EMPTY);
 				}
 				// back to the home lane: RNG state and depth (negative = the path has ended)
@@ -2193,7 +2197,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, float4* 
 // Sequential per-pixel sum of this batch's samples, then (last batch) the mean.
 // reference render/renderer.cc:244-248 + core/vec3.h:214-220 (operator/= multiplies by 1/SPP)
 __global__ void __launch_bounds__(RL_BLOCK)
-k_resolve(const DRenderParams P, const float4* __restrict__ samples, float4* __restrict__ accum, float4* __restrict__ out, int firstBatch, int lastBatch)
+k_resolve(const DRenderParams P, const SampleRGB* __restrict__ samples, float4* __restrict__ accum, float4* __restrict__ out, int firstBatch, int lastBatch)
 {
 	const uint32_t numSlots = P.numLocalCells * 64u;
 	const uint32_t slot = blockIdx.x * RL_BLOCK + threadIdx.x;
@@ -2206,7 +2210,7 @@ k_resolve(const DRenderParams P, const float4* __restrict__ samples, float4* __r
 	if (valid) {
 		if (!firstBatch) a = accum[slot];
 		for (uint32_t s = 0; s < P.sampleCount; ++s) {
-			const float4 v = samples[(size_t)s * numSlots + slot];
+			const SampleRGB v = samples[(size_t)s * numSlots + slot];
 			a.x += v.x; a.y += v.y; a.z += v.z;
 		}
 		if (lastBatch) {

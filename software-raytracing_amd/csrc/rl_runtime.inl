@@ -82,7 +82,7 @@ struct RankCtx {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // 0/1 render, 2/3 megakernel, 4 "my cells are on rank 0's device"
 	// reusable work buffers
-	float4* samples = nullptr; size_t samplesBytes = 0;
+	SampleRGB* samples = nullptr; size_t samplesBytes = 0;
 	float4* accum = nullptr; size_t accumBytes = 0;
 	float4* image = nullptr; size_t imageBytes = 0;
 	float* pathStack = nullptr; size_t pathStackBytes = 0;
@@ -400,7 +400,7 @@ bool SyncSky(Scene& sc)
 	return true;
 }
 
-typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot, float4*, float*, unsigned long long*, unsigned int*);
+typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot, SampleRGB*, float*, unsigned long long*, unsigned int*);
 
 // poolK = 0: k_trace (one path per lane); poolK = K: k_trace_pool with 64*K paths per wave
 template <int STACK, bool PRIMS>
@@ -484,13 +484,13 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 	} else {
 		// sample batches: one launch per <= 16 GiB of sample buffer (288 GB of HBM: few, large launches -- every launch pays its
 		// ramp-up and its tail once; measured on the 298 k-triangle scene at 128 spp: 1 launch 61.3 ms, 2 launches 68.9, 4 launches 90.1)
-		const size_t perSample = (size_t)numSlots * sizeof(float4);
+		const size_t perSample = (size_t)numSlots * sizeof(SampleRGB);
 		size_t capBytes = (size_t)16 << 30;
 		if (const char* e = getenv("RAYLIB_SAMPLE_BUFFER_GIB")) { const int v = atoi(e); if (v > 0) capBytes = (size_t)v << 30; }
 		uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(SPP, capBytes / perSample));
 		if (const char* e = getenv("RAYLIB_SAMPLE_BATCH")) { int v = atoi(e); if (v > 0) batch = std::min<uint32_t>((uint32_t)v, SPP); }
 		if (!Grow(R.samples, R.samplesBytes, perSample * batch)) return false;
-		if (batch < SPP && !Grow(R.accum, R.accumBytes, perSample)) return false;
+		if (batch < SPP && !Grow(R.accum, R.accumBytes, (size_t)numSlots * sizeof(float4))) return false;
 		// Scheduling of the megakernel: the pool schedule for triangle scenes from RAYLIB_POOL_MIN_TRIS triangles on, else k_trace
 		// (the Cornell class: tens of triangles, shading-bound).  Measured crossover (tools/gpu_crossover.py, tessellated rooms at
 		// 1080p x 16 spp, pool time / k_trace time): 36 triangles 1.07, 144: 0.97, 324: 0.95, 1296: 0.89, 5184: 0.80, 20736: 0.67.
