@@ -479,7 +479,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		// SAH tree: starting from the root, the sub-tree with the largest area x triangle count is opened until the list is full or only the tree's own leaves are left.
 		// Up to 4.5 triangles per leaf on average: beyond, the leaves of the cut grow towards 8 triangles and the tree wins again (tools/gpu_leaflist.py,
 		// leaf list / BVH4 walk: 36 triangles 0.86, 72: 0.92, 84: 0.88, 96: 0.89, 108: 0.90, 120: 1.05).
-		if (n <= kLeafListMax * 9 / 2) {
+		if (n <= RL_LEAFLIST_MAXTRIS) {
 			std::vector<uint32_t> triFirst(T.size(), 0), triCount(T.size(), 0);
 			for (size_t t = T.size(); t-- > 0;) {   // children follow their parent in T (pre-order): a reverse sweep sees them first
 				if (T[t].left < 0) { triFirst[t] = ((uint32_t)~leafCode[t]) >> 6; triCount[t] = T[t].count; }

@@ -120,6 +120,8 @@ struct DCamera {
 #ifndef RL_LEAFLIST_RECORDS
 #define RL_LEAFLIST_RECORDS 6
 #endif
+// ... and at most this many triangles: 4.5 per leaf on average -- beyond, the leaves grow towards 8 triangles and the tree wins again (tools/gpu_leaflist.py)
+#define RL_LEAFLIST_MAXTRIS (RL_LEAFLIST_RECORDS * 18)
 
 struct DSceneView {
 	const DNode* nodes;

@@ -221,6 +221,19 @@ __device__ __forceinline__ Mat LoadMat(const DSceneView& S, int i)
 #define RL_LDS_MAXMATS 32
 #endif
 #define RL_LDS_TOTAL  (RL_LDS_MATS + RL_LDS_MAXMATS * 5)
+// The leaf-list kernel (LDS == 2) has its own layout: six records of leaf boxes instead of a tree, at most 108 triangles, and an intersection
+// record of SIX float4 that holds what the triangle test would otherwise recompute per test -- the edges u = v1 - v0, v = v2 - v0 (triangle.cc:30-31)
+// and the triangle's own box (the candidate rule's) -- computed once per workgroup when the scene is copied in, with the same operations.
+template <int LDS> struct LdsAt {
+	static constexpr int NODES = RL_LDS_NODES;
+	static constexpr int MAXNODES = LDS == 2 ? RL_LEAFLIST_RECORDS : RL_LDS_MAXNODES;
+	static constexpr int TRI = LDS == 2 ? 6 : RL_LDS_TSTRIDE;                 // float4 per intersection record
+	static constexpr int MAXTRIS = LDS == 2 ? RL_LEAFLIST_MAXTRIS : RL_LDS_MAXTRIS;
+	static constexpr int ISECT = NODES + MAXNODES * RL_LDS_NSTRIDE;
+	static constexpr int SHADE = ISECT + MAXTRIS * TRI;
+	static constexpr int MATS = SHADE + MAXTRIS * RL_LDS_TSTRIDE;
+	static constexpr int TOTAL = MATS + RL_LDS_MAXMATS * 5;
+};
 
 __device__ __forceinline__ Mat MatFrom(const float4* p)
 {
@@ -299,10 +312,21 @@ __device__ __forceinline__ bool AlphaTestCandidate(const DSceneView& S, int tri,
 // same hit, and since every box of the reference's tree contains this AABB (and rounding is monotone) the reference accepts
 // whatever is accepted here.  (What it accepts beyond that -- a hit outside the triangle's own box but inside its random
 // parent's -- is tree-dependent on its side; the oracle counts those events so that tests can tell them from real mismatches.)
+__device__ __forceinline__ bool OwnBoxPassBox(V3 mn, V3 mx, V3 o, V3 inv /* exact 1/d */, float tMin, float t);
 __device__ __forceinline__ bool OwnBoxPass(V3 a, V3 b, V3 c, V3 o, V3 inv /* exact 1/d */, float tMin, float t)
 {
 	const V3 mn = v3(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
 	const V3 mx = v3(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
+	return OwnBoxPassBox(mn, mx, o, inv, tMin, t);
+}
+// the same with the box in hand (the leaf-list kernel's six-float4 triangle record keeps it in float4 4 and 5)
+__device__ __forceinline__ bool OwnBoxPassMnMx(const float4* rec, V3 o, V3 inv, float tMin, float t)
+{
+	const float4 q4 = rec[4], q5 = rec[5];
+	return OwnBoxPassBox(v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), o, inv, tMin, t);
+}
+__device__ __forceinline__ bool OwnBoxPassBox(V3 mn, V3 mx, V3 o, V3 inv /* exact 1/d */, float tMin, float t)
+{
 	float lo = tMin, hi = FLT_MAX;
 	{ float t0 = (mn.x - o.x) * inv.x, t1 = (mx.x - o.x) * inv.x; if (inv.x < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = t0 > lo ? t0 : lo; hi = t1 < hi ? t1 : hi; }
 	bool ok = !(hi < lo);
@@ -574,7 +598,7 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 	const V3 cc = v3(-(o.x * invb.x), -(o.y * invb.y), -(o.z * invb.z));
 	const V3 ce = v3(fabsf(cc.x) * 2.3841858e-7f, fabsf(cc.y) * 2.3841858e-7f, fabsf(cc.z) * 2.3841858e-7f);
 	const V3 cn = cc - ce, cf = cc + ce;
-	const char* recs = (const char*)(sm + RL_LDS_NODES);
+	const char* recs = (const char*)(sm + LdsAt<2>::NODES);
 	const uint32_t oNX = nx ? 48u : 0u, oFX = 48u - oNX, oNY = ny ? 64u : 16u, oFY = 80u - oNY, oNZ = nz ? 80u : 32u, oFZ = 112u - oNZ;
 	#pragma unroll
 	for (int g = 0; g < RL_LEAFLIST_RECORDS; ++g) {
@@ -613,13 +637,17 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 		from = m + 1u;
 		RL_WSTEP(6);
 		const uint32_t j = m & 31u;
-		const int ref = ((const int*)(sm + RL_LDS_NODES + (j >> 2) * RL_LDS_NSTRIDE + 6))[j & 3u];
+		const int ref = ((const int*)(sm + LdsAt<2>::NODES + (j >> 2) * RL_LDS_NSTRIDE + 6))[j & 3u];
 		const uint32_t code = (uint32_t)~ref;
 		const int first = (int)(code >> 6);
 		const int count = (int)(code & 7u) + 1;
 		const bool alpha = (code & 8u) != 0;
 		for (int i = 0; i < count; ++i) {
-			const Tri T = TriFrom(sm + RL_LDS_ISECT + (first + i) * RL_LDS_TSTRIDE);
+			const float4* tr = sm + LdsAt<2>::ISECT + (first + i) * 6;
+			const float4 q0 = tr[0], q1 = tr[1], q2 = tr[2], q3 = tr[3];
+			struct { V3 v0, n, u, v; float uv, uu, vv, denom; } T;
+			T.v0 = v3(q0.x, q0.y, q0.z); T.n = v3(q0.w, q1.x, q1.y); T.u = v3(q1.z, q1.w, q2.x); T.v = v3(q2.y, q2.z, q2.w);
+			T.uv = q3.x; T.uu = q3.y; T.vv = q3.z; T.denom = q3.w;
 			c.tris++;
 			RL_WSTEP(5);
 			const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
@@ -629,7 +657,7 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const float wv = dot(w, T.v), wu = dot(w, T.u);
 			const float pa = (T.uv * wv - T.vv * wu) / T.denom;
 			const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tMin, t)) {
+			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPassMnMx(tr, o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tMin, t)) {
 				if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 				best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 				if (ANYHIT) return true;
@@ -720,7 +748,7 @@ __device__ __forceinline__ int BuildSurface(const DSceneView& S, V3 o, V3 d, con
 	s.p = o + h.t * d;
 	const uint32_t kind = PRIMS ? (((uint32_t)h.tri) >> 28) : 0u;
 	if (kind == 0u) {
-		const Shade sh = LDS ? ShadeFrom(sm + RL_LDS_SHADE + h.tri * RL_LDS_TSTRIDE) : LoadShade(S, h.tri);
+		const Shade sh = LDS ? ShadeFrom(sm + LdsAt<LDS>::SHADE + h.tri * RL_LDS_TSTRIDE) : LoadShade(S, h.tri);
 		c.shaded++;
 		const float a = h.a, b = h.b;
 		s.n = normalize((1 - a - b) * sh.n0 + a * sh.n1 + b * sh.n2);
@@ -1189,7 +1217,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 {
 	RL_MATH_PROLOGUE();
 	__shared__ int s_stack[STACK * RL_BLOCK];
-	__shared__ float4 s_scene[LDS ? RL_LDS_TOTAL : 1];
+	__shared__ float4 s_scene[LDS ? LdsAt<LDS>::TOTAL : 1];
 	const float4* sm = s_scene;
 #if RL_QUEUE_SHARED_CHUNK
 	// LDS == 2: the workgroup's four waves draw their batches of 64 jobs from ONE chunk (low word: next job, high word: end of the chunk)
@@ -1205,8 +1233,20 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 		const uint32_t nN = (uint32_t)(LDS == 2 ? S.numLeafRecords : S.numNodes4) * 8u, nT = (uint32_t)S.numTriangles * 4u, nM = (uint32_t)S.numMaterials * 5u;
 		for (uint32_t i = threadIdx.x; i < 4u; i += RL_BLOCK) s_scene[RL_LDS_ROOT + i] = ((const float4*)S.nodes)[i];
 		for (uint32_t i = threadIdx.x; i < nN; i += RL_BLOCK) s_scene[RL_LDS_NODES + (i >> 3) * RL_LDS_NSTRIDE + (i & 7u)] = ((const float4*)(LDS == 2 ? S.leafList : S.nodes4f))[i];
-		for (uint32_t i = threadIdx.x; i < nT; i += RL_BLOCK) { const uint32_t at = (i >> 2) * RL_LDS_TSTRIDE + (i & 3u); s_scene[RL_LDS_ISECT + at] = ((const float4*)S.isect)[i]; s_scene[RL_LDS_SHADE + at] = ((const float4*)S.shade)[i]; }
-		for (uint32_t i = threadIdx.x; i < nM; i += RL_BLOCK) s_scene[RL_LDS_MATS + i] = ((const float4*)S.materials)[i];
+		if (LDS == 2) {
+			for (uint32_t i = threadIdx.x; i < nT; i += RL_BLOCK) s_scene[LdsAt<LDS>::SHADE + i] = ((const float4*)S.shade)[i];
+			for (uint32_t t = threadIdx.x; t < (uint32_t)S.numTriangles; t += RL_BLOCK) {   // the six-float4 record (LdsAt): edges and own box worked out here, once
+				const Tri T = LoadTri(S, (int)t);
+				const V3 mn = v3(fminf(fminf(T.v0.x, T.v1.x), T.v2.x), fminf(fminf(T.v0.y, T.v1.y), T.v2.y), fminf(fminf(T.v0.z, T.v1.z), T.v2.z));
+				const V3 mx = v3(fmaxf(fmaxf(T.v0.x, T.v1.x), T.v2.x), fmaxf(fmaxf(T.v0.y, T.v1.y), T.v2.y), fmaxf(fmaxf(T.v0.z, T.v1.z), T.v2.z));
+				float4* r = s_scene + LdsAt<LDS>::ISECT + t * 6u;
+				r[0] = make_float4(T.v0.x, T.v0.y, T.v0.z, T.n.x); r[1] = make_float4(T.n.y, T.n.z, T.u.x, T.u.y); r[2] = make_float4(T.u.z, T.v.x, T.v.y, T.v.z);
+				r[3] = make_float4(T.uv, T.uu, T.vv, T.denom); r[4] = make_float4(mn.x, mn.y, mn.z, mx.x); r[5] = make_float4(mx.y, mx.z, 0.0f, 0.0f);
+			}
+		} else {
+			for (uint32_t i = threadIdx.x; i < nT; i += RL_BLOCK) { const uint32_t at = (i >> 2) * RL_LDS_TSTRIDE + (i & 3u); s_scene[LdsAt<LDS>::ISECT + at] = ((const float4*)S.isect)[i]; s_scene[LdsAt<LDS>::SHADE + at] = ((const float4*)S.shade)[i]; }
+		}
+		for (uint32_t i = threadIdx.x; i < nM; i += RL_BLOCK) s_scene[LdsAt<LDS>::MATS + i] = ((const float4*)S.materials)[i];
 		__syncthreads();
 	}
 	int* stk = s_stack + threadIdx.x;
@@ -1477,7 +1517,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 				subLast = __builtin_amdgcn_s_memtime();
 #endif
 				const int mi = BuildSurface<PRIMS, LDS>(S, o, d, h, s, true, c, sm);
-				const Mat m = LDS ? MatFrom(sm + RL_LDS_MATS + mi * 5) : LoadMat(S, mi);
+				const Mat m = LDS ? MatFrom(sm + LdsAt<LDS>::MATS + mi * 5) : LoadMat(S, mi);
 				RL_SUBSTAMP(0);
 				V3 refl = v3s(0.0f), outD = v3s(0.0f);
 				float pdf = 0.0f, sp = 0.0f;
