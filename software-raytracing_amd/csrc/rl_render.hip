@@ -1863,6 +1863,9 @@ template <int STACK, bool PRIMS, int K, int LSTACK = STACK, bool WIDE = false>
 __global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<LSTACK, PRIMS, K>::kBlocks))
 k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __restrict__ samples,
              float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
+#ifndef RL_TU_POOL
+;   // defined in the translation unit of rl_render_pool.hip: this same source, compiled with a scheduler strategy of its own (Makefile); instances below
+#else
 {
 	RL_MATH_PROLOGUE();
 	constexpr int PP = 64 * K;
@@ -2255,7 +2258,21 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 		if (lane == 0 && v) atomicAdd(&counters[k], v);
 	}
 }
+#endif
+// The instances the runtime selects from (rl_runtime.inl SelectTraceKernel): defined in rl_render_pool.hip's translation unit, referenced from this one.
+#define RL_POOL_INSTANCES(X) \
+	X(16, false, 2, 16, false) X(16, false, 3, 16, false) X(16, false, 4, 16, false) X(32, false, 2, 32, false) X(32, false, 3, 32, false) X(32, false, 4, 32, false) \
+	X(32, false, 2, 4, false) X(32, false, 2, RL_POOL_SHORT_LSTACK, false) \
+	X(32, false, 2, 32, true) X(64, false, 2, 32, true) X(32, false, 2, RL_POOL_SHORT_LSTACK, true) X(64, false, 2, RL_POOL_SHORT_LSTACK, true)
+#ifdef RL_TU_POOL
+#define RL_POOL_X(a, b, c, d, e) template __global__ void k_trace_pool<a, b, c, d, e>(const DRenderParams, const DSceneView, const SkyRot, SampleRGB* __restrict__, float* __restrict__, unsigned long long* __restrict__, unsigned int* __restrict__);
+#else
+#define RL_POOL_X(a, b, c, d, e) extern template __global__ void k_trace_pool<a, b, c, d, e>(const DRenderParams, const DSceneView, const SkyRot, SampleRGB* __restrict__, float* __restrict__, unsigned long long* __restrict__, unsigned int* __restrict__);
+#endif
+RL_POOL_INSTANCES(RL_POOL_X)
+#undef RL_POOL_X
 
+#ifndef RL_TU_POOL   // everything below belongs to the main translation unit alone
 // Sequential per-pixel sum of this batch's samples, then (last batch) the mean.
 // reference render/renderer.cc:244-248 + core/vec3.h:214-220 (operator/= multiplies by 1/SPP)
 __global__ void __launch_bounds__(RL_BLOCK)
@@ -2530,6 +2547,10 @@ k_scatter_cells(const float4* __restrict__ gather, float4* __restrict__ out, uin
 	out[i] = gather[plan.offset[rank] + local * 64u + ((y & 7u) << 3) + (x & 7u)];
 }
 
+#endif   // RL_TU_POOL
+
 } // namespace rl
 
+#ifndef RL_TU_POOL
 #include "rl_runtime.inl"
+#endif
