@@ -623,14 +623,22 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 	uint32_t from = 0u;   // keys below this one are done (keys are distinct: the slot is part of the key)
 	// (One triangle per turn of ONE loop -- a lane picks its next leaf while its neighbours test their next triangle -- was measured too: 9.8
 	// triangle steps per wave and bounce instead of 12 on 16 leaves, but 19.81 ms against 19.42: the pick costs more per turn than it saves.)
+#ifdef RL_WATCHDOG
+	int guardSel = 0;
+#endif
 	for (;;) {
-		// the smallest key >= from, as the smallest (key - from) in unsigned arithmetic: a key below `from` wraps around to more than
-		// 0xffffffff - from, which is where the unused keys (0xffffffff) land
+#ifdef RL_WATCHDOG
+		if (++guardSel > 200) { printf("leaf-list pick stuck: lane %u from %u tMin %g best %g keys %u %u %u %u\n", threadIdx.x, from, tMin, best.t, key[0], key[1], key[2], key[3]); break; }
+#endif
+		// the smallest key >= from, as the smallest (key - from) in unsigned arithmetic: an unused key (0xffffffff) lands on 0xffffffff - from and
+		// a key below `from` (a leaf already visited) wraps around to more than that -- so "nothing left" is "the smallest is not below
+		// 0xffffffff - from".  (Comparing the re-based minimum with 0xffffffff instead is wrong exactly when all 24 slots are candidates and
+		// all have been visited: the minimum is then a wrapped one, never equals 0xffffffff, and the loop does not end.  tools/gpu_fuzz.py found it.)
 		uint32_t m = 0xffffffffu;
 		#pragma unroll
 		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] - from);
+		if (m >= 0xffffffffu - from) break;
 		m += from;
-		if (m == 0xffffffffu) break;
 		// the nearest leaf left starts behind the hit (the slab test's own cut: tf * widen < tn).  Not with a negative rayTMin: the keys hold
 		// max(entry, 0), and a leaf entered behind the origin may still hold a hit nearer (more negative) than a negative best one
 		if (tMin >= 0.0f && best.t * RL_BOX_WIDEN < __uint_as_float(m & ~31u)) break;
@@ -1293,7 +1301,13 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 	#define RL_LANEBEGIN()
 #endif
 
+#ifdef RL_WATCHDOG
+	unsigned guardMain = 0;
+#endif
 	for (;;) {
+#ifdef RL_WATCHDOG
+		if (++guardMain > 200000u) { if (lane == 0) printf("k_trace main loop stuck: block %u wave %u active %llx exhausted %llx qCount %u globalDone %d chunk %u %u depth %d\n", blockIdx.x, threadIdx.x >> 6, (unsigned long long)__ballot(active), (unsigned long long)__ballot(exhausted), qCount, (int)globalDone, chunkNext, chunkEnd, depth); break; }
+#endif
 		// ---- refill idle lanes: wave64 ballot + prefix rank ----
 		// Up to RL_REFILL_ROUNDS rounds: a fresh camera ray that misses both boxes of the root node can
 		// only run the (sun-less) miss shader, so it is finished here and its lane takes another job at

@@ -11,6 +11,7 @@ d = tempfile.mkdtemp()
 MODES = [dict(RAYLIB_POOL="0"), dict(), dict(RAYLIB_BVH4="0"), dict(RAYLIB_POOL_SHORT_STACK="0"), dict(RAYLIB_BVH4="0", RAYLIB_POOL_SHORT_STACK="4"),
          dict(RAYLIB_POOL="3", RAYLIB_BVH4="0"), dict(RAYLIB_POOL="2", RAYLIB_SAMPLE_BATCH="1"),
          dict(RAYLIB_POOL="0", RAYLIB_LEAF_LIST="0"), dict(RAYLIB_POOL="0", RAYLIB_LDS_SCENE="0")]
+if os.environ.get("FUZZ_MODES_JSON"): import json; MODES = json.loads(os.environ["FUZZ_MODES_JSON"])   # debugging: the schedules to run, e.g. '[{"RAYLIB_POOL": "0"}]'
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 bad = 0
 only = int(os.environ.get("FUZZ_ONLY", "-1"))
@@ -39,14 +40,17 @@ for case in range(cases):
     aperture = 0.0 if rng.rand() < 0.6 else float(rng.uniform(0.01, 0.2))
     seed_val = int(rng.randint(1, 1 << 30))
     tmin = float(rng.choice([1e-4, 1e-4, 1e-4, 0.0, 1e-2, -0.05])) if os.environ.get("FUZZ_TMIN") else 1e-4   # FUZZ_TMIN=1: also rayTMin 0, 1e-2 and a negative one
+    fov, shutter_end = float(rng.uniform(30, 80)), float(rng.choice([0.0, 1.0]))   # drawn before the skip: FUZZ_ONLY must see the full run's stream
     if only >= 0 and case != only: continue
+    if os.environ.get("FUZZ_TMIN_OVERRIDE"): tmin = float(os.environ["FUZZ_TMIN_OVERRIDE"])
     obj, n = gen[0](os.path.join(d, "f%d.obj" % case), **gen[1])
-    ses = binding.SceneSession(lib, obj, origin, (0, 1, -1), float(rng.uniform(30, 80)), w / h, sun=sun, sun_dir=sun_dir, sky_image=sky,
-                               aperture=aperture, focal=4.0, shutter=(0.0, float(rng.choice([0.0, 1.0]))))
+    ses = binding.SceneSession(lib, obj, origin, (0, 1, -1), fov, w / h, sun=sun, sun_dir=sun_dir, sky_image=sky,
+                               aperture=aperture, focal=4.0, shutter=(0.0, shutter_end))
     lib.RaylibAMD_SetSeed(seed_val)
     ref = None
     for env in MODES:
         for k, v in env.items(): os.environ[k] = v
+        if os.environ.get("FUZZ_VERBOSE"): print("case %d kind %d tris %d %dx%d spp %d len %d tmin %g env %s" % (case, kind, n, w, h, spp, max_path, tmin, env), flush=True)
         img = ses.render(w, h, spp, max_path=max_path, tmin=tmin)
         st = ses.stats().as_dict()
         for k in env: del os.environ[k]
