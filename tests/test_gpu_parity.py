@@ -413,6 +413,28 @@ def test_small_scene_walks_agree(name, sessions, gpu_lib, monkeypatch):
                 assert st0["nodesVisited"] != st1["nodesVisited"], "the leaf list was not the walk that ran"
 
 
+@pytest.mark.timeout(120)
+def test_leaf_list_with_every_leaf_a_candidate(gpu_lib, workdir, monkeypatch):
+    """Soups of large overlapping triangles, 24 leaves: with a negative rayTMin (no cut) a ray visits every leaf whose box it meets, and many meet
+    all 24 -- the case in which the pick loop of the first version never ended (its end test assumed an unused slot).  Must return, and with the
+    bits of the BVH4 walk."""
+    from raylib_amd import binding
+    monkeypatch.setenv("RAYLIB_POOL", "0")
+    d = os.path.join(str(workdir), "leaflist_all"); os.makedirs(d, exist_ok=True)
+    for k, (n, seed) in enumerate(((97, 5), (103, 11), (108, 23))):
+        obj, nt = helpers.scenes.soup(os.path.join(d, "s%d.obj" % k), n_tris=n, seed=seed, extent=0.6, size=1.8)
+        ses = binding.SceneSession(gpu_lib, obj, (0, 1, 4), (0, 1, -1), 50.0, 1.5)
+        most = C.c_uint32()
+        assert gpu_lib.RaylibAMD_SceneLeafListInfo(ses.scene, C.byref(most)) == 24
+        for tmin in (-1e-4, -0.05, 0.0, 1e-4):
+            img = ses.render(96, 64, 2, max_path=9, tmin=tmin)
+            monkeypatch.setenv("RAYLIB_LEAF_LIST", "0")
+            ref = ses.render(96, 64, 2, max_path=9, tmin=tmin)
+            monkeypatch.delenv("RAYLIB_LEAF_LIST")
+            assert helpers.same(img, ref).all(), (n, tmin)
+        ses.close()
+
+
 # ---- the pool schedule of the megakernel (k_trace_pool) -------------------------------------
 # Scenes whose BVH is deeper than 16 run it by default; RAYLIB_POOL=K forces it (K = 2, 3, 4 -> 128, 192, 256 paths
 # per wave) and RAYLIB_POOL=0 forces the one-path-per-lane schedule.  Every schedule must produce the same bits.
