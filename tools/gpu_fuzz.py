@@ -18,6 +18,7 @@ only = int(os.environ.get("FUZZ_ONLY", "-1"))
 t0 = time.time()
 for case in range(cases):
     kind = rng.randint(int(os.environ.get("FUZZ_KINDS", "6")))   # FUZZ_KINDS=5 reproduces the case list of the runs recorded before the small-soup kind existed
+    if os.environ.get("FUZZ_FORCE_KIND"): kind = int(os.environ["FUZZ_FORCE_KIND"])   # e.g. 5: only small soups (the draw above still happens: same stream)
     if kind == 0:
         gen = (scenes.cornell, dict(tess=int(rng.randint(1, 20)), displace_fraction=float(rng.choice([0.0, 0.1, 0.3])),
                                     tall_material=str(rng.choice([scenes.MIRROR, scenes.GLASS, scenes.WHITE])), short_material=str(rng.choice([scenes.WHITE, scenes.GLASS]))))
