@@ -478,7 +478,8 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		// the union of their walks (Cornell frame: 10 node steps per wave and bounce for 3.5 per ray).  The leaves are a cut through the
 		// SAH tree: starting from the root, the sub-tree with the largest area x triangle count is opened until the list is full or only the tree's own leaves are left.
 		// Up to 4.5 triangles per leaf on average: beyond, the leaves of the cut grow towards 8 triangles and the tree wins again (tools/gpu_leaflist.py,
-		// leaf list / BVH4 walk: 36 triangles 0.86, 72: 0.92, 84: 0.88, 96: 0.89, 108: 0.90, 120: 1.05).
+		// leaf list / BVH4 walk, first version: 36 triangles 0.86, 72: 0.92, 84: 0.88, 96: 0.89, 108: 0.90, 120 (8-triangle leaves): 1.05; final version: 0.79, 0.80, 0.79,
+		// 0.77, 0.78 -- the limit is also what the kernel's LDS layout holds, rl_device.h RL_LEAFLIST_MAXTRIS).
 		if (n <= RL_LEAFLIST_MAXTRIS) {
 			std::vector<uint32_t> triFirst(T.size(), 0), triCount(T.size(), 0);
 			for (size_t t = T.size(); t-- > 0;) {   // children follow their parent in T (pre-order): a reverse sweep sees them first
