@@ -1,26 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the hot path (Raylib_Render's megakernel) on N MI355X GPUs.
 
-A "step" is one full frame of BASELINE.json's configs[1]: synthetic Cornell box
-(36 triangles), 1920x1080, 64 spp, maxPathLength 5, fixed RNG seed, scene resident
-in HBM.  At N = 1 the timed call is Raylib_Render itself -- the reference's entry point
-(raylib/raylib.cc:231-239), frame left resident in HBM -- and the frame it produced is
-checked, outside the timed region, against windows rendered by the reference build
-(tests/golden/bench_windows.npz).  With N ranks (one process per GPU) the 8x8-pixel cells
-of the frame are dealt round-robin to the ranks, each rank renders its cells into device
-memory (RaylibAMD_RenderDevice), and one RCCL gather per frame brings them to rank 0
-(strong scaling: total work fixed).
+A "step" is one full frame of BASELINE.json's configs[1]: synthetic Cornell box (36 triangles), 1920x1080, 64 spp,
+maxPathLength 5, fixed RNG seed, scene resident in HBM.  Two ways to run N GPUs, the same JSON schema from both:
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+  library mode  `python bench.py --gpus N`  (no torch.distributed.run).  The timed call is Raylib_Render itself -- the reference's
+                entry point (raylib/raylib.cc:231-239), the frame left resident in HBM.  N > 1 sets RAYLIB_NUM_GPUS=N before
+                Raylib_Initialize: the library splits the frame's 8x8 cells over N devices of this process behind that same call
+                (csrc/rl_runtime.inl RenderMulti: RCCL grouped send / recv or peer copies, one scatter kernel).  Exits non-zero when fewer
+                than N devices are visible (RAYLIB_GPU_MAP, a test aid, may name one device several times).
+  process mode  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+                --gpus N ...` (what the driver launches for N > 1): one process per GPU, each renders its cells into device memory
+                (RaylibAMD_RenderDevice), one RCCL gather per frame brings them to rank 0.  --gpus must equal WORLD_SIZE.
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+Strong scaling: the total work is fixed.  Outside the timed region the frame is checked against windows rendered by the reference
+build (tests/golden/bench_windows.npz).  Rank 0 prints ONE JSON line; DESIGN.md section 5 describes every field.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import tempfile
 import time
@@ -30,18 +30,22 @@ sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
 os.environ.setdefault("RAYLIB_QUIET", "1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-# wave64 VALU instructions per cycle per SIMD-32 at saturation: 0.5 (2 cycles each; MI355X_MICROARCH.md constants table, and measured on
-# the bench box by tools/valu_calib.hip: 944 G wave-instructions/s over 1024 SIMDs at the ~1.9 GHz the chip holds under that load)
-VALU_CYCLES_PER_WAVE_INST = 2.0
-NUM_SIMDS = 256 * 4
+# ---- hardware constants (MI355X_MICROARCH.md, chip-level parameters): peaks are CONSTANTS, never derived from a run -----------------
+HBM_PEAK_GBS = 8000.0            # HBM3E spec peak
+NUM_SIMDS = 256 * 4              # 256 CUs x 4 SIMD-32
+MAX_CLOCK_HZ = 2.4e9             # "Max clock 2400 MHz"
+# VALU roof: a SIMD's vector issue port is busy `cost` cycles per wave64 instruction (2 for v_fma_f32 = 157.3 TFLOP/s f32 at 2.4 GHz;
+# the other classes: tools/valu_calib.hip, measured on the bench box, profiles/valu_calib.json).  Unit: SIMD issue cycles per second.
+VALU_PEAK_GCYC = NUM_SIMDS * MAX_CLOCK_HZ / 1e9
 
 WORKLOADS = {
     # BASELINE.json configs[1]
     "cornell_1080p_64spp": dict(scene="cornell", kw={}, w=1920, h=1080, spp=64, max_path=5, camera="cornell"),
-    # configs[2]-sized stress (parity-test size by default; selectable for profiling)
+    # configs[2]-sized stress: a memory-bound megakernel (the pool schedule on 298 k triangles)
     "breakfast_300k_1080p_128spp": dict(scene="cornell", kw=dict(tess=91, displace_fraction=0.2), w=1920, h=1080, spp=128, max_path=5, camera="breakfast"),
 }
+HEADLINE = "cornell_1080p_64spp"
+EXTRA = "breakfast_300k_1080p_128spp"
 
 
 def cpu_baseline(workload, cam, gpu_rays_per_sample):
@@ -82,46 +86,319 @@ def cpu_baseline(workload, cam, gpu_rays_per_sample):
                       % (w, h, spp, 100.0 * spp / workload["spp"], cores, gpu_rays_per_sample)}
 
 
+def golden_windows(workload_name, frame_hw):
+    """The timed frame against windows of the same frame rendered by the REAL reference build (tests/golden/gen_golden.py ->
+    bench_windows.npz: data; only windows in which no sample met two surfaces at exactly the same t).  Bit for bit."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "bench_windows.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if workload_name + "_pos" not in g.files:
+        return None
+    pos, px = g[workload_name + "_pos"], g[workload_name + "_px"]
+    bad = 0
+    for (x0, y0), want in zip(pos, px):
+        got = frame_hw[y0:y0 + 16, x0:x0 + 16]
+        bad += int((np.ascontiguousarray(got[..., :3]).view(np.uint32) != np.ascontiguousarray(want[..., :3]).view(np.uint32)).any(-1).sum())
+    n = len(pos) * 256
+    return ("%d / %d pixels of %d reference-rendered windows bit-identical" % (n - bad, n, len(pos))) if bad == 0 else \
+           ("MISMATCH: %d of %d pixels of the reference-rendered windows differ" % (bad, n))
+
+
+def step_times(ts):
+    """min / median / max of the host-visible time of each timed step (ms)."""
+    if not ts:
+        return None
+    return {"min": min(ts) * 1e3, "median": statistics.median(ts) * 1e3, "max": max(ts) * 1e3, "n": len(ts)}
+
+
+def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
+    """The roofline object of the line.
+
+    Measured in THIS run: launches, average megakernel launch duration (HIP events on the library's stream), the launch's record
+    counters -> algorithmic bytes.  Hardware counters cannot be read from inside this process: HBM traffic and the VALU instruction
+    counts by class are REPLAYED from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_traffic.json, written by
+    tools/profile_round.sh -> tools/pmc_traffic.py); they sit in `replayed_pmc` with the build id of the library they were taken from,
+    and when that is not the loaded library's (`RaylibAMD_BuildId`) the line says STALE and takes its headline figure from what this run
+    measured alone.  Peaks are constants."""
+    launches = max(1, acc["launches"])
+    avg_launch_ms = acc["trace_ms"] / launches
+    sec = avg_launch_ms * 1e-3
+    samples_per_launch = acc["samples"] / launches
+    # ---- algorithmic bytes, SURVEY 8(d): a property of the WORKLOAD -- the records a tree walk of this scene fetches: 64 B per BVH4
+    # grid-node step (a float-box BVH4 step = 2 records), 64 B per triangle test, 64 B per shading record, 16 B per texel and per pixel.
+    # Where the kernel that ran walks something else (the Cornell class: the leaf list, every box of it per ray, from LDS), the tree-walk
+    # counts come from one untimed frame with RAYLIB_LEAF_LIST=0 and the kernel's own LDS-served bytes are reported next to them.
+    ran_bytes = acc["bytes"] / launches
+    if tree_walk is not None:
+        alg_bytes = tree_walk["bytes_per_launch"]
+        served = {"schedule": "leaf list (k_trace<.., LDS = 2>): every traced ray reads all leaf-box records, from LDS",
+                  "lds_served_bytes_per_launch": ran_bytes, "lds_served_bytes_per_camera_sample": ran_bytes / max(1.0, samples_per_launch)}
+    else:
+        alg_bytes, served = ran_bytes, None
+    alg_gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
+    algorithmic = {"bytes_per_launch": alg_bytes, "bytes_per_camera_sample": alg_bytes / max(1.0, samples_per_launch), "gbs": alg_gbs,
+                   "frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+                   "definition": "64 B x (BVH4-walk node records + triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran",
+                   "served_elsewhere": served}
+    out = {"kernel": "k_trace" if acc["paths_per_wave"] <= 64 else "k_trace_pool", "paths_per_wave": int(acc["paths_per_wave"]),
+           "avg_launch_ms": avg_launch_ms, "launches": acc["launches"], "job_heads": acc.get("job_heads"), "algorithmic": algorithmic}
+    # ---- replayed hardware counters
+    rec, stale, source = None, None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world == 1 and os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc)).get(workload_name)
+        except (OSError, ValueError) as e:
+            source = "profiles/pmc_traffic.json could not be read: %s" % e
+    if rec:
+        stale = rec.get("build_id") != build_id
+        source = ("STALE: " if stale else "") + "replayed from profiles/pmc_traffic.json (%s, build %s; loaded library is build %s)" % (rec.get("round"), rec.get("build_id"), build_id)
+    traffic = rec["hbm_bytes_per_launch"] if rec else None
+    hbm = None
+    if rec and sec > 0:
+        gbs = traffic / sec / 1e9
+        hbm = {"measured_bytes_per_launch": traffic, "gbs": gbs, "frac": gbs / HBM_PEAK_GBS, "tcc_hit_rate": rec.get("tcc_hit_rate")}
+    valu = None
+    if rec and sec > 0 and rec.get("valu_weighted_cycles_per_launch"):
+        wc = rec["valu_weighted_cycles_per_launch"]
+        ach = wc / sec / 1e9
+        valu = {"weighted_issue_cycles_per_launch": wc, "insts_per_launch": rec.get("valu_insts_per_launch"),
+                "mean_cost_cycles_per_inst": wc / rec["valu_insts_per_launch"], "class_counts": rec.get("valu_class_counts"),
+                "achieved_gcyc_per_s": ach, "peak_gcyc_per_s": VALU_PEAK_GCYC, "frac_of_spec_peak": ach / VALU_PEAK_GCYC,
+                # the same cycles against the cycles the launch really had (GRBM_GUI_ACTIVE / 8 of the profiled pass: the clock the chip held)
+                "frac_of_profiled_pass_cycles": rec.get("valu_weighted_busy_fraction"), "unweighted_2cyc_busy_fraction": rec.get("valu_busy_fraction"),
+                "lane_utilisation": rec.get("valu_lane_utilisation"), "wave_wait_fraction": rec.get("wave_wait_fraction"),
+                "waves_per_simd": rec.get("waves_per_simd"), "salu_insts_per_launch": rec.get("salu_insts_per_launch"),
+                "profiled_clock_ghz": rec.get("profiled_clock_ghz")}
+    # ---- headline: the resource nearest its roof among those measured with fresh counters; else this run's algorithmic bytes
+    if valu and not stale and (not hbm or valu["frac_of_spec_peak"] >= hbm["frac"]):
+        head = {"achieved": valu["achieved_gcyc_per_s"], "peak": VALU_PEAK_GCYC, "unit": "G SIMD-issue-cycles/s", "frac": valu["frac_of_spec_peak"], "resource": "VALU issue (class-weighted)"}
+    elif hbm and not stale:
+        head = {"achieved": hbm["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "resource": "HBM (measured bytes)"}
+    else:
+        head = {"achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "resource": "HBM (algorithmic bytes; no fresh counters)"}
+    vf = valu["frac_of_profiled_pass_cycles"] if valu and valu["frac_of_profiled_pass_cycles"] else (valu["frac_of_spec_peak"] if valu else 0.0)
+    hf = hbm["frac"] if hbm else 0.0
+    if hbm and hf >= 0.6 and hf >= vf:
+        bound = "hbm"
+    elif valu and vf >= 0.75:
+        bound = "valu"
+    elif valu or hbm:
+        bound = "latency (VALU issue %.0f %% of the launch's cycles, HBM %.0f %% of peak: neither saturated)" % (100 * vf, 100 * hf)
+    else:
+        bound = "unknown (no counter passes for this workload)"
+    line = {"bound": bound}
+    line.update(head)
+    line.update({"traffic": traffic, "traffic_source": source})
+    line.update(out)
+    line.update({"hbm": hbm, "valu": valu,
+                 "replayed_pmc": None if not rec else {"file": "profiles/pmc_traffic.json", "round": rec.get("round"), "build_id": rec.get("build_id"),
+                                                       "loaded_build_id": build_id, "stale": stale, "kernel": rec.get("kernel")}})
+    return line
+
+
+def accumulate(acc, stats, binding):
+    acc["rays"] += stats.rays; acc["trace_ms"] += stats.traceKernelMs; acc["launches"] += stats.traceLaunches
+    acc["kernel_ms"] += stats.kernelMs
+    acc["bytes"] += binding.algorithmic_bytes(stats)
+    acc["samples"] += stats.cameraSamples
+    acc["paths_per_wave"] = stats.pathsPerWave
+    acc["job_heads"] = stats.jobHeads
+
+
+def new_acc():
+    return dict(rays=0, trace_ms=0.0, launches=0, bytes=0, samples=0, kernel_ms=0.0, paths_per_wave=64, job_heads=None)
+
+
+def library_run(lib, binding, scenes, workload_name, steps, warmup, n_gpus, rank_tag="0", want_device_entry=True):
+    """K timed Raylib_Render calls on one workload (library mode).  Returns the measurements and, untimed, the frame check, the
+    render + dump time, the device-pointer entry's time and the tree-walk record counts."""
+    import numpy as np
+    wl = WORKLOADS[workload_name]
+    cam = scenes.CONFIG_CAMERAS[wl["camera"]]
+    w, h = wl["w"], wl["h"]
+    tmp = tempfile.mkdtemp()
+    obj, ntris = getattr(scenes, wl["scene"])(os.path.join(tmp, "bench_%s.obj" % rank_tag), **wl["kw"])
+    ses = binding.SceneSession(lib, obj, cam["origin"], cam["look_at"], cam["fov"], w / h, sun=cam["sun"], sun_dir=cam["sun_dir"])
+    st = ses.settings(w, h, wl["spp"], max_path=wl["max_path"])
+    image = lib.Raylib_CreateImage(w, h)          # what a front-end hands to Raylib_Render
+    stats = binding.Stats()
+    acc = new_acc()
+    for _ in range(warmup):
+        lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)
+    import torch
+    torch.cuda.synchronize()
+    per_step = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts = time.perf_counter()
+        lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)     # the boundary itself (synchronous); the frame stays in HBM
+        per_step.append(time.perf_counter() - ts)
+        lib.RaylibAMD_GetLastStats(C.byref(stats))
+        accumulate(acc, stats, binding)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    last = stats.as_dict()
+    # ---- untimed from here on -------------------------------------------------------------------------------------------------
+    host = np.zeros(w * h * 3, np.float32)
+    lib.Raylib_DumpImageData(image, host.ctypes.data_as(C.POINTER(C.c_float)))
+    frame_check = golden_windows(workload_name, host.reshape(h, w, 3))
+    # what a front-end observes: the render plus the read-back of the frame (the reference's Raylib_Render returns with the pixels
+    # in host memory, render/renderer.cc:292-356; here the first reader pays the 33 MB copy)
+    k2 = max(1, min(steps, 10))
+    t1 = time.perf_counter()
+    for _ in range(k2):
+        lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)
+        lib.Raylib_DumpImageData(image, host.ctypes.data_as(C.POINTER(C.c_float)))
+    render_plus_dump = (time.perf_counter() - t1) / k2
+    boundary = {"timed_entry": "Raylib_Render", "raylib_render_ms_per_step": elapsed / steps * 1e3,
+                "render_plus_dump_ms_per_step": render_plus_dump * 1e3}
+    if want_device_entry and n_gpus == 1:
+        dev = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(k2):
+            if lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, 0, 1, C.c_void_p(dev.data_ptr())) != 1:
+                raise SystemExit("RaylibAMD_RenderDevice failed")
+        torch.cuda.synchronize()
+        boundary["render_device_ms_per_step"] = (time.perf_counter() - t2) / k2 * 1e3
+    tree_walk = None
+    if acc["paths_per_wave"] <= 64 and n_gpus == 1:
+        # the workload's algorithmic bytes: the same frame on the BVH4 walk (the leaf-list kernel reads every leaf box per ray, from LDS)
+        keep = os.environ.get("RAYLIB_LEAF_LIST")
+        os.environ["RAYLIB_LEAF_LIST"] = "0"
+        lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)
+        lib.RaylibAMD_GetLastStats(C.byref(stats))
+        if keep is None:
+            del os.environ["RAYLIB_LEAF_LIST"]
+        else:
+            os.environ["RAYLIB_LEAF_LIST"] = keep
+        tree_walk = {"bytes_per_launch": binding.algorithmic_bytes(stats) / max(1, stats.traceLaunches), "launch_ms": stats.traceKernelMs / max(1, stats.traceLaunches)}
+    lib.Raylib_DestroyImage(image)
+    ses.close()
+    return dict(acc=acc, elapsed=elapsed, per_step=per_step, frame_check=frame_check, boundary=boundary, tree_walk=tree_walk,
+                ntris=ntris, last_stats=last, wl=wl, cam=cam)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell_1080p_64spp", choices=list(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=HEADLINE, choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the second workload (a memory-bound megakernel) reported under \"extra\"")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1:
+        raise SystemExit("--gpus and --steps must be positive")
 
+    distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # under torch.distributed.run the gather path is used even with one rank (so it can be exercised on a 1-GPU box)
-    distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if distributed else 1
+    if distributed and world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: under torch.distributed.run --gpus must equal --nproc-per-node" % (args.gpus, world))
     import torch
-    import torch.distributed as dist
-    from raylib_amd import binding, scenes, tiling
+    from raylib_amd import binding, scenes
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if distributed:
+        return process_mode(args, rank, local_rank, world, torch, binding, scenes)
+
+    # ---- library mode ---------------------------------------------------------------------------------------------------------
+    n = args.gpus
+    env_n = os.environ.get("RAYLIB_NUM_GPUS")
+    if env_n is not None and int(env_n) != n:
+        raise SystemExit("RAYLIB_NUM_GPUS=%s in the environment but --gpus %d: the line would attribute the rays to the wrong number of GPUs" % (env_n, n))
+    gpu_map = os.environ.get("RAYLIB_GPU_MAP")
+    visible = torch.cuda.device_count()
+    if n > visible and not gpu_map:
+        raise SystemExit("--gpus %d but %d device(s) visible: refusing to measure fewer GPUs than asked for "
+                         "(RAYLIB_GPU_MAP=0,0,.. puts several logical ranks on one device, for tests)" % (n, visible))
+    if n > 1:
+        os.environ["RAYLIB_NUM_GPUS"] = str(n)
+    lib = binding.load()
+    if lib.Raylib_Initialize() != 1:
+        raise SystemExit("Raylib_Initialize failed")
+    lib.RaylibAMD_SetSeed(1)
+    build_id = lib.RaylibAMD_BuildId().decode()
+
+    r = library_run(lib, binding, scenes, args.workload, args.steps, args.warmup, n)
+    ranks = int(r["last_stats"]["ranks"])
+    if ranks != n:
+        raise SystemExit("asked for %d GPU(s) but the library rendered on %d rank(s)" % (n, ranks))
+    acc, elapsed, wl = r["acc"], r["elapsed"], r["wl"]
+    out = {
+        "metric": "Mrays/sec (primary+secondary) + frame time, Cornell Box 1080p 64spp",
+        "value": acc["rays"] / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": ranks,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_spread": step_times(r["per_step"]),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "mode": "library (Raylib_Render; RAYLIB_NUM_GPUS=%d)" % n, "scene_triangles": r["ntris"],
+                   "width": wl["w"], "height": wl["h"], "spp": wl["spp"], "max_path_length": wl["max_path"], "seed": 1,
+                   "tiling": "8x8 cells round-robin over %d rank(s)" % ranks, "rays_per_step": acc["rays"] / args.steps,
+                   "camera_samples_per_step": acc["samples"] / args.steps, "frame_check": r["frame_check"], "boundary": r["boundary"],
+                   "build_id": build_id, "timed_region_s": elapsed},
+        "roofline": roofline_block(args.workload, acc, ranks, build_id, r["tree_walk"]),
+    }
+    if ranks > 1 or gpu_map:
+        s = r["last_stats"]
+        out["multi_gpu"] = {"ranks": ranks, "devices": s["devices"], "gpu_map": gpu_map, "gather": s["gatherMode"], "rccl_comm_size": s["rcclCommSize"],
+                            "gather_ms": s["gatherMs"], "scatter_ms": s["scatterMs"], "rank_kernel_ms": s["rankKernelMs"], "rank_trace_ms": s["rankTraceMs"],
+                            "note": "last timed frame; gather_ms = rank 0's stream from the end of its own kernels until every rank's cells are on its device"}
+    if ranks == 1 and not args.no_extra and args.workload == HEADLINE:
+        # a second object in the same invocation: the configs[2]-sized scene, whose megakernel (the pool schedule) waits on memory
+        k = max(3, min(20, args.steps // 5))
+        e = library_run(lib, binding, scenes, EXTRA, k, 1, 1, rank_tag="x", want_device_entry=False)
+        ea = e["acc"]
+        out["extra"] = {"workload": EXTRA, "value": ea["rays"] / e["elapsed"] / 1e6, "unit": "Mrays/s", "steps": k, "warmup": 1,
+                        "ms_per_step": e["elapsed"] / k * 1e3, "ms_per_step_spread": step_times(e["per_step"]), "scene_triangles": e["ntris"],
+                        "spp": e["wl"]["spp"], "frame_check": e["frame_check"], "boundary": e["boundary"],
+                        "roofline": roofline_block(EXTRA, ea, 1, build_id, e["tree_walk"])}
+    if ranks == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, r["cam"], acc["rays"] / max(1.0, acc["samples"]))
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def process_mode(args, rank, local_rank, world, torch, binding, scenes):
+    """One process per GPU (what the driver launches): RaylibAMD_RenderDevice per rank, one RCCL gather per frame."""
+    import torch.distributed as dist
+    from raylib_amd import tiling
     # BENCH_SHARE_GPU=1 (test aid, 1-GPU box): several ranks on the one device, the gather staged through the host over gloo --
     # RCCL refuses two ranks per device.  It exercises the N > 1 frame assembly, not its speed.
     share = os.environ.get("BENCH_SHARE_GPU", "0") == "1"
+    visible = torch.cuda.device_count()
+    if world > visible and not share:
+        raise SystemExit("WORLD_SIZE=%d but %d device(s) visible (BENCH_SHARE_GPU=1 shares one device, for tests)" % (world, visible))
+    if os.environ.get("RAYLIB_NUM_GPUS", "1") != "1":
+        raise SystemExit("RAYLIB_NUM_GPUS must not be set in process mode: every process drives one GPU")
     # one visible device per rank (a launcher that masks devices per process) or all of the node's devices visible to every rank
-    device_index = local_rank % max(1, torch.cuda.device_count())
+    device_index = local_rank % max(1, visible)
     os.environ["RAYLIB_DEVICE"] = str(device_index)
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
-    if distributed:
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+    if share:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     lib = binding.load()
     if lib.Raylib_Initialize() != 1:
         raise SystemExit("Raylib_Initialize failed")
     lib.RaylibAMD_SetSeed(1)
+    build_id = lib.RaylibAMD_BuildId().decode()
 
     wl = WORKLOADS[args.workload]
     cam = scenes.CONFIG_CAMERAS[wl["camera"]]
@@ -132,201 +409,89 @@ def main():
     st = ses.settings(w, h, wl["spp"], max_path=wl["max_path"])
 
     # device buffers: this rank's cells (padded to equal size for the gather) and, on rank 0, the frame
-    if distributed:
-        pad_floats = max(tiling.padded_cells(w, h, world) * 64 * 4, w * h * 4 if world == 1 else 0)
-        # two send buffers, used alternately: the gather of frame i (RCCL's stream) may still be reading its buffer while the
-        # library (its own stream) already renders frame i + 1 into the other one
-        mines = [torch.zeros(pad_floats, dtype=torch.float32, device=dev) for _ in range(2)]
-        mine = mines[0]
-        gathered = [torch.zeros(pad_floats, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
-        frame = torch.zeros(h * w, 4, dtype=torch.float32, device=dev) if rank == 0 else None
-        plan = tiling.torch_scatter_plan(w, h, world, dev) if rank == 0 else None
-    else:
-        mine = torch.zeros(w * h * 4, dtype=torch.float32, device=dev)
-        boundary_image = lib.Raylib_CreateImage(w, h)       # what a front-end hands to Raylib_Render
+    pad_floats = max(tiling.padded_cells(w, h, world) * 64 * 4, w * h * 4 if world == 1 else 0)
+    # two send buffers, used alternately: the gather of frame i (RCCL's stream) may still be reading its buffer while the
+    # library (its own stream) already renders frame i + 1 into the other one
+    mines = [torch.zeros(pad_floats, dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.zeros(pad_floats, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+    frame = torch.zeros(h * w, 4, dtype=torch.float32, device=dev) if rank == 0 else None
+    plan = tiling.torch_scatter_plan(w, h, world, dev) if rank == 0 else None
 
     stats = binding.Stats()
-    acc = dict(rays=0, trace_ms=0.0, launches=0, bytes=0, nodes=0, tris=0, shaded=0, texels=0, samples=0, kernel_ms=0.0)
-
+    acc = new_acc()
     pending = [None, None]
     frame_no = [0]
 
     def step(record):
-        out = mine
-        if distributed:
-            k = frame_no[0] & 1
-            frame_no[0] += 1
-            out = mines[k]
-            if pending[k] is not None:
-                pending[k].wait()                             # the gather that read this buffer two frames ago ...
-                torch.cuda.current_stream().synchronize()     # ... is complete before the library's stream overwrites it (returns at once in steady state)
-        if distributed:
-            ok = lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(out.data_ptr()))
-            if ok != 1:
-                raise SystemExit("RaylibAMD_RenderDevice failed")
-        else:
-            lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, boundary_image)    # the boundary itself; the frame stays in HBM
-        if distributed:
-            if share:
-                host = out.cpu()
-                host_list = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, host_list, dst=0)
-                if rank == 0:
-                    for dst_t, src_t in zip(gathered, host_list):
-                        dst_t.copy_(src_t)
-            else:
-                pending[k] = dist.gather(out, gathered, dst=0, async_op=True)   # one RCCL gather per frame
+        k = frame_no[0] & 1
+        frame_no[0] += 1
+        out = mines[k]
+        if pending[k] is not None:
+            pending[k].wait()                             # the gather that read this buffer two frames ago ...
+            torch.cuda.current_stream().synchronize()     # ... is complete before the library's stream overwrites it (returns at once in steady state)
+        if lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(out.data_ptr())) != 1:
+            raise SystemExit("RaylibAMD_RenderDevice failed")
+        if share:
+            host = out.cpu()
+            host_list = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, host_list, dst=0)
             if rank == 0:
-                if pending[k] is not None:
-                    pending[k].wait()                         # stream-level: the assembly below is ordered after the gather
-                if world == 1:
-                    frame.copy_(gathered[0][: h * w * 4].view(h * w, 4))   # one rank renders the row-major frame directly
-                else:
-                    frame[plan[1]] = torch.stack(gathered).reshape(-1, 4)[plan[0]]
+                for dst_t, src_t in zip(gathered, host_list):
+                    dst_t.copy_(src_t)
+        else:
+            pending[k] = dist.gather(out, gathered, dst=0, async_op=True)   # one RCCL gather per frame
+        if rank == 0:
+            if pending[k] is not None:
+                pending[k].wait()                         # stream-level: the assembly below is ordered after the gather
+            if world == 1:
+                frame.copy_(gathered[0][: h * w * 4].view(h * w, 4))   # one rank renders the row-major frame directly
+            else:
+                frame[plan[1]] = torch.stack(gathered).reshape(-1, 4)[plan[0]]
         if record:
             lib.RaylibAMD_GetLastStats(C.byref(stats))
-            acc["rays"] += stats.rays; acc["trace_ms"] += stats.traceKernelMs; acc["launches"] += stats.traceLaunches
-            acc["kernel_ms"] += stats.kernelMs
-            acc["bytes"] += binding.algorithmic_bytes(stats)
-            acc["nodes"] += stats.nodesVisited; acc["tris"] += stats.trisTested; acc["shaded"] += stats.shadedHits
-            acc["texels"] += stats.texFetches; acc["samples"] += stats.cameraSamples
+            accumulate(acc, stats, binding)
 
     for _ in range(args.warmup):
         step(False)
 
     def fence():
         torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     fence()
+    per_step = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step(True)
+        per_step.append(time.perf_counter() - ts)
     fence()
     elapsed = time.perf_counter() - t0
 
-    if distributed:
-        red_dev = torch.device("cpu") if share else dev
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(acc["rays"]), float(acc["samples"])], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
-    else:
-        total_rays, total_samples = float(acc["rays"]), float(acc["samples"])
-
-    def golden_windows(frame_hw4):
-        """The timed frame against windows of the same frame rendered by the REAL reference build (tests/golden/gen_golden.py ->
-        bench_windows.npz: data; only windows in which no sample met two surfaces at exactly the same t).  Bit for bit."""
-        import numpy as np
-        path = os.path.join(ROOT, "tests", "golden", "bench_windows.npz")
-        if not os.path.exists(path):
-            return None
-        g = np.load(path)
-        if args.workload + "_pos" not in g.files:
-            return None
-        pos, px = g[args.workload + "_pos"], g[args.workload + "_px"]
-        bad = 0
-        for (x0, y0), want in zip(pos, px):
-            got = frame_hw4[y0:y0 + 16, x0:x0 + 16]
-            bad += int((np.ascontiguousarray(got[..., :3]).view(np.uint32) != np.ascontiguousarray(want[..., :3]).view(np.uint32)).any(-1).sum())
-        n = len(pos) * 256
-        return ("%d / %d pixels of %d reference-rendered windows bit-identical" % (n - bad, n, len(pos))) if bad == 0 else \
-               ("MISMATCH: %d of %d pixels of the reference-rendered windows differ" % (bad, n))
+    red_dev = torch.device("cpu") if share else dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    tot = torch.tensor([float(acc["rays"]), float(acc["samples"])], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
+    # every rank's megakernel time of the last frame, for attributing a scaling loss
+    km = torch.zeros(world, dtype=torch.float64, device=red_dev)
+    km[rank] = stats.traceKernelMs
+    dist.all_reduce(km, op=dist.ReduceOp.SUM)
 
     frame_check = None
-    boundary = None
-    if not distributed:
-        # outside the timed region: (1) the frame the LAST timed Raylib_Render call produced, read back through the reference's own
-        # accessor and compared with the reference build's pixels; (2) the same K steps through the device-pointer entry, for comparison
-        import numpy as np
-        host = np.zeros(w * h * 3, np.float32)
-        lib.Raylib_DumpImageData(boundary_image, host.ctypes.data_as(C.POINTER(C.c_float)))
-        frame_check = golden_windows(host.reshape(h, w, 3))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            if lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, 0, 1, C.c_void_p(mine.data_ptr())) != 1:
-                raise SystemExit("RaylibAMD_RenderDevice failed")
-        torch.cuda.synchronize()
-        boundary = {"timed_entry": "Raylib_Render", "raylib_render_ms_per_step": elapsed / args.steps * 1e3,
-                    "render_device_ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3}
-    if distributed and rank == 0:
+    if rank == 0:
         # outside the timed region: the frame assembled from the ranks' cells against this rank's own render of the whole frame
         torch.cuda.synchronize()
         whole = torch.zeros(h * w * 4, dtype=torch.float32, device=dev)
         if lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, 0, 1, C.c_void_p(whole.data_ptr())) == 1:
             same = bool(torch.equal(whole.view(torch.int32), frame.reshape(-1).view(torch.int32)))
             frame_check = "assembled frame bit-identical to a one-GPU render" if same else "MISMATCH between the assembled frame and a one-GPU render"
-            gw = golden_windows(frame.reshape(h, w, 4).cpu().numpy())
+            gw = golden_windows(args.workload, frame.reshape(h, w, 4).cpu().numpy())
             if gw is not None:
                 frame_check += "; " + gw
-        lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(mines[0].data_ptr()))   # stats of a timed-style call again
-
-    if rank == 0:
-        launches = max(1, acc["launches"])
-        avg_launch_ms = acc["trace_ms"] / launches
-        bytes_per_launch = acc["bytes"] / launches
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        # Hardware counters cannot be read from inside this process: `traffic` and the VALU figures are REPLAYED from the committed
-        # rocprofv3 --pmc passes of this same command (tools/pmc_profile.sh -> tools/pmc_traffic.py -> profiles/pmc_traffic.json),
-        # rescaled to this run's launch time where they are rates.  traffic_source says so in the line.
-        traffic = None
-        valu = None
-        hbm_measured = None
-        bound = "unknown (no PMC passes committed for this workload)"
-        traffic_source = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc)).get(args.workload)
-                if rec and world == 1:
-                    traffic = rec["hbm_bytes_per_launch"]
-                    traffic_source = "replayed from profiles/pmc_traffic.json (%s)" % rec.get("round", "rocprofv3 --pmc passes of this workload")
-                    hbm_measured = traffic / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else None
-                    # VALU issue: wave-level VALU instructions x 2 cycles / (SIMDs x the launch's cycles), and the share of lanes doing work
-                    cycles = rec.get("cycles_per_launch")
-                    busy = (VALU_CYCLES_PER_WAVE_INST * rec["valu_insts_per_launch"] / NUM_SIMDS / cycles) if cycles else rec.get("valu_busy_fraction")
-                    valu = {"busy_fraction": busy, "lane_utilisation": rec.get("valu_lane_utilisation"),
-                            "insts_per_launch": rec.get("valu_insts_per_launch"), "cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST,
-                            "wave_wait_fraction": rec.get("wave_wait_fraction"), "waves_per_simd": rec.get("waves_per_simd")}
-                    hbm_frac = (hbm_measured or 0.0) / HBM_PEAK_GBS
-                    # what binds: the larger of the two utilisations -- and neither when both are low (then the waves are waiting on
-                    # each other's latencies: too few of them per SIMD to fill the issue slots)
-                    if hbm_frac >= 0.6 and hbm_frac >= (busy or 0.0):
-                        bound = "hbm"
-                    elif (busy or 0.0) >= 0.75:
-                        bound = "valu-issue"
-                    else:
-                        bound = "latency (VALU issue %.0f %%, HBM %.0f %% of peak: neither saturated)" % (100 * (busy or 0.0), 100 * hbm_frac)
-            except Exception:
-                traffic = None
-        # achieved / peak / unit / frac describe the resource the counters show nearest its roof:
-        #   HBM        -- ALGORITHMIC bytes per launch over the launch time against the HBM peak, as SURVEY 8(d) defines the figure;
-        #   VALU issue -- wave-level VALU instructions per second against 1024 SIMDs x (1 instruction / 2 cycles) x the launch's clock
-        #                 (tools/valu_calib.hip measures that 0.5 per cycle on this part): what binds a scene that lives in LDS or L2,
-        #                 where the algorithmic bytes never reach HBM and "bytes / HBM peak" can exceed 1 without meaning anything.
-        # The algorithmic figure is kept in every line (algorithmic_gbs, algorithmic_frac_of_hbm_peak) next to what the memory system
-        # really moved (hbm_measured_*); `bound` says whether anything is saturated at all.
-        algorithmic = {"algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_gbs": achieved, "algorithmic_frac_of_hbm_peak": achieved / HBM_PEAK_GBS}
-        busy_now = valu["busy_fraction"] if valu else None
-        hbm_now = (hbm_measured / HBM_PEAK_GBS) if hbm_measured else None
-        if busy_now is not None and busy_now >= (hbm_now or 0.0) and avg_launch_ms > 0:
-            a = valu["insts_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
-            head = {"achieved": a, "peak": a / busy_now, "unit": "Gwave-inst/s", "frac": busy_now, "resource": "VALU issue"}
-        else:
-            head = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "resource": "HBM (algorithmic bytes)"}
-        roofline = {"bound": bound}
-        roofline.update(head)
-        roofline.update({"traffic": traffic, "traffic_source": traffic_source,
-                         "hbm_measured_gbs": hbm_measured, "hbm_measured_frac": hbm_now,
-                         "kernel": "k_trace" if stats.pathsPerWave <= 64 else "k_trace_pool", "paths_per_wave": int(stats.pathsPerWave), "avg_launch_ms": avg_launch_ms, "launches": acc["launches"]})
-        roofline.update(algorithmic)
-        roofline.update({"valu": valu,
-                         "note": "rank 0's launches; algorithmic bytes = 64 B x (BVH node / leaf-list records + triangle records + shading records) + 16 B x (texels + pixels)"})
         out = {
             "metric": "Mrays/sec (primary+secondary) + frame time, Cornell Box 1080p 64spp",
             "value": total_rays / elapsed / 1e6,
@@ -335,28 +500,29 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_spread": step_times(per_step),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "scene_triangles": ntris, "width": w, "height": h, "spp": wl["spp"],
-                       "max_path_length": wl["max_path"], "seed": 1, "tiling": "8x8 cells round-robin over %d rank(s)" % world,
-                       "rays_per_step": total_rays / args.steps, "camera_samples_per_step": total_samples / args.steps,
-                       "frame_check": frame_check, "boundary": boundary},
-            "roofline": roofline,
+            "config": {"workload": args.workload, "mode": "one process per GPU (RaylibAMD_RenderDevice + one RCCL gather per frame)", "scene_triangles": ntris,
+                       "width": w, "height": h, "spp": wl["spp"], "max_path_length": wl["max_path"], "seed": 1,
+                       "tiling": "8x8 cells round-robin over %d rank(s)" % world, "rays_per_step": total_rays / args.steps,
+                       "camera_samples_per_step": total_samples / args.steps, "frame_check": frame_check,
+                       "boundary": {"timed_entry": "RaylibAMD_RenderDevice + torch.distributed gather", "ms_per_step": elapsed / args.steps * 1e3},
+                       "build_id": build_id, "timed_region_s": elapsed},
+            "roofline": roofline_block(args.workload, acc, world, build_id),
+            "multi_gpu": {"ranks": world, "devices": min(world, visible), "gather": "gloo via host (BENCH_SHARE_GPU)" if share else "rccl (torch.distributed gather)",
+                          "rank_trace_ms": [float(x) for x in km.tolist()], "note": "rank_trace_ms: every rank's megakernel time in the last timed frame"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, cam, total_rays / max(1.0, total_samples))
         print(json.dumps(out))
         sys.stdout.flush()
-
-    if not distributed:
-        lib.Raylib_DestroyImage(boundary_image)
     ses.close()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -47,6 +47,16 @@ typedef struct RaylibAMDStats {
 	uint64_t waveTrips;       /* bounce-loop trips summed over waves: rays / (64 * waveTrips) = share of lane slots that traced a ray */
 	uint32_t pathsPerWave;    /* schedule of the megakernel: 64 = k_trace (one path per lane), 128/192/256 = k_trace_pool */
 	uint32_t ranks;           /* logical ranks (devices) that rendered the frame: 1, or RAYLIB_NUM_GPUS for a whole-frame render */
+	/* ---- a whole-frame render over several ranks (RAYLIB_NUM_GPUS > 1): where the time went, so that a scaling loss can be attributed ---- */
+	uint32_t gatherMode;      /* how the ranks' cells reached rank 0's device: 0 nothing to move (one rank, or every rank on rank 0's device),
+	                             1 RCCL grouped ncclSend / ncclRecv, 2 hipMemcpyPeerAsync pushes (RAYLIB_GATHER=peer, or RCCL could not be initialised) */
+	uint32_t rcclCommSize;    /* devices in the library's RCCL communicator (0: not initialised) */
+	uint32_t devices;         /* distinct physical devices the ranks ran on */
+	uint32_t jobHeads;        /* heads of the job list in the last megakernel launch: 8 = one per XCD (csrc/rl_render.hip TakeJobs), RAYLIB_JOB_HEADS overrides */
+	double   gatherMs;        /* on rank 0's stream: from the end of rank 0's own kernels until every rank's cells are on its device (waiting for slower ranks included) */
+	double   scatterMs;       /* k_scatter_cells: cell buffers -> row-major frame */
+	double   rankKernelMs[16];/* per rank: HIP-event time of all its kernels (kernelMs is their maximum) */
+	double   rankTraceMs[16]; /* per rank: ... of its megakernel launches (traceKernelMs is their maximum) */
 } RaylibAMDStats;
 
 /* Seed of the per-(pixel, sample) streams of include/raylib_amd_rng.h. */
@@ -58,6 +68,9 @@ RAYLIB_API void RaylibAMD_GetLastStats(RaylibAMDStats* outStats);
 
 /* 1 when a gfx950-capable HIP device is present and the kernels are loadable. */
 RAYLIB_API int32_t RaylibAMD_DeviceAvailable(void);
+/* 16 hex digits: SHA-256 prefix of the device sources + build flags this library was made from (software-raytracing_amd/Makefile BUILD_ID).
+ * Hardware-counter profiles kept under profiles/ carry the id of the library they were taken from; bench.py compares. */
+RAYLIB_API const char* RaylibAMD_BuildId(void);
 
 /*
  * Render the cells {cellFirst, cellFirst + cellStride, ...} (8x8-pixel cells numbered

@@ -60,7 +60,7 @@ bool RenderInternal(const RendererSettings* settings, Scene* scene, Camera* came
 	if (scene->hasMovingCubes && (scene->accelT0 != camera->beginTime || scene->accelT1 != camera->endTime)) {
 		// moving cubes: their boxes must cover the motion over THIS camera's shutter interval
 		if (scene->device) { DeviceReleaseScene(scene->device); scene->device = nullptr; }
-		scene->BuildAccel(camera->beginTime, camera->endTime);
+		if (!scene->BuildAccel(camera->beginTime, camera->endTime)) { Log("Raylib_Render: the acceleration structure could not be rebuilt for this camera's shutter interval"); return false; }
 	}
 	if (scene->sky && !g_images.contains(scene->sky)) {
 		// the reference would read freed memory here; a destroyed panorama is treated as none
@@ -267,12 +267,14 @@ void Raylib_Render(const RendererSettings* settings, SceneHandle scene, CameraHa
 	if (settings->viewportWidth != img->width || settings->viewportHeight != img->height)
 		img->Reallocate(settings->viewportWidth, settings->viewportHeight, 0.0f, 0.0f, 0.0f, 1.0f);   // renderer.cc:292-296
 	if ((size_t)img->width * img->height == 0) return;
-	void* dev = DeviceImagePixels(*img);   // the frame stays on the device: Raylib_PostProcess works on it there, and the host pixels
-	img->devValid = false;                 // are fetched when somebody asks for them (Raylib_DumpImageData, Raylib_WriteImageToDisk, ...)
-	img->hostStale = false;
+	// The frame stays on the device: Raylib_PostProcess works on it there, and the host pixels are fetched when somebody asks for them
+	// (Raylib_DumpImageData, Raylib_WriteImageToDisk, ...).  A render that is REFUSED (scene not finalized, invalid mode, no device)
+	// must leave the image as it was -- including a previous frame that still lives only on the device (hostStale): the image's state
+	// changes only on success.  (Every refusal happens before anything is enqueued; DeviceImagePixels keeps a buffer that is large enough.)
+	void* dev = DeviceImagePixels(*img);
 	if (!RenderInternal(settings, (Scene*)scene, (Camera*)camera, 0, 1, dev, dev ? nullptr : img->rgba.data()))
 		fprintf(stderr, "Raylib_Render: FAILED (no HIP device or invalid arguments); the image was not written\n");
-	else { img->devValid = (dev != nullptr); img->hostStale = (dev != nullptr); ++img->version; }
+	else { img->devValid = (dev != nullptr); img->hostStale = (dev != nullptr); img->Touch(); }
 }
 
 int32_t Raylib_Denoise(ImageHandle, int32_t, ImageHandle, ImageHandle, ImageHandle)
@@ -287,7 +289,7 @@ void Raylib_PostProcess(ImageHandle h)
 	if (!DevicePostProcess(*img)) {
 		Log("Raylib_PostProcess: no HIP device, running on the host");
 		PostProcessHost(*img);
-		++img->version;
+		img->Touch();
 	}
 }
 
@@ -316,6 +318,10 @@ void RaylibAMD_SetSeed(uint64_t seed) { std::lock_guard<std::mutex> lk(g_stateMu
 uint64_t RaylibAMD_GetSeed(void) { return CurrentSeed(); }
 void RaylibAMD_GetLastStats(RaylibAMDStats* out) { if (!out) return; std::lock_guard<std::mutex> lk(g_stateMu); *out = g_lastStats; }
 int32_t RaylibAMD_DeviceAvailable(void) { return DeviceAvailable() ? 1 : 0; }
+#ifndef RL_BUILD_ID
+#define RL_BUILD_ID "unknown"
+#endif
+const char* RaylibAMD_BuildId(void) { return RL_BUILD_ID; }
 
 uint32_t RaylibAMD_NumCells(uint32_t w, uint32_t h) { return ((w + 7) / 8) * ((h + 7) / 8); }
 uint64_t RaylibAMD_CellBufferFloats(uint32_t w, uint32_t h, uint32_t cellFirst, uint32_t cellStride)

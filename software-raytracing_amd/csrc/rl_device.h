@@ -162,7 +162,11 @@ struct DRenderParams {
 	uint32_t numJobs;          // numLocalCells * sampleCount * 64
 	uint32_t stackStride;      // threads in the grid (path-stack column count)
 	uint32_t rowMajorOutput;   // 1: out[y*W+x]; 0: out[localCell*64 + p]
-	uint32_t jobChunk;         // jobs a wave takes from the global counter per atomic
+	uint32_t jobChunk;         // jobs a wave takes from a head of the job list per atomic
+	uint32_t numHeads;         // heads of the job list: 8 (one per XCD) or 1; head h covers jobs [h, h + 1) * jobsPerHead (rl_render.hip TakeJobs)
+	uint32_t jobsPerHead;      // whole cells: a multiple of 64 * sampleCount
+	uint32_t guideShift;       // 0: every draw asks for jobChunk jobs; s > 0: at most (jobs left in the band at the wave's previous draw) >> s (TakeJobs)
+	uint32_t padQueue;
 	uint32_t magicSamples;     // floor(2^32 / sampleCount), floor(2^32 / cellsX): division by multiply-high in DecodeJob
 	uint32_t magicCellsX;
 	uint64_t seedMixed;        // raylib_rng_mix64(seed), hoisted out of the per-sample stream set-up

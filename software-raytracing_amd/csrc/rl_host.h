@@ -63,6 +63,7 @@ struct HostMaterial {
 };
 static_assert(sizeof(HostMaterial) == 76, "HostMaterial layout");
 
+uint64_t NextImageVersion();   // rl_image_io.cc: 1, 2, 3, ... over all images of the process
 struct Image {
 	uint32_t width = 0, height = 0;
 	std::vector<float> rgba;          // 4 floats per pixel, row 0 = top
@@ -75,11 +76,14 @@ struct Image {
 	bool hostStale = false;
 	// bumped whenever the pixels change (reallocation, a render into the image, PostProcess): a scene that uses the image as its
 	// sky panorama re-reads it at the next render, as the reference does through the handle (renderer.cc:159-176)
-	uint64_t version = 1;
+	// The value is unique in the PROCESS, not per image (NextImageVersion): a new image that malloc puts at a destroyed image's address
+	// can never look like that image to a cache keyed on (pointer, version) -- the device copy of the sky, rl_runtime.inl SyncSky.
+	uint64_t version = NextImageVersion();
+	void Touch() { version = NextImageVersion(); }
 	void SyncHost() const;
 	Image() = default;
 	Image(const Image& o) : width(o.width), height(o.height) { o.SyncHost(); rgba = o.rgba; }
-	Image& operator=(const Image& o) { o.SyncHost(); width = o.width; height = o.height; rgba = o.rgba; devValid = false; hostStale = false; ++version; return *this; }
+	Image& operator=(const Image& o) { o.SyncHost(); width = o.width; height = o.height; rgba = o.rgba; devValid = false; hostStale = false; Touch(); return *this; }
 	~Image();
 	void Reallocate(uint32_t w, uint32_t h, float r, float g, float b, float a);
 };

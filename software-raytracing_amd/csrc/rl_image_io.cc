@@ -17,7 +17,15 @@
 #include <zlib.h>
 #include <string>
 
+#include <atomic>
+
 namespace rl {
+
+uint64_t NextImageVersion()
+{
+	static std::atomic<uint64_t> next{1};
+	return next.fetch_add(1, std::memory_order_relaxed);
+}
 
 Image::~Image() { if (devPixels) DeviceFreePixels(devPixels); }
 
@@ -33,7 +41,7 @@ void Image::Reallocate(uint32_t w, uint32_t h, float r, float g, float b, float 
 {
 	SyncHost();
 	devValid = false;
-	++version;
+	Touch();
 	// reference render/image.cc:29-34: vector::resize keeps existing pixels, new ones get the clear colour
 	width = w; height = h;
 	size_t old = rgba.size() / 4, now = (size_t)w * h;

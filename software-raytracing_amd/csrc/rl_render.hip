@@ -55,6 +55,9 @@ __shared__ double rlm_lds_tab[80];
 namespace rl {
 
 #define RL_BLOCK 256
+#ifndef RL_LEAFBOX_V2
+#define RL_LEAFBOX_V2 0   /* the leaf list's box test in 2-cycle VALU instructions where it can (TraverseLeafList): experiment, see there */
+#endif
 #ifndef RL_REFILL_ROUNDS
 #define RL_REFILL_ROUNDS 4
 #endif
@@ -96,8 +99,8 @@ __device__ __forceinline__ bool isZero(V3 a) { return a.x == 0.0f && a.y == 0.0f
 // diagnostic build (-DRL_DIAG_TIMELINE=1, RAYLIB_PRINT_STAMPS=1): k_trace's waves record when they start, when they first find the
 // job queue empty and when they end (s_memrealtime, 100 MHz), three arrays of 8192 slots behind the counters
 #ifdef RL_DIAG_TIMELINE
-#define RL_TIMELINE_SLOTS (3 * 8192)
-#define RL_TIMELINE(which) { if (lane == 0 && (gtid >> 6) < 8192u) counters[CNT_COUNT + 24 + (which) * 8192 + (gtid >> 6)] = __builtin_amdgcn_s_memrealtime(); }
+#define RL_TIMELINE_SLOTS (4 * 8192)   /* start | job list seen empty | end | XCC id */
+#define RL_TIMELINE(which) { if (lane == 0 && (gtid >> 6) < 8192u) { counters[CNT_COUNT + 24 + (which) * 8192 + (gtid >> 6)] = __builtin_amdgcn_s_memrealtime(); if ((which) == 0) counters[CNT_COUNT + 24 + 3 * 8192 + (gtid >> 6)] = XccId(); } }
 #else
 #define RL_TIMELINE_SLOTS 0
 #define RL_TIMELINE(which)
@@ -610,6 +613,31 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const float4 nX = *(const float4*)(rec + oNX), fX = *(const float4*)(rec + oFX);
 			const float4 nY = *(const float4*)(rec + oNY), fY = *(const float4*)(rec + oFY);
 			const float4 nZ = *(const float4*)(rec + oNZ), fZ = *(const float4*)(rec + oFZ);
+#if RL_LEAFBOX_V2
+			// The gfx950 VALU issues v_fma / v_mul / v_add / v_sub_f32 and the plain 32-bit integer and / or / xor / add / shift-right in 2 cycles per
+			// wave64 and EVERYTHING else -- min, max, compares, selects, v_and_or -- in 4 (tools/valu_calib.hip, profiles/valu_calib.json), and this
+			// kernel sits on its VALU issue roof.  So with rayTMin >= 0 (every front-end's value; the other case keeps the first form):
+			//   entry = max(tMin, max3(x, y, z))          -- already >= 0: no second max for the key
+			//   exit  = min3(x, y, z)                     -- no clamp to FLT_MAX: +inf and (all three planes NaN: a ray without a direction) NaN pass as they did
+			//   culled <=> exit * widen - entry < 0, ONE fma whose sign bit, smeared over the word, is or-ed into the key (0xffffffff = no candidate)
+			// instead of max, max3, min, min3, mul, max, compare, select, and_or.  The fma compares the EXACT product with the entry where the first form
+			// compared the rounded one: a difference of one ulp of a test that is widened by 1e-5 (and 1e-6 wider than the candidate rule needs).
+			#define RL_LSLAB(k, slot) { \
+				const float tn = fmaxf(tMin, fmaxf(fmaxf(__builtin_fmaf(nX.k, invb.x, cn.x), __builtin_fmaf(nY.k, invb.y, cn.y)), __builtin_fmaf(nZ.k, invb.z, cn.z))); \
+				const float tf = fminf(fminf(__builtin_fmaf(fX.k, invb.x, cf.x), __builtin_fmaf(fY.k, invb.y, cf.y)), __builtin_fmaf(fZ.k, invb.z, cf.z)); \
+				const uint32_t culled = (uint32_t)(__float_as_int(__builtin_fmaf(tf, RL_BOX_WIDEN, -tn)) >> 31); \
+				key[slot] = (__float_as_uint(tn) & ~31u) | ((uint32_t)(slot) | culled); }
+			#define RL_LSLAB1(k, slot) { \
+				float tn = tMin, tf = FLT_MAX; \
+				tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = fminf(tf, __builtin_fmaf(fX.k, invb.x, cf.x)); \
+				tn = fmaxf(tn, __builtin_fmaf(nY.k, invb.y, cn.y)); tf = fminf(tf, __builtin_fmaf(fY.k, invb.y, cf.y)); \
+				tn = fmaxf(tn, __builtin_fmaf(nZ.k, invb.z, cn.z)); tf = fminf(tf, __builtin_fmaf(fZ.k, invb.z, cf.z)); \
+				if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(fmaxf(tn, 0.0f)) & ~31u) | (uint32_t)(slot); }
+			if (tMin >= 0.0f) { RL_LSLAB(x, 4 * g) RL_LSLAB(y, 4 * g + 1) RL_LSLAB(z, 4 * g + 2) RL_LSLAB(w, 4 * g + 3) }
+			else { RL_LSLAB1(x, 4 * g) RL_LSLAB1(y, 4 * g + 1) RL_LSLAB1(z, 4 * g + 2) RL_LSLAB1(w, 4 * g + 3) }
+			#undef RL_LSLAB
+			#undef RL_LSLAB1
+#else
 			#define RL_LSLAB(k, slot) { \
 				float tn = tMin, tf = FLT_MAX; \
 				tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = fminf(tf, __builtin_fmaf(fX.k, invb.x, cf.x)); \
@@ -618,6 +646,7 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 				if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(fmaxf(tn, 0.0f)) & ~31u) | (uint32_t)(slot); }
 			RL_LSLAB(x, 4 * g) RL_LSLAB(y, 4 * g + 1) RL_LSLAB(z, 4 * g + 2) RL_LSLAB(w, 4 * g + 3)
 			#undef RL_LSLAB
+#endif
 		}
 	}
 	uint32_t from = 0u;   // keys below this one are done (keys are distinct: the slot is part of the key)
@@ -1180,6 +1209,12 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 	uint32_t cellLocal = __umulhi(rest, P.magicSamples);
 	uint32_t sLocal = rest - cellLocal * P.sampleCount;
 	while (sLocal >= P.sampleCount) { sLocal -= P.sampleCount; ++cellLocal; }
+#ifdef RL_EXP_STRIPS
+	{   // experiment (whole frames whose cell columns divide by the heads only): a head's cells are a vertical STRIP of the frame, walked row by row
+		const uint32_t cph = P.jobsPerHead / (P.sampleCount * 64u), hh = cellLocal / cph, ii = cellLocal % cph, sw = P.cellsX / P.numHeads;
+		cellLocal = (ii / sw) * P.cellsX + hh * sw + ii % sw;
+	}
+#endif
 	const uint32_t cell = P.cellFirst + cellLocal * P.cellStride;
 	uint32_t cy = __umulhi(cell, P.magicCellsX);
 	uint32_t cx = cell - cy * P.cellsX;
@@ -1189,6 +1224,72 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 	j.sample = sLocal;
 	j.valid = (j.x < P.width) && (j.y < P.height);
 	return j;
+}
+
+// ---------------------------------------------------------------------------
+// The job list, sharded over the chip's XCDs.  An MI355X is 8 XCDs with a private, non-coherent 4 MiB L2 each; workgroups are dealt
+// round-robin over them (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement").  The job list (cell-major: all samples of local cell 0,
+// then cell 1, ...) is cut into P.numHeads contiguous ranges of P.jobsPerHead jobs -- whole cells, so a range is a horizontal BAND of the
+// frame (of this rank's cells) -- each behind a head word of its own, 128 bytes apart.  A wave draws from the head of the XCD it runs
+// on (s_getreg HW_REG_XCC_ID): the camera rays an XCD's L2 sees come from one eighth of the image, i.e. they walk one region's part of
+// the tree and its triangles, and eight words share the atomic traffic that one hot address took before.  When its own band is used up
+// a wave steals from the band with the most jobs left (eight sc1 loads by eight lanes, a 3-step lane max), so the launch's end is
+// worked on by everybody.  Heads count RELATIVE to their band's first job, so the host resets the whole queue with one memset.
+// Results cannot depend on any of this: streams are keyed by (seed, pixel, sample).
+// The reference's analogue is the single LIFO work queue of core/thread_pool.cc:93-112.
+#define RL_HEAD_STRIDE 32u   /* uint32 words between two heads (128 B: one L2 line each) */
+#define RL_MAX_HEADS 8u
+__device__ __forceinline__ uint32_t XccId()
+{
+	return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // GETREG_IMMED(size - 1 = 3, offset 0, XCC_ID = 20): bits 3:0 of XCC_ID
+}
+struct JobSource { uint32_t cur, dry, left; };   // wave-uniform: the head this wave draws from; bit h: head h is known to be used up (it stays so); jobs that were left in `cur` after this wave's last draw
+__device__ __forceinline__ JobSource JobSourceInit(const DRenderParams& P)
+{
+	JobSource js; js.cur = P.numHeads > 1u ? XccId() % P.numHeads : 0u; js.dry = 0u; js.left = 0xffffffffu;
+	return js;
+}
+__device__ __forceinline__ uint32_t HeadLength(const DRenderParams& P, uint32_t h)
+{
+	const uint32_t first = h * P.jobsPerHead;   // (numHeads * jobsPerHead stays below 2^32: host side)
+	return first < P.numJobs ? min(P.jobsPerHead, P.numJobs - first) : 0u;
+}
+// `want` (a multiple of 64) consecutive jobs for this wave: true with [base, end) set, false when every band is used up.  Wave-uniform.
+__device__ __forceinline__ bool TakeJobs(const DRenderParams& P, unsigned int* __restrict__ heads, JobSource& js, uint32_t want, uint32_t lane, uint32_t& base, uint32_t& end)
+{
+	for (;;) {
+		const uint32_t len = HeadLength(P, js.cur);
+		// The end of a band in smaller pieces (P.guideShift > 0): a draw is at most 1 / 2^guideShift of what was left in the band after this
+		// wave's previous draw there -- about half of "what is left / waves drawing from it" -- so that when the list runs dry a wave
+		// holds a few batches, not a whole chunk of what may be the frame's dearest cells.  No extra read of the head: the size comes from
+		// the wave's own last atomic (a stale upper bound: the band only shrinks).
+		uint32_t ask = want;
+		if (P.guideShift) ask = min(want, max(64u, (js.left >> P.guideShift) & ~63u));
+		uint32_t rel = 0;
+		if (lane == 0) rel = atomicAdd(&heads[js.cur * RL_HEAD_STRIDE], ask);
+		rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
+		if (rel < len) {
+			base = js.cur * P.jobsPerHead + rel; end = base + min(ask, len - rel);
+			js.left = len - rel - min(ask, len - rel);
+			return true;
+		}
+		js.dry |= 1u << js.cur;
+		if (P.numHeads <= 1u) return false;
+		// the fullest of the other bands.  A head only grows, so a stale value can only make a band look fuller than it is: the atomic
+		// above then says so and the band is marked; "every band looks used up" is never wrong.
+		uint32_t key = 0;
+		if (lane < P.numHeads && !((js.dry >> lane) & 1u)) {
+			const uint32_t nx = __hip_atomic_load(&heads[lane * RL_HEAD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t ln = HeadLength(P, lane);
+			key = nx < ln ? ((ln - nx) | lane) : 0u;   // jobs left (a multiple of 64) with the head's number in the low bits
+		}
+		key = max(key, (uint32_t)__shfl_xor((int)key, 1));
+		key = max(key, (uint32_t)__shfl_xor((int)key, 2));
+		key = max(key, (uint32_t)__shfl_xor((int)key, 4));
+		key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+		if (key < 64u) return false;
+		js.cur = key & 7u; js.left = key & ~63u;
+	}
 }
 
 __device__ __forceinline__ void WaveLdsSync()
@@ -1231,11 +1332,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 	// LDS == 2: the workgroup's four waves draw their batches of 64 jobs from ONE chunk (low word: next job, high word: end of the chunk)
 	__shared__ unsigned long long s_jobs;
 	__shared__ unsigned int s_lock, s_done;
-	if (LDS == 2 && threadIdx.x == 0) {
-		const uint32_t first = min(blockIdx.x * P.jobChunk, P.numJobs);
-		s_jobs = (unsigned long long)first | ((unsigned long long)min(first + P.jobChunk, P.numJobs) << 32);
-		s_lock = 0u; s_done = 0u;
-	}
+	if (LDS == 2 && threadIdx.x == 0) { s_jobs = 0ull; s_lock = 0u; s_done = 0u; }   // empty: the first wave to ask draws the workgroup's first chunk from its XCD's head
 #endif
 	if (LDS) {
 		const uint32_t nN = (uint32_t)(LDS == 2 ? S.numLeafRecords : S.numNodes4) * 8u, nT = (uint32_t)S.numTriangles * 4u, nM = (uint32_t)S.numMaterials * 5u;
@@ -1275,10 +1372,10 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 	// with ONE atomic and deals them to its lanes itself.  (A returning atomic on one address
 	// saturates near 88 dequeues/us chip-wide -- MI355X_MICROARCH.md "dequeue" -- and one atomic
 	// per wave and bounce was exactly that rate: the kernel ran at the atomic's speed.)
-	// Every wave's FIRST chunk is its own (wave w: jobs [w, w + 1) x jobChunk) and the counter starts behind those (host side): 4096 waves asking the
-	// one counter at the same instant stand in line for ~45 us, which is 2 % of what one of 8 ranks renders of the Cornell frame
-	uint32_t chunkNext = min((blockIdx.x * (RL_BLOCK / 64u) + (threadIdx.x >> 6)) * P.jobChunk, P.numJobs), chunkEnd = min(chunkNext + P.jobChunk, P.numJobs);
-	if (LDS == 2 && RL_QUEUE_SHARED_CHUNK) chunkNext = chunkEnd = 0;   // there the first chunk is the workgroup's (s_jobs)
+	// (Round 2 gave every wave its first chunk without an atomic, because 4096 waves asking ONE counter at the same instant stood in line for ~45 us; with a
+	// head per XCD the line is an eighth as long and the first chunk comes from the wave's own band like every other.)
+	uint32_t chunkNext = 0, chunkEnd = 0;
+	JobSource js = JobSourceInit(P);
 	bool globalDone = false;
 	uint32_t qCount = 0;   // LDS == 2: camera rays waiting in the wave's queue
 	RL_TIMELINE(0);
@@ -1344,12 +1441,11 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 						const unsigned long long cur = __atomic_load_n(&s_jobs, __ATOMIC_RELAXED);
 						if ((uint32_t)cur >= (uint32_t)(cur >> 32) && __atomic_load_n(&s_done, __ATOMIC_RELAXED) == 0u) {   // still used up: nobody refilled it in between
-							uint32_t base = 0;
-							if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
-							base = __shfl(base, 0);
+							uint32_t base = 0, bend = 0;
+							const bool got = TakeJobs(P, jobCounter, js, P.jobChunk, lane, base, bend);
 							if (lane == 0) {
-								if (base >= P.numJobs) __atomic_store_n(&s_done, 1u, __ATOMIC_RELAXED);
-								else __atomic_store_n(&s_jobs, (unsigned long long)base | ((unsigned long long)min(base + P.jobChunk, P.numJobs) << 32), __ATOMIC_RELAXED);
+								if (!got) __atomic_store_n(&s_done, 1u, __ATOMIC_RELAXED);
+								else __atomic_store_n(&s_jobs, (unsigned long long)base | ((unsigned long long)bend << 32), __ATOMIC_RELAXED);
 							}
 						}
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1365,11 +1461,9 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 						while (__atomic_load_n(&s_lock, __ATOMIC_RELAXED) != 0u && ++spins < RL_QUEUE_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
 						if (spins >= RL_QUEUE_SPIN_LIMIT) {
 #endif
-							uint32_t base = 0;
-							if (lane == 0) base = atomicAdd(jobCounter, 64u);
-							base = __shfl(base, 0);
-							if (base >= P.numJobs) { globalDone = true; chunkNext = chunkEnd = 0; }
-							else { chunkNext = base; chunkEnd = min(base + 64u, P.numJobs); }
+							uint32_t base = 0, bend = 0;
+							if (!TakeJobs(P, jobCounter, js, 64u, lane, base, bend)) { globalDone = true; chunkNext = chunkEnd = 0; }
+							else { chunkNext = base; chunkEnd = bend; }
 							break;
 						}
 					}
@@ -1377,11 +1471,9 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 				if (globalDone) { RL_TIMELINE(1); break; }
 #else
 				if (chunkNext >= chunkEnd) {
-					uint32_t base = 0;
-					if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
-					base = __shfl(base, 0);
-					if (base >= P.numJobs) { globalDone = true; RL_TIMELINE(1); break; }
-					chunkNext = base; chunkEnd = min(base + P.jobChunk, P.numJobs);
+					uint32_t base = 0, bend = 0;
+					if (!TakeJobs(P, jobCounter, js, P.jobChunk, lane, base, bend)) { globalDone = true; RL_TIMELINE(1); break; }
+					chunkNext = base; chunkEnd = bend;
 				}
 #endif
 				const uint32_t avail = chunkEnd - chunkNext;
@@ -1450,11 +1542,9 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 			const unsigned long long mask = __ballot(need);
 			if (mask == 0ull) break;
 			if (chunkNext >= chunkEnd && !globalDone) {
-				uint32_t base = 0;
-				if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
-				base = __shfl(base, 0);
-				if (base >= P.numJobs) { globalDone = true; RL_TIMELINE(1); }
-				else { chunkNext = base; chunkEnd = min(base + P.jobChunk, P.numJobs); }
+				uint32_t base = 0, bend = 0;
+				if (!TakeJobs(P, jobCounter, js, P.jobChunk, lane, base, bend)) { globalDone = true; RL_TIMELINE(1); }
+				else { chunkNext = base; chunkEnd = bend; }
 			}
 			const uint32_t avail = chunkEnd - chunkNext;
 			if (need) {
@@ -1906,10 +1996,15 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 	bool stActive[K];
 	#pragma unroll
 	for (int p = 0; p < K; ++p) { stRng[p] = 0; stOut[p] = 0; stDepth[p] = 0; stActive[p] = false; pool[F_TRI][p * 64 + lane] = __int_as_float(Q_EMPTY); }
-	// Every wave's FIRST chunk is its own (wave w: jobs [w, w + 1) x jobChunk) and the counter starts behind those (host side): 4096 waves asking the
-	// one counter at the same instant stand in line for ~45 us, which is 2 % of what one of 8 ranks renders of the Cornell frame
-	uint32_t chunkNext = min((blockIdx.x * (RL_BLOCK / 64u) + (threadIdx.x >> 6)) * P.jobChunk, P.numJobs), chunkEnd = min(chunkNext + P.jobChunk, P.numJobs);
+	// (Round 2 gave every wave its first chunk without an atomic, because 4096 waves asking ONE counter at the same instant stood in line for ~45 us; with a
+	// head per XCD the line is an eighth as long and the first chunk comes from the wave's own band like every other.)
+	uint32_t chunkNext = 0, chunkEnd = 0;
+	JobSource js = JobSourceInit(P);
 	bool globalDone = false, exhausted = false;   // wave-uniform
+#ifdef RL_DIAG_TIMELINE
+	const uint32_t gtid = blockIdx.x * RL_BLOCK + threadIdx.x;
+#endif
+	RL_TIMELINE(0);
 	uint32_t surviveQ8 = 256u;                    // share of freshly generated camera samples that reached a pool slot, x 256 (wave-uniform)
 	// traversal state of the ray this lane is tracing; survives trips (a straggler keeps going while the rest of the pool is shaded)
 	bool busy = false;
@@ -1968,11 +2063,9 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 			uint32_t filled = 0;
 			for (int round = 0; round < RL_REFILL_ROUNDS && filled < nFree; ++round) {
 				if (chunkNext >= chunkEnd && !globalDone) {
-					uint32_t base = 0;
-					if (lane == 0) base = atomicAdd(jobCounter, P.jobChunk);
-					base = __shfl(base, 0);
-					if (base >= P.numJobs) globalDone = true;
-					else { chunkNext = base; chunkEnd = min(base + P.jobChunk, P.numJobs); }
+					uint32_t base = 0, bend = 0;
+					if (!TakeJobs(P, jobCounter, js, P.jobChunk, lane, base, bend)) { globalDone = true; RL_TIMELINE(1); }
+					else { chunkNext = base; chunkEnd = bend; }
 				}
 				const uint32_t avail = chunkEnd - chunkNext;
 				if (avail == 0) { exhausted = true; break; }
@@ -2265,6 +2358,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 #ifdef RL_DIAG_STAMPS
 	if (lane == 0) for (int k = 0; k < 4; ++k) { atomicAdd(&counters[CNT_COUNT + k], stampAcc[k]); atomicAdd(&counters[CNT_COUNT + 12 + k], c.tAcc[k]); }
 #endif
+	RL_TIMELINE(2);
 	uint32_t vals[CNT_COUNT] = { c.rays, c.nodes, c.tris, c.shaded, c.texels, c.samples, c.trips };
 	for (int k = 0; k < CNT_COUNT; ++k) {
 		unsigned long long v = vals[k];

@@ -80,7 +80,7 @@ struct Worker {
 struct RankCtx {
 	int rank = 0, device = 0, devSlot = 0, numCUs = 0;
 	hipStream_t stream = nullptr;
-	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // 0/1 render, 2/3 megakernel, 4 "my cells are on rank 0's device"
+	hipEvent_t ev[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // 0/1 render, 2/3 megakernel, 4 "my cells are on rank 0's device", (rank 0) 5 every rank's cells are here, 6 frame assembled
 	// reusable work buffers
 	SampleRGB* samples = nullptr; size_t samplesBytes = 0;
 	float4* accum = nullptr; size_t accumBytes = 0;
@@ -148,9 +148,9 @@ bool EnsureRuntime()
 		HIP_OK(hipGetDeviceProperties(&prop, C->device));
 		C->numCUs = prop.multiProcessorCount;
 		HIP_OK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
-		for (int i = 0; i < 5; ++i) HIP_OK(hipEventCreate(&C->ev[i]));
+		for (int i = 0; i < 7; ++i) HIP_OK(hipEventCreate(&C->ev[i]));
 		HIP_OK(hipMalloc(&C->counters, (CNT_COUNT + 24 + RL_TIMELINE_SLOTS) * sizeof(unsigned long long)));
-		HIP_OK(hipMalloc(&C->jobCounter, sizeof(unsigned int)));
+		HIP_OK(hipMalloc(&C->jobCounter, RL_MAX_HEADS * RL_HEAD_STRIDE * sizeof(unsigned int)));   // the heads of the job list, one per XCD, 128 B apart
 		if (r > 0) { C->worker = new Worker; C->worker->Start(C->device); }
 		R.ranks.push_back(C);
 		Log("raylib(MI355X): rank %d of %d on device %d %s (%s), %d CUs", r, n, C->device, prop.name, prop.gcnArchName, C->numCUs);
@@ -177,7 +177,11 @@ bool EnsureRccl()
 	RcclApi& A = R.rccl;
 	if (A.tried) return A.ok;
 	A.tried = true;
-	A.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+	// an RCCL the process already holds (a PyTorch process loads its own) is used as it is: two copies of the library in one process would each
+	// keep their own device state
+	A.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+	if (!A.lib) A.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+	if (!A.lib) A.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
 	if (!A.lib) A.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
 	if (!A.lib) { Log("raylib(MI355X): librccl could not be loaded (%s); the gather uses peer copies", dlerror()); return false; }
 	A.CommInitAll = (int (*)(void**, int, const int*))dlsym(A.lib, "ncclCommInitAll");
@@ -436,7 +440,7 @@ struct PendingRender {
 	RankCtx* ctx = nullptr;
 	bool pathTrace = false, lastBatchPending = false;
 	float traceMs = 0.0f;
-	uint32_t launches = 0, schedulePaths = 1;
+	uint32_t launches = 0, schedulePaths = 1, jobHeads = 0;
 	uint64_t pixels = 0;
 	float4* out = nullptr; size_t outBytes = 0;
 	unsigned long long cnt[CNT_COUNT + 24];
@@ -544,7 +548,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 			P.sampleBegin = s0; P.sampleCount = cnt;
 			P.magicSamples = cnt > 1 ? (uint32_t)(0x100000000ull / cnt) : 0xFFFFFFFFu;
 			const uint64_t jobs64 = (uint64_t)numLocalCells * cnt * 64u;
-			if (jobs64 > 0xFFFFFF00ull) { Log("Raylib_Render: job count overflow"); return false; }
+			if (jobs64 > 0xF0000000ull) { Log("Raylib_Render: job count overflow"); return false; }   // (a head overshoots its band by one chunk per wave and attempt)
 			P.numJobs = (uint32_t)jobs64;
 			uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)R.numCUs * blocksPerCU, (jobs64 + RL_BLOCK * pathsPerThread - 1) / (RL_BLOCK * pathsPerThread));
 			if (blocks < 1) blocks = 1;
@@ -556,6 +560,14 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				uint64_t chunk = ((jobs64 / (waves * 16)) + 32) & ~63ull;
 				if (const char* e = getenv("RAYLIB_JOB_CHUNK")) chunk = (uint64_t)atoi(e);
 				P.jobChunk = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, chunk));
+				// The pool schedule's jobs differ by two orders of magnitude (a cell that misses the scene's root box against one full of geometry): the launch's
+				// tail is what a wave needs for its LAST chunk, and on the 298 k-triangle frame a chunk of 1024 heavy jobs is 6 ms of a 45 ms launch (wave timeline,
+				// tools/gpu_timeline_pool.py: first wave out of jobs at 39.7 ms, last at 46.0).  One head took chunks no smaller than 1024 (256: 48.1 ms, the atomic's
+				// queue); with a head per XCD 256 is the best: 1024 -> 46.5 ms, 512 -> 45.0, 256 -> 44.0, 128 -> 44.0, 64 -> 48.4 (one head, 1024: 44.9).
+				if (poolK > 0 && !getenv("RAYLIB_JOB_CHUNK")) {
+					uint32_t h = RL_MAX_HEADS; if (const char* e = getenv("RAYLIB_JOB_HEADS")) h = (uint32_t)std::max(1, atoi(e));
+					if (h >= 4) P.jobChunk = std::min<uint32_t>(P.jobChunk, 256u);
+				}
 				// the leaf-list kernel's chunk belongs to a workgroup, whose four waves draw batches of 64 from it (RL_QUEUE_SHARED_CHUNK): four waves' worth,
 				// RAYLIB_JOB_CHUNK_MAX (default 1024) at most
 				if (RL_QUEUE_SHARED_CHUNK && traceKernel == (TraceKernel)k_trace<16, false, true, 2> && !getenv("RAYLIB_JOB_CHUNK")) {
@@ -564,11 +576,21 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				}
 			}
 			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
-			{   // the counter starts behind the waves' own first chunks (rl_render.hip: chunkNext at kernel start)
-				// (the leaf-list kernel's first chunks are per workgroup: its waves share one, RL_QUEUE_SHARED_CHUNK)
-				const bool perBlock = RL_QUEUE_SHARED_CHUNK && traceKernel == (TraceKernel)k_trace<16, false, true, 2>;
-				const uint64_t first = (uint64_t)blocks * (perBlock ? 1 : RL_BLOCK / 64) * P.jobChunk;
-				HIP_OK(hipMemsetD32Async((hipDeviceptr_t)R.jobCounter, (int)(uint32_t)std::min<uint64_t>(first, 0xFFFFFF00ull), 1, R.stream));
+			{   // the job list in bands of whole cells, one head per XCD (rl_render.hip TakeJobs); heads count from their band's first job: one memset
+				uint32_t heads = RL_MAX_HEADS; if (const char* e = getenv("RAYLIB_JOB_HEADS")) heads = (uint32_t)std::min<int>((int)RL_MAX_HEADS, std::max(1, atoi(e)));
+				const uint32_t cellsPerHead = (numLocalCells + heads - 1) / heads;
+				heads = (numLocalCells + cellsPerHead - 1) / cellsPerHead;   // no empty band: every head's first job exists (and h * jobsPerHead < numJobs < 2^32)
+				P.numHeads = heads; P.jobsPerHead = cellsPerHead * cnt * 64u;
+				{   // guided draws at the end of a band: 2^shift ~ twice the drawers per head (waves; workgroups in the leaf-list kernel, whose chunk is shared)
+					const bool perBlockChunk = RL_QUEUE_SHARED_CHUNK && traceKernel == (TraceKernel)k_trace<16, false, true, 2>;
+					const uint32_t drawers = std::max(1u, blocks * (perBlockChunk ? 1u : (uint32_t)(RL_BLOCK / 64)) / heads);
+					uint32_t shift = 1; while ((1u << shift) < 2u * drawers && shift < 24u) ++shift;
+					int guided = 0;   // measured: no gain on either bench workload -- a heavy chunk drawn three rounds before the end outlasts the guided ones
+					if (const char* e = getenv("RAYLIB_GUIDED")) guided = atoi(e);
+					P.guideShift = guided > 0 ? shift + (uint32_t)(guided - 1) : 0u;
+				}
+				pend.jobHeads = heads;
+				HIP_OK(hipMemsetAsync(R.jobCounter, 0, RL_MAX_HEADS * RL_HEAD_STRIDE * sizeof(unsigned int), R.stream));
 			}
 			HIP_OK(hipEventRecord(R.ev[2], R.stream));
 			hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
@@ -632,6 +654,8 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 	stats.kernelMs = std::max(stats.kernelMs, (double)totalMs);
 	stats.traceKernelMs = std::max(stats.traceKernelMs, (double)(pend.pathTrace ? pend.traceMs : totalMs));
 	stats.traceLaunches = std::max(stats.traceLaunches, pend.pathTrace ? pend.launches : 1u);
+	if (R.rank >= 0 && R.rank < 16) { stats.rankKernelMs[R.rank] = (double)totalMs; stats.rankTraceMs[R.rank] = (double)(pend.pathTrace ? pend.traceMs : totalMs); }
+	if (pend.jobHeads) stats.jobHeads = pend.jobHeads;
 #ifdef RL_DIAG_TIMELINE
 	if (getenv("RAYLIB_PRINT_STAMPS")) {
 		std::vector<unsigned long long> tl(RL_TIMELINE_SLOTS);
@@ -643,6 +667,11 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 		auto pct = [](std::vector<double>& v, double q) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
 		Log("timeline (us from the first wave's start; last launch, %d waves): start p50 %.1f max %.1f | queue seen empty min %.1f p50 %.1f max %.1f | end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f",
 			(int)st.size(), pct(st, 0.5), pct(st, 1.0), pct(ex, 0.0), pct(ex, 0.5), pct(ex, 1.0), pct(en, 0.0), pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), pct(en, 1.0));
+		for (unsigned x = 0; x < 8; ++x) {   // per XCD: which waves ran there, when they found the job list empty, when they ended
+			std::vector<double> xe, xn;
+			for (int w = 0; w < 8192; ++w) if (tl[w] && tl[24576 + w] == x) { if (tl[8192 + w]) xe.push_back((tl[8192 + w] - t0) * 0.01); xn.push_back((tl[16384 + w] - t0) * 0.01); }
+			if (!xn.empty()) Log("   XCC %u: %d waves | job list seen empty min %.1f p50 %.1f max %.1f | end min %.1f p50 %.1f max %.1f", x, (int)xn.size(), pct(xe, 0.0), pct(xe, 0.5), pct(xe, 1.0), pct(xn, 0.0), pct(xn, 0.5), pct(xn, 1.0));
+		}
 	}
 #endif
 	if (getenv("RAYLIB_PRINT_STAMPS")) {
@@ -723,11 +752,15 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		if (rc != 0 || rcEnd != 0) { Log("Raylib_Render: RCCL gather failed (%s)", A.GetErrorString ? A.GetErrorString(rc ? rc : rcEnd) : "?"); ok = false; }
 		(void)hipSetDevice(R0.device);
 	}
+	bool timed = false;
 	if (ok) {
 		for (int r = 1; r < N; ++r) HIP_OK(hipStreamWaitEvent(R0.stream, R.ranks[(size_t)r]->ev[4], 0));
+		HIP_OK(hipEventRecord(R0.ev[5], R0.stream));
 		const uint32_t blocks = (uint32_t)(((size_t)W * H + RL_BLOCK - 1) / RL_BLOCK);
 		hipLaunchKernelGGL(k_scatter_cells, dim3(blocks), dim3(RL_BLOCK), 0, R0.stream, (const float4*)R.gather, out, W, H, cellsX, plan);
 		HIP_OK(hipGetLastError());
+		HIP_OK(hipEventRecord(R0.ev[6], R0.stream));
+		timed = true;
 		if (req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, frameBytes, hipMemcpyDeviceToHost, R0.stream));
 	}
 	// every rank's stream is drained whatever happened (the closures above borrow this frame's stack)
@@ -736,6 +769,13 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		else { (void)hipSetDevice(R.ranks[(size_t)r]->device); (void)hipStreamSynchronize(R.ranks[(size_t)r]->stream); }
 	}
 	HIP_OK(hipSetDevice(R0.device));
+	stats.gatherMode = !anyRemote ? 0u : (useRccl ? 1u : 2u);
+	stats.rcclCommSize = R.rccl.ok ? (uint32_t)R.rccl.comms.size() : 0u;
+	if (ok && timed) {   // rank 0's stream is drained: its render-end event, "all cells here" and "frame assembled" have fired
+		float g = 0.0f, s = 0.0f;
+		if (hipEventElapsedTime(&g, R0.ev[1], R0.ev[5]) == hipSuccess) stats.gatherMs = (double)g;
+		if (hipEventElapsedTime(&s, R0.ev[5], R0.ev[6]) == hipSuccess) stats.scatterMs = (double)s;
+	}
 	return ok;
 }
 
@@ -766,13 +806,14 @@ bool DeviceRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	if (whole && (g_rt.ranks.size() > 1 || g_rt.gatherSelf)) {
 		ok = RenderMulti(sc, req, stats);
 		stats.ranks = (uint32_t)g_rt.ranks.size();
+		stats.devices = (uint32_t)g_rt.devices.size();
 	} else {
 		PendingRender pend;
 		ok = EnqueueDispatch(Rank0(), sc, req, pend);
 		if (ok && req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, pend.out, pend.outBytes, hipMemcpyDeviceToHost, Rank0().stream));
 		if (pend.ctx) ok = FinishRender(pend, stats) && ok;
 		else (void)hipStreamSynchronize(Rank0().stream);
-		stats.ranks = 1;
+		stats.ranks = 1; stats.devices = 1;
 	}
 	stats.numNodes = (uint32_t)sc.bvh.nodes.size(); stats.numTriangles = (uint32_t)sc.triangles.size(); stats.bvhDepth = sc.bvh.depth;
 	stats.wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -918,7 +959,7 @@ bool DevicePostProcess(Image& img)
 	HIP_OK(hipStreamSynchronize(R.stream));
 	img.devValid = true;
 	img.hostStale = true;   // read back when the pixels are asked for (Image::SyncHost)
-	++img.version;
+	img.Touch();
 	Log("Max white luminance: %f", white);
 	return true;
 }

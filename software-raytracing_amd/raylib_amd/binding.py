@@ -28,10 +28,18 @@ class Stats(C.Structure):
                 ("shadedHits", C.c_uint64), ("texFetches", C.c_uint64), ("cameraSamples", C.c_uint64),
                 ("pixels", C.c_uint64), ("kernelMs", C.c_double), ("traceKernelMs", C.c_double), ("wallMs", C.c_double),
                 ("traceLaunches", C.c_uint32), ("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("bvhDepth", C.c_uint32),
-                ("waveTrips", C.c_uint64), ("pathsPerWave", C.c_uint32), ("ranks", C.c_uint32)]
+                ("waveTrips", C.c_uint64), ("pathsPerWave", C.c_uint32), ("ranks", C.c_uint32),
+                ("gatherMode", C.c_uint32), ("rcclCommSize", C.c_uint32), ("devices", C.c_uint32), ("jobHeads", C.c_uint32),
+                ("gatherMs", C.c_double), ("scatterMs", C.c_double), ("rankKernelMs", C.c_double * 16), ("rankTraceMs", C.c_double * 16)]
+
+    GATHER_MODES = {0: "none", 1: "rccl", 2: "peer"}
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["rankKernelMs"] = list(self.rankKernelMs)[: max(1, self.ranks)]
+        d["rankTraceMs"] = list(self.rankTraceMs)[: max(1, self.ranks)]
+        d["gatherMode"] = self.GATHER_MODES.get(self.gatherMode, "?")
+        return d
 
 
 # Per-ray / per-unit algorithmic byte constants of the flat layout (csrc/rl_device.h)
@@ -84,6 +92,7 @@ _EXPORTS = {
     "RaylibAMD_GetSeed": (C.c_uint64, []),
     "RaylibAMD_GetLastStats": (None, [C.POINTER(Stats)]),
     "RaylibAMD_DeviceAvailable": (C.c_int32, []),
+    "RaylibAMD_BuildId": (C.c_char_p, []),
     "RaylibAMD_RenderDevice": (C.c_int32, [C.POINTER(RendererSettings), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "RaylibAMD_RenderCellsHost": (C.c_int32, [C.POINTER(RendererSettings), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "RaylibAMD_CellBufferFloats": (C.c_uint64, [C.c_uint32] * 4),

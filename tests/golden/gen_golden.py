@@ -102,6 +102,30 @@ def main(only=None):
             print("bench windows", wl, len(pos), "of", len(wins))
         np.savez_compressed(os.path.join(HERE, "bench_windows.npz"), **out)
 
+    # ---- statistics of the UNTOUCHED reference (oracle/_ref/libref_native.so: its own std::random_device RNG, core/random.h:17-29) ----
+    # Every other fixture goes through the determinism overlay (oracle/ref_shim/core/random.h).  This one pins the link the overlay
+    # cannot: that the seeded stream contract samples the same distribution as the reference's own generator in the reference's own
+    # draw order (core/random.cc:3-50, renderer.cc:210-248).  RUNS independent renders of SPP samples each; per pixel and channel the
+    # mean of the run means and their standard deviation (ddof = 1) -> standard error of the mean = std / sqrt(RUNS).
+    if want("native_stats"):
+        native = ffi.load_ref(False)
+        assert native is not None, "build oracle/_ref first (make -C oracle ref)"
+        RUNS, SPP, W = 16, 512, 64
+        out = {"runs": np.array(RUNS), "spp_per_run": np.array(SPP)}
+        for name in ("cornell", "cornell_glass_sun", "pbr_maps", "cutout_sky"):
+            obj, c, flat = helpers.flat_for_case(name, tmp, orc)
+            scene = native.scene_create(flat, BUILD_SEED)
+            cam = helpers.camera_for_case(c)
+            st = ffi.make_settings(W, W, SPP)
+            runs = np.stack([native.render_native(scene, cam, st)[..., :3].astype(np.float64) for _ in range(RUNS)])
+            out[name + "_mean"] = runs.mean(0).astype(np.float32)
+            out[name + "_std"] = runs.std(0, ddof=1).astype(np.float32)
+            # what the seeded contract gives on the same statistic (the GPU must produce exactly these bits): printed, not stored
+            seeded_scene = ref.scene_create(flat, BUILD_SEED)
+            seeded = np.stack([ref.render(seeded_scene, cam, st, seed=SEED + k) for k in range(RUNS)])
+            print("native_stats", name, helpers.z_statistics(seeded, out[name + "_mean"], out[name + "_std"], RUNS))
+        np.savez_compressed(os.path.join(HERE, "native_stats.npz"), **out)
+
     if only is not None and not (want("procedural") or want("kat") or want("soup")):
         return
     # ---- procedural scene: spheres, a moving cube, Metal / DiffuseLight / Dielectric / Mirror -----------------------

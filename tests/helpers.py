@@ -128,6 +128,36 @@ def l2(a, b):
     return float(np.sqrt((d * d).sum(-1).mean())) if len(d) else 0.0
 
 
+def z_statistics(run_images, ref_mean, ref_std, runs):
+    """`runs` independent renders (different seeds, the same samples per pixel each) by the renderer under test against the statistics of
+    `runs` independent renders of the UNTOUCHED reference (tests/golden/native_stats.npz: per pixel and channel the mean and the standard
+    deviation of the run means).  If -- and only if -- both sample the same per-sample distribution, the two sets of run means are two
+    samples of one distribution, so the difference of their means is SYMMETRIC around 0 whatever that distribution's skew (path-traced
+    pixels are heavy-tailed: a one-sample z against the reference mean is biased by the skew, measured: 14 sigma on the Cornell box).
+        z = (mean_here - mean_ref) / sqrt((var_here + var_ref) / runs)
+    Returned: summaries over the pixels that vary on either side (n of them): mean z and the share of positive differences (both
+    centred under the hypothesis, with standard errors ~1.1 / sqrt(n) and 0.5 / sqrt(n)), the median |z| (0.68 for a normal z), the
+    whole-image sums, and the worst deviation among the pixels that are constant on both sides."""
+    g = np.asarray(run_images, np.float64)[..., :3]
+    assert g.shape[0] == runs
+    gm, gs = g.mean(0), g.std(0, ddof=1)
+    m, sd = np.asarray(ref_mean, np.float64), np.asarray(ref_std, np.float64)
+    finite = np.isfinite(gm) & np.isfinite(gs) & np.isfinite(m) & np.isfinite(sd)
+    vary = finite & ((sd > 0) | (gs > 0))
+    se = np.sqrt((gs[vary] ** 2 + sd[vary] ** 2) / float(runs))
+    d = gm[vary] - m[vary]
+    z = d / se
+    const = finite & ~vary
+    dev = np.abs(gm[const] - m[const]) / np.maximum(np.abs(m[const]), 1e-3)
+    n = int(vary.sum())
+    return {"n": n, "mean_z": float(z.mean()), "mean_z_in_sigmas": float(z.mean() * np.sqrt(n) / 1.1), "positive_share": float((d > 0).mean()),
+            "positive_share_in_sigmas": float(((d > 0).mean() - 0.5) * 2.0 * np.sqrt(n)), "median_abs_z": float(np.median(np.abs(z))),
+            "share_abs_z_gt_5": float((np.abs(z) > 5).mean()),
+            "image_sum_rel_err": float(d.sum() / m[vary].sum()), "image_sum_err_in_sigmas": float(d.sum() / np.sqrt((se * se).sum())),
+            "n_const": int(const.sum()), "max_const_rel_dev": float(dev.max()) if dev.size else 0.0,
+            "nonfinite_here": int((~np.isfinite(gm)).sum()), "nonfinite_ref": int((~np.isfinite(m)).sum())}
+
+
 def frac_bit_equal(a, b):
     return float((bits(a[..., :3]) == bits(b[..., :3])).all(-1).mean())
 

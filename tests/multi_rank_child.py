@@ -23,7 +23,7 @@ def render_all(lib, workdir):
         ses = helpers.session_for_case(lib, name, workdir)
         out["f%d" % i] = ses.render(w, h, spp, mode=mode)
         s = ses.stats()
-        stats.append((s.ranks, s.cameraSamples, s.pixels, s.rays))
+        stats.append((s.ranks, s.cameraSamples, s.pixels, s.rays, s.gatherMode, s.devices, s.rcclCommSize))
         ses.close()
     out["stats"] = np.asarray(stats, np.int64)
     return out

@@ -21,6 +21,20 @@ LAYOUTS = [
     dict(RAYLIB_NUM_GPUS="1", RAYLIB_GATHER_SELF="1", RAYLIB_GATHER="rccl"),
     dict(RAYLIB_NUM_GPUS="2", RAYLIB_GPU_MAP="0,0", RAYLIB_GATHER_SELF="1", RAYLIB_GATHER="peer"),
 ]
+# Two PHYSICAL devices (per-device scene copies, SyncSky's peer copy, cross-device stream waits, ncclCommInitAll over two devices, grouped
+# send / recv between them, peer access): run where the box has them, SKIPPED -- and not counted as covered -- where it has one.
+LAYOUTS_2DEV = [
+    dict(RAYLIB_NUM_GPUS="2", RAYLIB_GPU_MAP="0,1", RAYLIB_GATHER="rccl"),
+    dict(RAYLIB_NUM_GPUS="2", RAYLIB_GPU_MAP="0,1", RAYLIB_GATHER="peer"),
+    dict(RAYLIB_NUM_GPUS="4", RAYLIB_GPU_MAP="0,1,0,1", RAYLIB_GATHER="rccl"),
+    dict(RAYLIB_NUM_GPUS="4", RAYLIB_GPU_MAP="0,1,0,1", RAYLIB_GATHER="peer"),
+]
+GATHER_MODE = {"none": 0, "rccl": 1, "peer": 2}
+
+
+def visible_devices():
+    import torch
+    return torch.cuda.device_count()
 
 
 @pytest.fixture(scope="module")
@@ -28,8 +42,11 @@ def one_rank_frames(gpu_lib, workdir):
     return multi_rank_child.render_all(gpu_lib, workdir)
 
 
-@pytest.mark.parametrize("layout", LAYOUTS, ids=lambda d: "-".join("%s%s" % (k.replace("RAYLIB_", "").lower(), v) for k, v in d.items()))
+@pytest.mark.parametrize("layout", LAYOUTS + LAYOUTS_2DEV, ids=lambda d: "-".join("%s%s" % (k.replace("RAYLIB_", "").lower(), v) for k, v in d.items()))
 def test_raylib_render_over_n_ranks_is_bit_identical(layout, one_rank_frames, workdir):
+    need = 1 + max(int(x) for x in layout.get("RAYLIB_GPU_MAP", "0").split(","))
+    if visible_devices() < need:
+        pytest.skip("needs %d physical devices, %d visible: NOT covered on this box" % (need, visible_devices()))
     out = os.path.join(str(workdir), "multi_%s.npz" % "_".join(layout.values()).replace(",", ""))
     env = dict(os.environ, **layout)
     for k in ("RAYLIB_POOL", "RAYLIB_LIB"):
@@ -42,8 +59,15 @@ def test_raylib_render_over_n_ranks_is_bit_identical(layout, one_rank_frames, wo
     for i in range(len(multi_rank_child.FRAMES)):
         assert helpers.same(got["f%d" % i], one_rank_frames["f%d" % i]).all(), multi_rank_child.FRAMES[i]
     # the same camera samples, pixels and rays, however they were dealt; `ranks` says who rendered
-    assert np.array_equal(got["stats"][:, 1:], one_rank_frames["stats"][:, 1:])
+    assert np.array_equal(got["stats"][:, 1:4], one_rank_frames["stats"][:, 1:4])
     assert (got["stats"][:, 0] == n).all() and (one_rank_frames["stats"][:, 0] == 1).all()
+    # the gather mechanism that actually ran is the one asked for: a silent fall-back from RCCL to peer copies fails here
+    remote = layout.get("RAYLIB_GATHER_SELF") == "1" or need > 1
+    want_mode = GATHER_MODE[layout.get("RAYLIB_GATHER", "rccl")] if remote else 0
+    assert (got["stats"][:, 4] == want_mode).all(), (got["stats"][:, 4], want_mode)
+    assert (got["stats"][:, 5] == need).all()
+    if want_mode == 1:
+        assert (got["stats"][:, 6] == need).all()      # the communicator spans the distinct devices
 
 
 def test_more_ranks_than_devices_without_a_map_fails_loudly(workdir):

@@ -530,7 +530,7 @@ def test_bench_multi_rank_frame_assembly_on_one_gpu():
     for k in ("RAYLIB_POOL", "RAYLIB_LIB"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stderr[-2000:]
@@ -539,28 +539,79 @@ def test_bench_multi_rank_frame_assembly_on_one_gpu():
     assert d["config"]["frame_check"].startswith("assembled frame bit-identical to a one-GPU render") and "MISMATCH" not in d["config"]["frame_check"]
     assert "reference-rendered windows bit-identical" in d["config"]["frame_check"]
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert d["multi_gpu"]["ranks"] == 2 and len(d["multi_gpu"]["rank_trace_ms"]) == 2 and min(d["multi_gpu"]["rank_trace_ms"]) > 0
 
 
 def test_bench_default_run_times_the_boundary_and_checks_the_frame():
     """`python bench.py` as the driver runs it at N = 1: the timed call is Raylib_Render, and the frame it produced is compared, outside
-    the timed region, with windows the reference build rendered (tests/golden/bench_windows.npz)."""
+    the timed region, with windows the reference build rendered (tests/golden/bench_windows.npz).  The same invocation reports the
+    configs[2]-sized scene (a memory-bound megakernel) under "extra"."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    for k in ("RAYLIB_POOL", "RAYLIB_LIB", "BENCH_SHARE_GPU", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for k in ("RAYLIB_POOL", "RAYLIB_LIB", "BENCH_SHARE_GPU", "WORLD_SIZE", "RANK", "LOCAL_RANK", "RAYLIB_NUM_GPUS", "RAYLIB_GPU_MAP", "RAYLIB_JOB_HEADS"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["boundary"]["timed_entry"] == "Raylib_Render"
     assert d["config"]["frame_check"].endswith("reference-rendered windows bit-identical") and "MISMATCH" not in d["config"]["frame_check"]
+    b = d["config"]["boundary"]
+    assert b["render_plus_dump_ms_per_step"] > b["raylib_render_ms_per_step"] > 0 and b["render_device_ms_per_step"] > 0
+    sp = d["ms_per_step_spread"]
+    assert sp["n"] == 10 and sp["min"] <= sp["median"] <= sp["max"] and abs(sp["median"] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
     r = d["roofline"]
-    assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_measured_frac", "traffic_source", "algorithmic_gbs", "algorithmic_frac_of_hbm_peak"}
-    if r["valu"] is not None:
-        assert 0.0 < r["valu"]["busy_fraction"] <= 1.0
-        # the Cornell scene lives in LDS: the line's roofline is the VALU issue rate, not bytes against the HBM peak
-        assert r["unit"] == "Gwave-inst/s" and 0.0 < r["frac"] <= 1.0 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
+    assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic", "hbm", "valu", "replayed_pmc"}
+    # peaks are constants of the part, whatever ran
+    assert r["peak"] in (8000.0, 1024 * 2.4) and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
+    a = r["algorithmic"]
+    # the Cornell frame's algorithmic bytes are the TREE WALK's (a workload property), the leaf list's LDS traffic sits next to them
+    assert 700 < a["bytes_per_camera_sample"] < 1000 and a["served_elsewhere"]["lds_served_bytes_per_camera_sample"] > a["bytes_per_camera_sample"]
+    assert r["job_heads"] == 8
+    if r["replayed_pmc"] is not None:
+        rp = r["replayed_pmc"]
+        assert rp["loaded_build_id"] == d["config"]["build_id"] and rp["stale"] == (rp["build_id"] != rp["loaded_build_id"])
+        assert ("STALE" in r["traffic_source"]) == rp["stale"]
+        if r["valu"] is not None:
+            assert 0.0 < r["valu"]["frac_of_spec_peak"] <= 1.0 and 2.0 <= r["valu"]["mean_cost_cycles_per_inst"] < 8.0
+    e = d["extra"]
+    assert e["workload"] == "breakfast_300k_1080p_128spp" and e["value"] > 0 and e["scene_triangles"] > 290000
+    assert e["frame_check"].endswith("reference-rendered windows bit-identical")
+    assert e["roofline"]["kernel"] == "k_trace_pool" and e["roofline"]["algorithmic"]["frac_of_hbm_peak"] <= 1.0
+
+
+def test_bench_library_mode_runs_n_ranks_behind_raylib_render_or_refuses():
+    """`python bench.py --gpus N` without torch.distributed.run is the library mode: RAYLIB_NUM_GPUS = N behind Raylib_Render.  On this
+    1-GPU box N = 2 must be REFUSED (exit code != 0, no JSON line) unless RAYLIB_GPU_MAP puts both logical ranks on the one device;
+    then the line says n_gpus 2, names the gather mechanism and carries per-rank times, and the frame check holds."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RAYLIB_POOL", "RAYLIB_LIB", "BENCH_SHARE_GPU", "WORLD_SIZE", "RANK", "LOCAL_RANK", "RAYLIB_NUM_GPUS", "RAYLIB_GPU_MAP", "RAYLIB_GATHER_SELF"):
+        env.pop(k, None)
+    import torch
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra"]
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
+        assert "refusing to measure fewer GPUs" in out.stderr
+    out = subprocess.run(cmd, env=dict(env, RAYLIB_GPU_MAP="0,0", RAYLIB_GATHER_SELF="1"), capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["boundary"]["timed_entry"] == "Raylib_Render"
+    assert d["config"]["frame_check"].endswith("reference-rendered windows bit-identical")
+    m = d["multi_gpu"]
+    assert m["ranks"] == 2 and m["devices"] == 1 and m["gather"] in ("rccl", "peer") and len(m["rank_kernel_ms"]) == 2 and min(m["rank_kernel_ms"]) > 0
+    assert m["gather"] != "rccl" or m["rccl_comm_size"] == 1
+    # a mismatch between --gpus and the launcher is an error, not a silent one-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra"],
+                         env=dict(env, RAYLIB_NUM_GPUS="2", RAYLIB_GPU_MAP="0,0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "RAYLIB_NUM_GPUS" in bad.stderr
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
 
 
 def test_bench_rccl_gather_path_with_one_rank():
@@ -573,7 +624,7 @@ def test_bench_rccl_gather_path_with_one_rank():
     for k in ("RAYLIB_POOL", "RAYLIB_LIB", "BENCH_SHARE_GPU"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29534",
-           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stderr[-2000:]
@@ -632,6 +683,31 @@ def test_deferred_readback_reaches_every_host_reader(gpu_lib, workdir):
     assert np.array_equal(small.reshape(16, 24, 3), ses.render(24, 16, 1)[..., :3])
     lib.Raylib_DestroyImage(img)
     ses.close()
+
+
+def test_sky_panorama_swapped_by_destroy_and_create(gpu_lib):
+    """A front-end that swaps panoramas destroys image A and creates image B; the allocator very likely hands B the address A had.  The
+    device copy of the sky is keyed on (handle, pixel version): versions are unique in the process, so B can never pass for A."""
+    from raylib_amd import binding
+    lib = gpu_lib
+    cam = lib.Raylib_CreateCamera()
+    lib.Raylib_CameraSetPosition(cam, 0.0, 0.0, 0.0); lib.Raylib_CameraSetLookAt(cam, 0.0, 0.0, -1.0); lib.Raylib_CameraSetPerspective(cam, 60.0, 1.0)
+    sc = lib.Raylib_CreateScene(); lib.Raylib_FinalizeScene(sc)
+    st = binding.RendererSettings(16, 16, 1, 5, 0.0001, 0)
+    out = lib.Raylib_CreateImage(16, 16)
+    seen = []
+    for colour in ((0.75, 0.0, 0.0, 1.0), (0.0, 0.5, 0.0, 1.0), (0.0, 0.0, 0.25, 1.0)):
+        px = np.tile(np.array(colour, np.float32), (8 * 16, 1))
+        sky = lib.RaylibAMD_CreateImageFromData(16, 8, px.ctypes.data_as(C.POINTER(C.c_float)))
+        seen.append(sky)
+        lib.Raylib_SetSkyPanorama(sc, sky)
+        lib.Raylib_Render(C.byref(st), sc, cam, out)
+        got = np.zeros((16, 16, 4), np.float32)
+        lib.RaylibAMD_DumpImageRGBA(out, got.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(got[..., :3], np.broadcast_to(np.array(colour[:3], np.float32), (16, 16, 3))), colour
+        lib.Raylib_DestroyImage(sky)     # no render between this and the next panorama's SetSkyPanorama
+    print("panorama handles: %s (%d distinct)" % (seen, len(set(seen))))
+    lib.Raylib_DestroyImage(out); lib.Raylib_DestroyScene(sc); lib.Raylib_DestroyCamera(cam)
 
 
 @pytest.mark.parametrize("name", ["cornell", "cornell_glass_sun", "pbr_maps"])

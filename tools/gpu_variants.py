@@ -11,7 +11,7 @@ for rnd in range(3):
         env["RAYLIB_LIB"] = os.path.join(ROOT, "software-raytracing_amd", "libraylib%s.so" % (("_" + name) if name != "base" else ""))
         for kv in extra.split(","):
             if kv: k, _, val = kv.partition("="); env[k] = val
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", os.environ.get("STEPS", "3"), "--warmup", "1", "--no-cpu-baseline", "--workload", workload], env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", os.environ.get("STEPS", "3"), "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--workload", workload], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line: print(v, "FAILED", out.stderr[-300:]); continue
         d = json.loads(line[-1]); res[v].append((d["value"], d["roofline"]["avg_launch_ms"]))

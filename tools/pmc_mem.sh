@@ -5,7 +5,7 @@ OUT=/root/repo/gpurun_out/pmcm_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-run() { name=$1; shift; timeout 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload ${WL:-cornell_1080p_64spp} > $OUT/$name.log 2>&1; }
+run() { name=$1; shift; timeout 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload ${WL:-cornell_1080p_64spp} > $OUT/$name.log 2>&1; }
 # few counters per block and pass (a request the hardware cannot schedule aborts rocprofv3 and then hangs it: hence the timeouts)
 run ta TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum
 run ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum

@@ -1,13 +1,39 @@
 """profiles/pmc_traffic.json from the PMC passes of tools/pmc_profile.sh.
 
-usage: ROUND_TAG=r02 python tools/pmc_traffic.py <workload>=<pmc out dir> [...]
-HBM bytes per launch of the dominant kernel (k_trace / k_trace_pool) = 2 x FETCH_SIZE (KB, the gfx950 correction of
-MI355X_MICROARCH.md's HBM section) + WRITE_SIZE (KB), each from its own pass; the SQ ratios come from the sq1 pass."""
-import csv, glob, json, os, sys, collections
+usage: ROUND_TAG=r03 python tools/pmc_traffic.py <workload>=<pmc out dir> [...]
+
+Per workload, for the dominant kernel (k_trace / k_trace_pool), mean per launch:
+  * HBM bytes = 2 x FETCH_SIZE (KB; the gfx950 correction of MI355X_MICROARCH.md's HBM section) + WRITE_SIZE (KB), each from its own pass;
+  * VALU instructions by class (SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 / _F64, TRANS_F32 / _F64, INT32, INT64, CVT; the rest = SQ_INSTS_VALU minus
+    those) priced with the issue costs measured by tools/valu_calib.hip under rocprofv3 (profiles/valu_calib.json: 2 cycles per wave64 for
+    v_fma / v_mul / v_add / v_sub_f32 and the plain 32-bit and / or / xor / add / sub / shift-right / mov, 4 for everything else, 8 / 16 for
+    f32 / f64 transcendentals).  INT32 and the unclassified rest mix 2- and 4-cycle opcodes that no counter separates: they are priced
+    with the static mix of the kernel's code (tools/static_mix.py), and the all-2 / all-4 bounds are kept next to the estimate.
+    valu_weighted_busy_fraction = sum(count x cost) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the share of the launch's cycles the SIMDs'
+    vector issue ports were taken;
+  * the build id of the library the passes ran on (RaylibAMD_BuildId): bench.py calls the record STALE when it is not the loaded library's."""
+import csv, glob, json, os, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
 out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 res = json.load(open(out_path)) if os.path.exists(out_path) else {}
-TAG = os.environ.get("ROUND_TAG", "r02")
+TAG = os.environ.get("ROUND_TAG", "r03")
+SIMDS = 256 * 4
+NOMINAL = {"FMA_F32": 2, "MUL_F32": 2, "ADD_F32": 2, "FMA_F64": 4, "MUL_F64": 4, "ADD_F64": 4, "TRANS_F32": 8, "TRANS_F64": 16, "CVT": 4, "INT64": 4}
+
+
+def build_id():
+    from raylib_amd import binding
+    return binding.load().RaylibAMD_BuildId().decode()
+
+
+def static_mix():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "static_mix.py")], capture_output=True, text=True).stdout
+    return json.loads(out)
+
+
+BUILD = build_id()
+MIX = static_mix()
 for arg in sys.argv[1:]:
     wl, d = arg.split("=", 1)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -16,9 +42,21 @@ for arg in sys.argv[1:]:
             acc[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     kern = max((k for k in acc if "k_trace" in k), key=lambda k: sum(acc[k].get("SQ_WAVE_CYCLES", [0])))
     m = {c: sum(v) / len(v) for c, v in acc[kern].items()}
-    simds = 256 * 4
+    cycles = m["GRBM_GUI_ACTIVE"] / 8.0
+    # static mix of this instantiation: "void rl::k_trace<16, false, true, 2>" -> "k_traceILi16ELb0ELb1ELi2E"
+    args = kern.strip().split("<", 1)[1].rstrip(">").split(",")
+    mangled = ("k_trace_pool" if "k_trace_pool" in kern else "k_trace") + "I" + "".join(("Lb1" if a.strip() == "true" else "Lb0" if a.strip() == "false" else "Li" + a.strip()) + "E" for a in args) + "E"
+    mix = MIX.get(mangled, {}).get("mean_cost", {})
+    counts = {c: m.get("SQ_INSTS_VALU_" + c, 0.0) for c in ("ADD_F32", "MUL_F32", "FMA_F32", "ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F32", "TRANS_F64", "CVT", "INT32", "INT64")}
+    other = m["SQ_INSTS_VALU"] - sum(counts.values())
+    counts["OTHER"] = other
+    fixed = sum(counts[c] * NOMINAL[c] for c in NOMINAL)
+    est = fixed + counts["INT32"] * mix.get("INT32", 3.0) + other * mix.get("OTHER", 3.5)
+    lo = fixed + (counts["INT32"] + other) * 2.0
+    hi = fixed + (counts["INT32"] + other) * 4.0
     rec = {
         "kernel": kern.strip(),
+        "build_id": BUILD,
         "hbm_bytes_per_launch": 2 * m["FETCH_SIZE"] * 1024 + m["WRITE_SIZE"] * 1024,
         "fetch_bytes_corrected_x2": 2 * m["FETCH_SIZE"] * 1024,
         "write_bytes": m["WRITE_SIZE"] * 1024,
@@ -26,16 +64,23 @@ for arg in sys.argv[1:]:
         "tcc_hit_rate": m["TCC_HIT_sum"] / max(1.0, m["TCC_REQ_sum"]),
         "valu_lane_utilisation": m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"]),
         "valu_insts_per_launch": m["SQ_INSTS_VALU"],
-        # a wave64 VALU instruction occupies its SIMD-32's issue for 2 cycles (MI355X_MICROARCH.md constants table; tools/valu_calib.hip
-        # measures 0.5 wave-instructions per cycle per SIMD at saturation on the bench box).  Round 1 used 4 and got 1.08.
-        "cycles_per_launch": m["GRBM_GUI_ACTIVE"] / 8.0,
-        "valu_busy_fraction": 2.0 * m["SQ_INSTS_VALU"] / simds / (m["GRBM_GUI_ACTIVE"] / 8.0),
+        "valu_class_counts": counts,
+        "valu_class_costs": dict(NOMINAL, INT32=mix.get("INT32", 3.0), OTHER=mix.get("OTHER", 3.5)),
+        "valu_weighted_cycles_per_launch": est,
+        "valu_weighted_cycles_bounds": [lo, hi],
+        "cycles_per_launch": cycles,
+        "profiled_clock_ghz": None,
+        "valu_weighted_busy_fraction": est / SIMDS / cycles,
+        "valu_weighted_busy_bounds": [lo / SIMDS / cycles, hi / SIMDS / cycles],
+        # round 2's figure, kept for comparison: every VALU instruction charged the 2 cycles of a v_fma_f32
+        "valu_busy_fraction": 2.0 * m["SQ_INSTS_VALU"] / SIMDS / cycles,
         "wave_wait_fraction": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
-        "waves_per_simd": m["SQ_WAVES"] / simds,
+        "waves_per_simd": m["SQ_WAVES"] / SIMDS,
         "salu_insts_per_launch": m.get("SQ_INSTS_SALU"),
         "round": TAG,
-        "source": "rocprofv3 --pmc passes of tools/pmc_profile.sh (FETCH_SIZE and WRITE_SIZE in separate passes), mean per launch; "
-                  "valu_busy = 2 cycles x SQ_INSTS_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); profiles/%s_pmc_%s.txt" % (TAG, wl),
+        "source": "rocprofv3 --pmc passes of tools/pmc_profile.sh (FETCH_SIZE and WRITE_SIZE in separate passes), mean per launch; VALU cycles = class counts x "
+                  "issue costs (profiles/valu_calib.json; INT32 and the unclassified rest at the kernel's static mix, tools/static_mix.py) over 1024 SIMDs x "
+                  "(GRBM_GUI_ACTIVE / 8 XCDs); profiles/%s_pmc_%s.txt" % (TAG, wl),
     }
     res[wl] = rec
     print(wl, json.dumps(rec, indent=1))

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for WL in cornell_1080p_64spp breakfast_300k_1080p_128spp; do
   python3 /root/repo/bench.py --steps 5 --warmup 1 --workload $WL > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $WL > $OUT/stats_$WL.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/stats_$WL.log 2>&1
   /root/repo/tools/pmc_profile.sh $WL $OUT/pmc_$WL > $OUT/pmc_$WL.log 2>&1
   python3 /root/repo/tools/pmc_summarize.py $OUT/pmc_$WL > $OUT/pmc_$WL.txt 2>&1
 done
