@@ -229,17 +229,35 @@ def library_run(lib, binding, scenes, workload_name, steps, warmup, n_gpus, rank
     for _ in range(warmup):
         lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)
     import torch
-    torch.cuda.synchronize()
+
+    def fence():
+        for d in range(torch.cuda.device_count()):
+            torch.cuda.synchronize(d)
+
+    lib.RaylibAMD_GetLastStats(C.byref(stats))    # (waits for what the warm-up left in flight)
+    fence()
     per_step = []
     t0 = time.perf_counter()
-    for _ in range(steps):
-        ts = time.perf_counter()
-        lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)     # the boundary itself (synchronous); the frame stays in HBM
-        per_step.append(time.perf_counter() - ts)
-        lib.RaylibAMD_GetLastStats(C.byref(stats))
-        accumulate(acc, stats, binding)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    if n_gpus == 1:
+        for _ in range(steps):
+            ts = time.perf_counter()
+            lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)     # the boundary itself (synchronous); the frame stays in HBM
+            per_step.append(time.perf_counter() - ts)
+            lib.RaylibAMD_GetLastStats(C.byref(stats))
+            accumulate(acc, stats, binding)
+        fence()
+        elapsed = time.perf_counter() - t0
+    else:
+        # several ranks behind the call: Raylib_Render returns with frame i in flight and frame i + 1 is enqueued behind it (rl_runtime.inl
+        # RenderMulti), so nothing asks for stats or pixels inside the timed region; the K frames are identical (same seed, same scene), the
+        # last one's counters stand for each
+        for _ in range(steps):
+            lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)
+        lib.RaylibAMD_GetLastStats(C.byref(stats))                            # waits for the last frame (every rank's stream, the gather, the assembly)
+        fence()
+        elapsed = time.perf_counter() - t0
+        for _ in range(steps):
+            accumulate(acc, stats, binding)
     last = stats.as_dict()
     # ---- untimed from here on -------------------------------------------------------------------------------------------------
     host = np.zeros(w * h * 3, np.float32)

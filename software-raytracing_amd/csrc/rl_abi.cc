@@ -316,7 +316,16 @@ void Raylib_FlushLogThread(void) { LogFlush(); }
 // ===========================================================================
 void RaylibAMD_SetSeed(uint64_t seed) { std::lock_guard<std::mutex> lk(g_stateMu); g_seed = seed; g_seedSet = true; }
 uint64_t RaylibAMD_GetSeed(void) { return CurrentSeed(); }
-void RaylibAMD_GetLastStats(RaylibAMDStats* out) { if (!out) return; std::lock_guard<std::mutex> lk(g_stateMu); *out = g_lastStats; }
+void RaylibAMD_GetLastStats(RaylibAMDStats* out)
+{
+	if (!out) return;
+	// a whole-frame render over several ranks returns with the frame in flight (rl_runtime.inl RenderMulti): its counters and times arrive now
+	RaylibAMDStats late;
+	const bool have = DeviceDrain(&late);
+	std::lock_guard<std::mutex> lk(g_stateMu);
+	if (have) g_lastStats = late;
+	*out = g_lastStats;
+}
 int32_t RaylibAMD_DeviceAvailable(void) { return DeviceAvailable() ? 1 : 0; }
 #ifndef RL_BUILD_ID
 #define RL_BUILD_ID "unknown"

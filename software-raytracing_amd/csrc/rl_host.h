@@ -192,6 +192,7 @@ struct RenderRequest {
 	uint64_t seed;
 	uint32_t cellFirst, cellStride;
 	bool cellMajor = false; // the rank's cells back to back even when it owns every cell (one rank going through the gather path)
+	int slot = 0;           // frame slot (0 / 1) of the rank's events and counter buffers: a multi-rank frame in flight while the next is enqueued
 	void* outDevice;        // may be null
 	float* outHostRGBA;     // may be null; receives what outDevice would (row-major image or the rank's cells)
 };
@@ -210,6 +211,7 @@ bool DecodeJPEG(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std:
 bool DecodeTGA(const std::vector<uint8_t>& data, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 bool EncodeJPEG(uint32_t w, uint32_t h, const uint8_t* rgbTopDown, std::vector<uint8_t>& out);   // baseline, quality 75, 4:2:0
 bool DeviceRender(Scene& scene, const RenderRequest& req, RaylibAMDStats& stats);
+bool DeviceDrain(RaylibAMDStats* outLastStats);   // waits for multi-rank frames in flight; true + stats when that completed the last render call's numbers
 bool DeviceClosestHit(Scene& scene, const float* rays, int32_t n, float tMin, void* outHits);
 bool DevicePostProcess(Image& img);          // Image2D::PostProcess on the device; false when no device
 bool DeviceReadback(Image& img);            // device copy -> img.rgba (the caller checked hostStale)

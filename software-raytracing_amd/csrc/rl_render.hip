@@ -55,8 +55,11 @@ __shared__ double rlm_lds_tab[80];
 namespace rl {
 
 #define RL_BLOCK 256
-#ifndef RL_LEAFBOX_V2
-#define RL_LEAFBOX_V2 0   /* the leaf list's box test in 2-cycle VALU instructions where it can (TraverseLeafList): experiment, see there */
+#ifndef RL_POOL_SHARED_CHUNK
+#define RL_POOL_SHARED_CHUNK 0   /* pool schedule: the workgroup's waves draw 64-job batches from one chunk in LDS (TakeBatch) */
+#endif
+#ifndef RL_ROOTMISS_RCP
+#define RL_ROOTMISS_RCP 1
 #endif
 #ifndef RL_REFILL_ROUNDS
 #define RL_REFILL_ROUNDS 4
@@ -366,7 +369,13 @@ __device__ __forceinline__ float FastRcp(float x) { return __builtin_amdgcn_rcpf
 template <int LDS = 0>
 __device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float tMin, const float4* sm = nullptr)
 {
+	// a filter: "true" only has to imply that a traversal finds nothing.  v_rcp_f32 reciprocals (1 ulp; 8 issue cycles each against the 36 of an
+	// IEEE division) under the 1e-5 widening of every box test here, as in the pool schedule's slab tests.  0 -> inf and the sign of a zero survive.
+#if RL_ROOTMISS_RCP
+	const V3 inv = v3(FastRcp(d.x), FastRcp(d.y), FastRcp(d.z));
+#else
 	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#endif
 	const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
 	const float4* np = LDS ? sm + RL_LDS_ROOT : (const float4*)(S.nodes);
 	const float4 q0 = np[0], q1 = np[1], q2 = np[2];
@@ -613,31 +622,8 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const float4 nX = *(const float4*)(rec + oNX), fX = *(const float4*)(rec + oFX);
 			const float4 nY = *(const float4*)(rec + oNY), fY = *(const float4*)(rec + oFY);
 			const float4 nZ = *(const float4*)(rec + oNZ), fZ = *(const float4*)(rec + oFZ);
-#if RL_LEAFBOX_V2
-			// The gfx950 VALU issues v_fma / v_mul / v_add / v_sub_f32 and the plain 32-bit integer and / or / xor / add / shift-right in 2 cycles per
-			// wave64 and EVERYTHING else -- min, max, compares, selects, v_and_or -- in 4 (tools/valu_calib.hip, profiles/valu_calib.json), and this
-			// kernel sits on its VALU issue roof.  So with rayTMin >= 0 (every front-end's value; the other case keeps the first form):
-			//   entry = max(tMin, max3(x, y, z))          -- already >= 0: no second max for the key
-			//   exit  = min3(x, y, z)                     -- no clamp to FLT_MAX: +inf and (all three planes NaN: a ray without a direction) NaN pass as they did
-			//   culled <=> exit * widen - entry < 0, ONE fma whose sign bit, smeared over the word, is or-ed into the key (0xffffffff = no candidate)
-			// instead of max, max3, min, min3, mul, max, compare, select, and_or.  The fma compares the EXACT product with the entry where the first form
-			// compared the rounded one: a difference of one ulp of a test that is widened by 1e-5 (and 1e-6 wider than the candidate rule needs).
-			#define RL_LSLAB(k, slot) { \
-				const float tn = fmaxf(tMin, fmaxf(fmaxf(__builtin_fmaf(nX.k, invb.x, cn.x), __builtin_fmaf(nY.k, invb.y, cn.y)), __builtin_fmaf(nZ.k, invb.z, cn.z))); \
-				const float tf = fminf(fminf(__builtin_fmaf(fX.k, invb.x, cf.x), __builtin_fmaf(fY.k, invb.y, cf.y)), __builtin_fmaf(fZ.k, invb.z, cf.z)); \
-				const uint32_t culled = (uint32_t)(__float_as_int(__builtin_fmaf(tf, RL_BOX_WIDEN, -tn)) >> 31); \
-				key[slot] = (__float_as_uint(tn) & ~31u) | ((uint32_t)(slot) | culled); }
-			#define RL_LSLAB1(k, slot) { \
-				float tn = tMin, tf = FLT_MAX; \
-				tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = fminf(tf, __builtin_fmaf(fX.k, invb.x, cf.x)); \
-				tn = fmaxf(tn, __builtin_fmaf(nY.k, invb.y, cn.y)); tf = fminf(tf, __builtin_fmaf(fY.k, invb.y, cf.y)); \
-				tn = fmaxf(tn, __builtin_fmaf(nZ.k, invb.z, cn.z)); tf = fminf(tf, __builtin_fmaf(fZ.k, invb.z, cf.z)); \
-				if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(fmaxf(tn, 0.0f)) & ~31u) | (uint32_t)(slot); }
-			if (tMin >= 0.0f) { RL_LSLAB(x, 4 * g) RL_LSLAB(y, 4 * g + 1) RL_LSLAB(z, 4 * g + 2) RL_LSLAB(w, 4 * g + 3) }
-			else { RL_LSLAB1(x, 4 * g) RL_LSLAB1(y, 4 * g + 1) RL_LSLAB1(z, 4 * g + 2) RL_LSLAB1(w, 4 * g + 3) }
-			#undef RL_LSLAB
-			#undef RL_LSLAB1
-#else
+			// (Round 3, measured and not kept: the same test in fewer issue cycles by the cost table of tools/valu_calib.hip -- entry = max(tMin, max3), exit = min3 without
+			// the clamp, culled <=> sign of fma(exit, widen, -entry) smeared into the key: 34 cycles per box for 44 on paper, 14.80 ms for 14.31 on the GPU, twice.)
 			#define RL_LSLAB(k, slot) { \
 				float tn = tMin, tf = FLT_MAX; \
 				tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = fminf(tf, __builtin_fmaf(fX.k, invb.x, cf.x)); \
@@ -646,7 +632,6 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 				if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(fmaxf(tn, 0.0f)) & ~31u) | (uint32_t)(slot); }
 			RL_LSLAB(x, 4 * g) RL_LSLAB(y, 4 * g + 1) RL_LSLAB(z, 4 * g + 2) RL_LSLAB(w, 4 * g + 3)
 			#undef RL_LSLAB
-#endif
 		}
 	}
 	uint32_t from = 0u;   // keys below this one are done (keys are distinct: the slot is part of the key)
@@ -1292,6 +1277,42 @@ __device__ __forceinline__ bool TakeJobs(const DRenderParams& P, unsigned int* _
 	}
 }
 
+// The workgroup's share of the job list: its waves draw BATCHES of 64 jobs (one cell at one sample) from one chunk in LDS -- an LDS atomic -- and whoever
+// finds the chunk used up takes the lock, draws the next chunk from the XCD's head (TakeJobs: the one global atomic per chunk) and publishes it.  The
+// chunk is the granule of the global list, the batch the granule of a wave's work: when the list runs dry a wave has a batch in front of it, not a chunk.
+// (k_trace's leaf-list instantiation has the same logic inline, with its bounded-wait test variant; this is the pool schedule's.)
+struct WgJobs { unsigned long long* jobs; unsigned int* lock; unsigned int* done; };   // LDS: (next job | end of the chunk << 32), lock word, "the list is used up"
+__device__ __forceinline__ bool TakeBatch(const DRenderParams& P, unsigned int* __restrict__ heads, JobSource& js, WgJobs w, uint32_t lane, uint32_t& base, uint32_t& end)
+{
+	for (;;) {
+		unsigned long long st = 0ull;
+		if (lane == 0) st = atomicAdd(w.jobs, 64ull);
+		st = __shfl(st, 0);
+		const uint32_t nx = (uint32_t)st, en = (uint32_t)(st >> 32);
+		if (nx < en) { base = nx; end = min(nx + 64u, en); return true; }
+		if (__atomic_load_n(w.done, __ATOMIC_RELAXED) != 0u) return false;
+		uint32_t won = 0;
+		if (lane == 0) won = atomicCAS(w.lock, 0u, 1u) == 0u ? 1u : 0u;
+		won = __shfl(won, 0);
+		if (won) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			const unsigned long long cur = __atomic_load_n(w.jobs, __ATOMIC_RELAXED);
+			if ((uint32_t)cur >= (uint32_t)(cur >> 32) && __atomic_load_n(w.done, __ATOMIC_RELAXED) == 0u) {   // still used up: nobody refilled it in between
+				uint32_t b = 0, e = 0;
+				const bool got = TakeJobs(P, heads, js, P.jobChunk, lane, b, e);
+				if (lane == 0) {
+					if (!got) __atomic_store_n(w.done, 1u, __ATOMIC_RELAXED);
+					else __atomic_store_n(w.jobs, (unsigned long long)b | ((unsigned long long)e << 32), __ATOMIC_RELAXED);
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) __atomic_store_n(w.lock, 0u, __ATOMIC_RELAXED);
+		} else {
+			while (__atomic_load_n(w.lock, __ATOMIC_RELAXED) != 0u) __builtin_amdgcn_s_sleep(2);   // microseconds: one global atomic
+		}
+	}
+}
+
 __device__ __forceinline__ void WaveLdsSync()
 {
 	// LDS operations of one wave are executed in issue order; this only stops the compiler from moving LDS
@@ -1780,6 +1801,9 @@ struct Trav { V3 o, d, inv; float rayTime; bool nx, ny, nz, anyhit; HitRec best;
 // (cur >= 0), at a leaf (cur < 0, leafI = next primitive of it), or finished (both return true then).
 // LSTACK entries of the traversal stack live in LDS (stk), deeper ones in the lane's private overflow array (scratch):
 // with a 19-entry LDS part a 32-deep stack fits 4 workgroups per CU; trees rarely need the overflow.
+// (Round 3, measured and not kept: a 16-bit entry distance beside every stack entry, so that a pop drops the entries that start behind the best hit without
+// fetching their node.  It drops next to nothing -- 6.8 node records per ray instead of 6.9 on the 298 k-triangle scene: the near-first walk with its
+// shrinking t leaves little behind -- and the column costs LDS stack depth (12 entries instead of 18): 51.6 ms against 44.7.)
 template <int LSTACK, int STACK>
 __device__ __forceinline__ void StackPush(Trav& T, int* stk, int* ovf, int v)
 {
@@ -1979,6 +2003,13 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 	int* ovf = ovfStore;
 	__shared__ float s_pool[RL_BLOCK / 64][PoolOcc<LSTACK, PRIMS, K>::kFields][PP];
 	__shared__ unsigned char s_free[RL_BLOCK / 64][PP];
+#if RL_POOL_SHARED_CHUNK
+	__shared__ unsigned long long s_jobs;
+	__shared__ unsigned int s_lock, s_done;
+	if (threadIdx.x == 0) { s_jobs = 0ull; s_lock = 0u; s_done = 0u; }
+	__syncthreads();
+	const WgJobs wg = { &s_jobs, &s_lock, &s_done };
+#endif
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	float (*pool)[PP] = s_pool[wave];
@@ -2064,7 +2095,11 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 			for (int round = 0; round < RL_REFILL_ROUNDS && filled < nFree; ++round) {
 				if (chunkNext >= chunkEnd && !globalDone) {
 					uint32_t base = 0, bend = 0;
+#if RL_POOL_SHARED_CHUNK
+					if (!TakeBatch(P, jobCounter, js, wg, lane, base, bend)) { globalDone = true; RL_TIMELINE(1); }
+#else
 					if (!TakeJobs(P, jobCounter, js, P.jobChunk, lane, base, bend)) { globalDone = true; RL_TIMELINE(1); }
+#endif
 					else { chunkNext = base; chunkEnd = bend; }
 				}
 				const uint32_t avail = chunkEnd - chunkNext;

@@ -80,7 +80,10 @@ struct Worker {
 struct RankCtx {
 	int rank = 0, device = 0, devSlot = 0, numCUs = 0;
 	hipStream_t stream = nullptr;
-	hipEvent_t ev[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // 0/1 render, 2/3 megakernel, 4 "my cells are on rank 0's device", (rank 0) 5 every rank's cells are here, 6 frame assembled
+	// Two frame slots (a whole-frame render over several ranks keeps frame i in flight while frame i + 1 is enqueued; everything else uses slot 0).
+	// Per slot: 0/1 render, 2/3 megakernel, 4 "my cells are on rank 0's device", (rank 0) 5 every rank's cells are here, 6 frame assembled, 7 counters are on the host
+	hipEvent_t ev[2][8] = {};
+	unsigned long long* cntHost[2] = { nullptr, nullptr };   // pinned: the counter read-back must not block the enqueuing thread
 	// reusable work buffers
 	SampleRGB* samples = nullptr; size_t samplesBytes = 0;
 	float4* accum = nullptr; size_t accumBytes = 0;
@@ -97,14 +100,19 @@ struct Runtime {
 	bool probed = false, ok = false;
 	std::vector<RankCtx*> ranks;
 	std::vector<int> devices;          // the distinct physical devices, rank 0's first
-	float4* gather = nullptr; size_t gatherBytes = 0;   // on rank 0's device: every rank's cells, rank by rank
-	bool gatherSelf = false, wantRccl = true;
+	float4* gather[2] = { nullptr, nullptr }; size_t gatherBytes[2] = { 0, 0 };   // on rank 0's device: every rank's cells, rank by rank; one per frame slot
+	hipStream_t gatherStream = nullptr;                  // rank 0's device: receives / waits for the ranks' cells and assembles the frame, beside rank 0's own rendering
+	bool gatherSelf = false, wantRccl = true, pipeline = true;
+	uint64_t frameNo = 0;                                // whole-frame renders over several ranks so far: slot = frameNo & 1
+	struct Inflight;
+	Inflight* inflight[2] = { nullptr, nullptr };        // enqueued, not yet waited for (oldest first by frameNo)
 	RcclApi rccl;
 	std::mutex lock;
 };
 Runtime g_rt;
 inline RankCtx& Rank0() { return *g_rt.ranks[0]; }
 bool ReadbackLocked(Image& img);   // device copy -> img.rgba; the runtime lock is held by the caller
+bool DrainLocked();                // waits for the multi-rank frames in flight (RenderMulti); the runtime lock is held by the caller
 
 bool EnsureRuntime()
 {
@@ -139,6 +147,7 @@ bool EnsureRuntime()
 	for (int d : map) if (std::find(R.devices.begin(), R.devices.end(), d) == R.devices.end()) R.devices.push_back(d);
 	if (const char* g = getenv("RAYLIB_GATHER")) R.wantRccl = strcmp(g, "peer") != 0;
 	if (const char* g = getenv("RAYLIB_GATHER_SELF")) R.gatherSelf = atoi(g) != 0;
+	if (const char* g = getenv("RAYLIB_PIPELINE")) R.pipeline = atoi(g) != 0;
 	for (int r = 0; r < n; ++r) {
 		RankCtx* C = new RankCtx;
 		C->rank = r; C->device = map[(size_t)r];
@@ -148,7 +157,10 @@ bool EnsureRuntime()
 		HIP_OK(hipGetDeviceProperties(&prop, C->device));
 		C->numCUs = prop.multiProcessorCount;
 		HIP_OK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
-		for (int i = 0; i < 7; ++i) HIP_OK(hipEventCreate(&C->ev[i]));
+		for (int q = 0; q < 2; ++q) {
+			for (int i = 0; i < 8; ++i) HIP_OK(hipEventCreate(&C->ev[q][i]));
+			HIP_OK(hipHostMalloc((void**)&C->cntHost[q], (CNT_COUNT + 24) * sizeof(unsigned long long), hipHostMallocDefault));
+		}
 		HIP_OK(hipMalloc(&C->counters, (CNT_COUNT + 24 + RL_TIMELINE_SLOTS) * sizeof(unsigned long long)));
 		HIP_OK(hipMalloc(&C->jobCounter, RL_MAX_HEADS * RL_HEAD_STRIDE * sizeof(unsigned int)));   // the heads of the job list, one per XCD, 128 B apart
 		if (r > 0) { C->worker = new Worker; C->worker->Start(C->device); }
@@ -166,6 +178,7 @@ bool EnsureRuntime()
 		}
 	}
 	HIP_OK(hipSetDevice(R.devices[0]));
+	if (n > 1 || R.gatherSelf) HIP_OK(hipStreamCreateWithFlags(&R.gatherStream, hipStreamNonBlocking));
 	R.ok = true;
 	return true;
 }
@@ -390,6 +403,7 @@ bool SyncSky(Scene& sc)
 		if (!sky || (size_t)sky->width * sky->height == 0) { C->view.sky = nullptr; C->view.skyWidth = C->view.skyHeight = 0; C->skyImage = nullptr; continue; }
 		if (C->skyImage == sky && C->skyVersion == sky->version && C->view.sky) continue;
 		const size_t bytes = (size_t)sky->width * sky->height * sizeof(float4);
+		(void)DrainLocked();   // a frame in flight reads the texels that are about to be replaced
 		HIP_OK(hipSetDevice(C->device));
 		if (!Grow(C->sky, C->skyBytes, bytes)) return false;
 		if (sky->hostStale && sky->devValid && sky->devPixels) {
@@ -443,7 +457,8 @@ struct PendingRender {
 	uint32_t launches = 0, schedulePaths = 1, jobHeads = 0;
 	uint64_t pixels = 0;
 	float4* out = nullptr; size_t outBytes = 0;
-	unsigned long long cnt[CNT_COUNT + 24];
+	int slot = 0;                              // frame slot: which of the rank's event sets / pinned counter buffers this render uses
+	const unsigned long long* cnt = nullptr;   // -> ctx->cntHost[slot], valid once ev[slot][7] has fired
 };
 
 // One rank's share of a render, queued on its stream: counters reset, the megakernel (or k_aov) per sample batch, k_resolve,
@@ -463,6 +478,8 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 	const uint32_t SPP = (uint32_t)(st.samplesPerPixel > 1 ? st.samplesPerPixel : 1);
 	const bool pathTrace = (st.renderMode == RAYLIB_RENDERMODE_Default);
 	pend.ctx = &R; pend.pathTrace = pathTrace;
+	const int q = req.slot & 1;
+	pend.slot = q; pend.cnt = R.cntHost[q];
 
 	DRenderParams P; memset(&P, 0, sizeof(P));
 	P.width = W; P.height = H; P.spp = SPP; P.maxPathLength = st.maxPathLength; P.rayTMin = st.rayTMin;
@@ -478,7 +495,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 	pend.out = out; pend.outBytes = outBytes;
 
 	HIP_OK(hipMemsetAsync(R.counters, 0, (CNT_COUNT + 24 + RL_TIMELINE_SLOTS) * sizeof(unsigned long long), R.stream));
-	HIP_OK(hipEventRecord(R.ev[0], R.stream));
+	HIP_OK(hipEventRecord(R.ev[q][0], R.stream));
 	if (numSlots == 0) {
 		// nothing to do for this rank
 	} else if (!pathTrace) {
@@ -592,26 +609,27 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				pend.jobHeads = heads;
 				HIP_OK(hipMemsetAsync(R.jobCounter, 0, RL_MAX_HEADS * RL_HEAD_STRIDE * sizeof(unsigned int), R.stream));
 			}
-			HIP_OK(hipEventRecord(R.ev[2], R.stream));
+			HIP_OK(hipEventRecord(R.ev[q][2], R.stream));
 			hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(RL_BLOCK), 0, R.stream,
 			                   P, traceView, DS->skyRot, R.samples, R.pathStack, R.counters, R.jobCounter);
 			HIP_OK(hipGetLastError());
-			HIP_OK(hipEventRecord(R.ev[3], R.stream));
+			HIP_OK(hipEventRecord(R.ev[q][3], R.stream));
 			const uint32_t rblocks = (numSlots + RL_BLOCK - 1) / RL_BLOCK;
 			hipLaunchKernelGGL(k_resolve, dim3(rblocks), dim3(RL_BLOCK), 0, R.stream,
 			                   P, R.samples, R.accum, out, (int)(s0 == 0), (int)(s0 + cnt >= SPP));
 			HIP_OK(hipGetLastError());
 			++pend.launches;
 			if (s0 + cnt < SPP) {   // the event pair is reused by the next batch; the last batch's pair is read after the one final sync
-				HIP_OK(hipEventSynchronize(R.ev[3]));
+				HIP_OK(hipEventSynchronize(R.ev[q][3]));
 				float ms = 0.0f;
-				HIP_OK(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]));
+				HIP_OK(hipEventElapsedTime(&ms, R.ev[q][2], R.ev[q][3]));
 				pend.traceMs += ms;
 			} else pend.lastBatchPending = true;
 		}
 	}
-	HIP_OK(hipEventRecord(R.ev[1], R.stream));
-	HIP_OK(hipMemcpyAsync(pend.cnt, R.counters, sizeof(pend.cnt), hipMemcpyDeviceToHost, R.stream));
+	HIP_OK(hipEventRecord(R.ev[q][1], R.stream));
+	HIP_OK(hipMemcpyAsync(R.cntHost[q], R.counters, (CNT_COUNT + 24) * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
+	HIP_OK(hipEventRecord(R.ev[q][7], R.stream));
 	uint64_t px = 0;
 	for (uint32_t k = 0; k < numLocalCells; ++k) {
 		const uint32_t cell = req.cellFirst + k * stride, cx = cell % cellsX, cy = cell / cellsX;
@@ -636,15 +654,16 @@ bool EnqueueDispatch(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRen
 bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 {
 	RankCtx& R = *pend.ctx;
+	const int q = pend.slot;
 	HIP_OK(hipSetDevice(R.device));
-	HIP_OK(hipStreamSynchronize(R.stream));
+	HIP_OK(hipEventSynchronize(R.ev[q][7]));   // this render's last operation on the rank's stream (a later frame may already be queued behind it)
 	if (pend.lastBatchPending) {
 		float ms = 0.0f;
-		HIP_OK(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]));
+		HIP_OK(hipEventElapsedTime(&ms, R.ev[q][2], R.ev[q][3]));
 		pend.traceMs += ms;
 	}
 	float totalMs = 0.0f;
-	HIP_OK(hipEventElapsedTime(&totalMs, R.ev[0], R.ev[1]));
+	HIP_OK(hipEventElapsedTime(&totalMs, R.ev[q][0], R.ev[q][1]));
 	const unsigned long long* cnt = pend.cnt;
 	stats.rays += cnt[CNT_RAYS]; stats.nodesVisited += cnt[CNT_NODES]; stats.trisTested += cnt[CNT_TRIS];
 	stats.shadedHits += cnt[CNT_SHADED]; stats.texFetches += cnt[CNT_TEXELS]; stats.cameraSamples += cnt[CNT_SAMPLES];
@@ -689,12 +708,65 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 	return true;
 }
 
-// The frame over N ranks: cells round-robin, one gather to rank 0's device, one scatter kernel.
-bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
+// ---- whole frames over N ranks -------------------------------------------------------------------------------------
+// cells round-robin, one gather to rank 0's device, one scatter kernel -- and up to two frames in flight: Raylib_Render returns when frame i
+// is ENQUEUED on every rank's stream (after waiting for frame i - 1's predecessor, whose buffers frame i reuses), so that while rank 0's gather
+// stream still receives and assembles frame i the ranks already render frame i + 1.  Whoever reads the pixels, the stats or changes anything
+// a frame in flight uses goes through DrainLocked() first: to a front-end the call is as synchronous as the reference's (raylib.cc:231-239),
+// it just finds out later.  RAYLIB_PIPELINE=0 waits at the end of every call.
+struct Runtime::Inflight {
+	std::vector<PendingRender> pend;
+	RaylibAMDStats stats;                 // what is known when the frame is enqueued; FinishInflight adds counters and times
+	int slot = 0;
+	bool ok = true, timed = false;
+	std::chrono::steady_clock::time_point t0;
+};
+RaylibAMDStats g_deferredStats;           // of the last frame FinishInflight completed
+bool g_deferredUnreported = false;
+
+bool FinishInflight(int slot)
+{
+	Runtime& R = g_rt;
+	Runtime::Inflight* F = R.inflight[slot];
+	if (!F) return true;
+	R.inflight[slot] = nullptr;
+	RankCtx& R0 = Rank0();
+	bool ok = F->ok;
+	for (int r = (int)F->pend.size() - 1; r >= 0; --r) {
+		if (F->pend[(size_t)r].ctx) ok = FinishRender(F->pend[(size_t)r], F->stats) && ok;
+		else { (void)hipSetDevice(R.ranks[(size_t)r]->device); (void)hipStreamSynchronize(R.ranks[(size_t)r]->stream); }
+	}
+	(void)hipSetDevice(R0.device);
+	if (F->timed) {
+		if (hipEventSynchronize(R0.ev[slot][6]) != hipSuccess) ok = false;   // frame assembled (and copied to the host, if asked for)
+		float g = 0.0f, sc = 0.0f;
+		if (hipEventElapsedTime(&g, R0.ev[slot][1], R0.ev[slot][5]) == hipSuccess) F->stats.gatherMs = (double)g;
+		if (hipEventElapsedTime(&sc, R0.ev[slot][5], R0.ev[slot][6]) == hipSuccess) F->stats.scatterMs = (double)sc;
+	} else if (R.gatherStream) (void)hipStreamSynchronize(R.gatherStream);
+	F->stats.wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - F->t0).count();
+	g_deferredStats = F->stats; g_deferredUnreported = true;
+	delete F;
+	return ok;
+}
+// waits for every frame in flight (oldest first); the runtime lock is held by the caller
+bool DrainLocked()
+{
+	Runtime& R = g_rt;
+	if (!R.ok) return true;
+	const int older = (int)(R.frameNo & 1);   // the slot the NEXT frame would take holds the older of two frames in flight
+	bool ok = FinishInflight(older);
+	return FinishInflight(older ^ 1) && ok;
+}
+
+bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats, bool& deferred)
 {
 	Runtime& R = g_rt;
 	const int N = (int)R.ranks.size();
 	RankCtx& R0 = Rank0();
+	const int b = (int)(R.frameNo & 1);
+	deferred = false;
+	// this slot's previous frame (two calls ago) gives up its buffers, events and counter blocks
+	bool ok = FinishInflight(b);
 	const uint32_t W = req.settings.viewportWidth, H = req.settings.viewportHeight;
 	const uint32_t cellsX = (W + 7) / 8, numCells = cellsX * ((H + 7) / 8);
 	ScatterPlan plan; memset(&plan, 0, sizeof(plan));
@@ -707,10 +779,14 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		total += local[(size_t)r];
 	}
 	HIP_OK(hipSetDevice(R0.device));
-	if (!Grow(R.gather, R.gatherBytes, std::max<size_t>(16, (size_t)total * 64 * sizeof(float4)))) return false;
+	if (!Grow(R.gather[b], R.gatherBytes[b], std::max<size_t>(16, (size_t)total * 64 * sizeof(float4)))) return false;
 	float4* out = (float4*)req.outDevice;
 	const size_t frameBytes = (size_t)W * H * sizeof(float4);
-	if (!out) { if (!Grow(R0.image, R0.imageBytes, frameBytes)) return false; out = R0.image; }
+	if (!out) {
+		if (frameBytes > R0.imageBytes) ok = FinishInflight(b ^ 1) && ok;   // the frame in flight may be writing the library's own image: not while it is re-allocated
+		if (!Grow(R0.image, R0.imageBytes, frameBytes)) return false;
+		out = R0.image;
+	}
 
 	// which ranks need a copy: those on another device than rank 0 (and rank 0 itself under RAYLIB_GATHER_SELF)
 	std::vector<char> remote((size_t)N, 0);
@@ -718,64 +794,93 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	for (int r = 0; r < N; ++r) { remote[(size_t)r] = (R.ranks[(size_t)r]->device != R0.device) || (r == 0 && R.gatherSelf); anyRemote = anyRemote || remote[(size_t)r]; }
 	const bool useRccl = anyRemote && R.wantRccl && EnsureRccl();
 
-	std::vector<PendingRender> pend((size_t)N);
+	Runtime::Inflight* F = new Runtime::Inflight;
+	F->pend.resize((size_t)N);
+	F->slot = b; F->t0 = std::chrono::steady_clock::now();
+	memset(&F->stats, 0, sizeof(F->stats));
+	std::vector<PendingRender>& pend = F->pend;
+	float4* gather = R.gather[b];
 	auto run = [&](int r) -> bool {
 		RankCtx& C = *R.ranks[(size_t)r];
 		HIP_OK(hipSetDevice(C.device));
 		RenderRequest q = req;
-		q.cellFirst = (uint32_t)r; q.cellStride = (uint32_t)N; q.cellMajor = true; q.outHostRGBA = nullptr;
+		q.cellFirst = (uint32_t)r; q.cellStride = (uint32_t)N; q.cellMajor = true; q.outHostRGBA = nullptr; q.slot = b;
 		const size_t bytes = (size_t)local[(size_t)r] * 64 * sizeof(float4);
-		float4* dst = R.gather + plan.offset[r];
+		float4* dst = gather + plan.offset[r];
 		if (remote[(size_t)r]) { if (!Grow(C.cells, C.cellsBytes, std::max<size_t>(16, bytes))) return false; q.outDevice = C.cells; }
 		else q.outDevice = dst;   // same device as rank 0: rendered in place, nothing to move
 		if (!EnqueueDispatch(C, sc, q, pend[(size_t)r])) return false;
 		if (remote[(size_t)r] && !useRccl && bytes) HIP_OK(hipMemcpyPeerAsync(dst, R0.device, C.cells, C.device, bytes, C.stream));
-		HIP_OK(hipEventRecord(C.ev[4], C.stream));
+		HIP_OK(hipEventRecord(C.ev[b][4], C.stream));
 		return true;
 	};
 	for (int r = 1; r < N; ++r) R.ranks[(size_t)r]->worker->Post([&run, r]() { return run(r); });
-	bool ok = run(0);
+	ok = run(0) && ok;
 	for (int r = 1; r < N; ++r) ok = R.ranks[(size_t)r]->worker->Wait() && ok;
 	HIP_OK(hipSetDevice(R0.device));
 	if (ok && useRccl) {
-		// one group: rank 0's stream receives every remote rank's cells, each remote rank's stream sends them (behind its kernels)
+		// one group: rank 0's GATHER stream receives every remote rank's cells, each remote rank's stream sends them (behind its kernels)
 		RcclApi& A = R.rccl;
+		// One stream per communicator inside the group: all ranks of a device send on the stream of that device's FIRST rank (the lead), which waits
+		// for the others' kernels; rank 0 sending to itself (RAYLIB_GATHER_SELF, tests) sends and receives on the gather stream.  Afterwards the
+		// other ranks' streams wait for the lead's sends, so that their next frame does not overwrite cells that are still being sent.
+		std::vector<int> lead(R.devices.size(), -1);
+		for (int r = 0; r < N; ++r) if (remote[(size_t)r] && local[(size_t)r] && lead[(size_t)R.ranks[(size_t)r]->devSlot] < 0) lead[(size_t)R.ranks[(size_t)r]->devSlot] = r;
+		auto sendStream = [&](const RankCtx& C) { return C.devSlot == R0.devSlot ? R.gatherStream : R.ranks[(size_t)lead[(size_t)C.devSlot]]->stream; };
+		for (int r = 0; r < N; ++r) {
+			RankCtx& C = *R.ranks[(size_t)r];
+			if (!remote[(size_t)r] || !local[(size_t)r] || lead[(size_t)C.devSlot] == r) continue;
+			(void)hipSetDevice(C.device);
+			HIP_OK(hipStreamWaitEvent(sendStream(C), C.ev[b][4], 0));
+		}
+		if (remote[0] && local[0]) { (void)hipSetDevice(R0.device); HIP_OK(hipStreamWaitEvent(R.gatherStream, R0.ev[b][4], 0)); }
 		int rc = A.GroupStart();
 		for (int r = 0; r < N && rc == 0; ++r) {
 			if (!remote[(size_t)r] || !local[(size_t)r]) continue;
 			RankCtx& C = *R.ranks[(size_t)r];
 			const size_t floats = (size_t)local[(size_t)r] * 64 * 4;
-			rc = A.Recv(R.gather + plan.offset[r], floats, kRcclFloat, C.devSlot, A.comms[(size_t)R0.devSlot], R0.stream);
-			if (rc == 0) rc = A.Send(C.cells, floats, kRcclFloat, R0.devSlot, A.comms[(size_t)C.devSlot], C.stream);
+			rc = A.Recv(gather + plan.offset[r], floats, kRcclFloat, C.devSlot, A.comms[(size_t)R0.devSlot], R.gatherStream);
+			if (rc == 0) rc = A.Send(C.cells, floats, kRcclFloat, R0.devSlot, A.comms[(size_t)C.devSlot], sendStream(C));
 		}
 		const int rcEnd = A.GroupEnd();
 		if (rc != 0 || rcEnd != 0) { Log("Raylib_Render: RCCL gather failed (%s)", A.GetErrorString ? A.GetErrorString(rc ? rc : rcEnd) : "?"); ok = false; }
+		for (size_t sl = 0; sl < lead.size() && ok; ++sl) {
+			if (lead[sl] < 0 || (int)sl == R0.devSlot) continue;
+			RankCtx& L = *R.ranks[(size_t)lead[sl]];
+			(void)hipSetDevice(L.device);
+			HIP_OK(hipEventRecord(L.ev[b][5], L.stream));   // (slots 5 and 6 belong to rank 0 on ITS device; a lead of another device uses its own 5 for "sends done")
+			for (int r = 0; r < N; ++r) if (r != lead[sl] && remote[(size_t)r] && R.ranks[(size_t)r]->devSlot == (int)sl) HIP_OK(hipStreamWaitEvent(R.ranks[(size_t)r]->stream, L.ev[b][5], 0));
+		}
 		(void)hipSetDevice(R0.device);
 	}
-	bool timed = false;
 	if (ok) {
-		for (int r = 1; r < N; ++r) HIP_OK(hipStreamWaitEvent(R0.stream, R.ranks[(size_t)r]->ev[4], 0));
-		HIP_OK(hipEventRecord(R0.ev[5], R0.stream));
+		// the gather stream waits for every rank's "my cells are there" (rank 0's own render included), assembles the frame, and rank 0's
+		// render stream is free for the next frame meanwhile
+		for (int r = 0; r < N; ++r) HIP_OK(hipStreamWaitEvent(R.gatherStream, R.ranks[(size_t)r]->ev[b][4], 0));
+		HIP_OK(hipEventRecord(R0.ev[b][5], R.gatherStream));
 		const uint32_t blocks = (uint32_t)(((size_t)W * H + RL_BLOCK - 1) / RL_BLOCK);
-		hipLaunchKernelGGL(k_scatter_cells, dim3(blocks), dim3(RL_BLOCK), 0, R0.stream, (const float4*)R.gather, out, W, H, cellsX, plan);
+		hipLaunchKernelGGL(k_scatter_cells, dim3(blocks), dim3(RL_BLOCK), 0, R.gatherStream, (const float4*)gather, out, W, H, cellsX, plan);
 		HIP_OK(hipGetLastError());
-		HIP_OK(hipEventRecord(R0.ev[6], R0.stream));
-		timed = true;
-		if (req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, frameBytes, hipMemcpyDeviceToHost, R0.stream));
+		if (req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, frameBytes, hipMemcpyDeviceToHost, R.gatherStream));
+		HIP_OK(hipEventRecord(R0.ev[b][6], R.gatherStream));
+		if (remote[0] && useRccl) HIP_OK(hipStreamWaitEvent(R0.stream, R0.ev[b][5], 0));   // rank 0's self-send has read its cell buffer before the next render writes it
+		F->timed = true;
 	}
-	// every rank's stream is drained whatever happened (the closures above borrow this frame's stack)
-	for (int r = N - 1; r >= 0; --r) {
-		if (pend[(size_t)r].ctx) ok = FinishRender(pend[(size_t)r], stats) && ok;
-		else { (void)hipSetDevice(R.ranks[(size_t)r]->device); (void)hipStreamSynchronize(R.ranks[(size_t)r]->stream); }
+	F->ok = ok;
+	F->stats.ranks = (uint32_t)N; F->stats.devices = (uint32_t)R.devices.size();
+	F->stats.gatherMode = !anyRemote ? 0u : (useRccl ? 1u : 2u);
+	F->stats.rcclCommSize = R.rccl.ok ? (uint32_t)R.rccl.comms.size() : 0u;
+	F->stats.numNodes = (uint32_t)sc.bvh.nodes.size(); F->stats.numTriangles = (uint32_t)sc.triangles.size(); F->stats.bvhDepth = sc.bvh.depth;
+	R.inflight[b] = F;
+	++R.frameNo;
+	if (!ok || !R.pipeline || req.outHostRGBA) {
+		// synchronous after all: a failure (every stream is drained whatever happened), the switch, or pixels wanted in host memory now
+		ok = DrainLocked() && ok;
+		stats = g_deferredStats; g_deferredUnreported = false;
+		return ok;
 	}
-	HIP_OK(hipSetDevice(R0.device));
-	stats.gatherMode = !anyRemote ? 0u : (useRccl ? 1u : 2u);
-	stats.rcclCommSize = R.rccl.ok ? (uint32_t)R.rccl.comms.size() : 0u;
-	if (ok && timed) {   // rank 0's stream is drained: its render-end event, "all cells here" and "frame assembled" have fired
-		float g = 0.0f, s = 0.0f;
-		if (hipEventElapsedTime(&g, R0.ev[1], R0.ev[5]) == hipSuccess) stats.gatherMs = (double)g;
-		if (hipEventElapsedTime(&s, R0.ev[5], R0.ev[6]) == hipSuccess) stats.scatterMs = (double)s;
-	}
+	stats = F->stats;   // counters and times follow when the frame is waited for (RaylibAMD_GetLastStats, any reader of the pixels, the call after next)
+	deferred = true;
 	return ok;
 }
 
@@ -804,10 +909,12 @@ bool DeviceRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 	bool ok;
 	const bool whole = req.cellFirst == 0 && (req.cellStride == 0 || req.cellStride == 1);
 	if (whole && (g_rt.ranks.size() > 1 || g_rt.gatherSelf)) {
-		ok = RenderMulti(sc, req, stats);
-		stats.ranks = (uint32_t)g_rt.ranks.size();
-		stats.devices = (uint32_t)g_rt.devices.size();
+		bool deferred = false;
+		ok = RenderMulti(sc, req, stats, deferred);
+		if (deferred) return ok;    // scene numbers are in; counters, times and wallMs follow at the drain
 	} else {
+		(void)DrainLocked();        // this path uses rank 0's slot-0 events and counter block
+		g_deferredUnreported = false;   // ... and its numbers are the ones the caller reads next
 		PendingRender pend;
 		ok = EnqueueDispatch(Rank0(), sc, req, pend);
 		if (ok && req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, pend.out, pend.outBytes, hipMemcpyDeviceToHost, Rank0().stream));
@@ -816,8 +923,21 @@ bool DeviceRender(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats)
 		stats.ranks = 1; stats.devices = 1;
 	}
 	stats.numNodes = (uint32_t)sc.bvh.nodes.size(); stats.numTriangles = (uint32_t)sc.triangles.size(); stats.bvhDepth = sc.bvh.depth;
-	stats.wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	if (!(whole && (g_rt.ranks.size() > 1 || g_rt.gatherSelf))) stats.wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	return ok;
+}
+
+// Waits for whatever Raylib_Render left in flight.  True with `out` filled when that completed the LAST render call's numbers (counters, times)
+// that the call itself could not report yet.
+bool DeviceDrain(RaylibAMDStats* out)
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	if (!g_rt.ok) return false;
+	(void)DrainLocked();
+	if (!g_deferredUnreported) return false;
+	g_deferredUnreported = false;
+	if (out) *out = g_deferredStats;
+	return true;
 }
 
 bool DeviceClosestHit(Scene& sc, const float* rays, int32_t n, float tMin, void* outHits)
@@ -900,6 +1020,7 @@ void* DeviceImagePixels(Image& img)
 	const size_t need = (size_t)img.width * img.height * sizeof(float4);
 	if (need == 0) return nullptr;
 	if (img.devPixels && img.devBytes >= need) return img.devPixels;
+	(void)DrainLocked();   // a frame in flight may be writing the buffer that is about to be freed
 	if (hipSetDevice(Rank0().device) != hipSuccess) return nullptr;
 	if (img.devPixels) { (void)hipFree(img.devPixels); img.devPixels = nullptr; img.devBytes = 0; }
 	if (hipMalloc(&img.devPixels, need) != hipSuccess) { img.devPixels = nullptr; return nullptr; }
@@ -919,6 +1040,7 @@ bool ReadbackLocked(Image& img)
 	const size_t n = (size_t)img.width * img.height;
 	if (n == 0) return true;
 	if (!g_rt.ok || !img.devPixels || !img.devValid || img.devBytes < n * sizeof(float4)) return false;
+	if (!DrainLocked()) Log("Image read-back: a frame in flight did not complete");
 	HIP_OK(hipSetDevice(Rank0().device));
 	img.rgba.resize(n * 4);
 	HIP_OK(hipMemcpyAsync(img.rgba.data(), img.devPixels, n * sizeof(float4), hipMemcpyDeviceToHost, Rank0().stream));
@@ -931,7 +1053,7 @@ void DeviceFreePixels(void* p)
 {
 	if (!p) return;
 	std::lock_guard<std::mutex> lk(g_rt.lock);
-	if (g_rt.ok) { (void)hipSetDevice(Rank0().device); (void)hipFree(p); }
+	if (g_rt.ok) { (void)DrainLocked(); (void)hipSetDevice(Rank0().device); (void)hipFree(p); }
 }
 
 // Image2D::PostProcess (reference render/image.cc:44-103) on the device: k_pp_max finds the white point
@@ -944,6 +1066,7 @@ bool DevicePostProcess(Image& img)
 	float4* px = (float4*)DeviceImagePixels(img);
 	if (!px) return false;
 	std::lock_guard<std::mutex> lk(g_rt.lock);
+	(void)DrainLocked();   // the frame this works on may still be in flight on the gather stream
 	RankCtx& R = Rank0();
 	HIP_OK(hipSetDevice(R.device));
 	if (!img.devValid) HIP_OK(hipMemcpyAsync(px, img.rgba.data(), n * sizeof(float4), hipMemcpyHostToDevice, R.stream));   // (never stale here: stale implies devValid)
@@ -968,6 +1091,7 @@ void DeviceReleaseScene(DeviceScene* D)
 {
 	if (!D) return;
 	std::lock_guard<std::mutex> lk(g_rt.lock);
+	(void)DrainLocked();   // frames in flight read this scene
 	FreeScene(D);
 }
 

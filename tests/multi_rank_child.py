@@ -26,7 +26,35 @@ def render_all(lib, workdir):
         stats.append((s.ranks, s.cameraSamples, s.pixels, s.rays, s.gatherMode, s.devices, s.rcclCommSize))
         ses.close()
     out["stats"] = np.asarray(stats, np.int64)
+    out.update(back_to_back(lib, workdir))
     return out
+
+
+def back_to_back(lib, workdir):
+    """Calls that leave no time between them: with several ranks Raylib_Render returns with the frame still in flight (csrc/rl_runtime.inl
+    RenderMulti), and whatever comes next -- another render into the same image, into another image, PostProcess, a destroyed image, the
+    stats -- must see the finished frame.  The one-rank run of the same sequence is the reference."""
+    import ctypes as C
+    a = helpers.session_for_case(lib, "cornell", workdir)
+    b = helpers.session_for_case(lib, "pbr_maps", workdir)
+    sta, stb = a.settings(64, 64, 4), b.settings(48, 64, 4)
+    img1, img2, img3 = lib.Raylib_CreateImage(64, 64), lib.Raylib_CreateImage(48, 64), lib.Raylib_CreateImage(64, 64)
+    for _ in range(3):
+        lib.Raylib_Render(C.byref(sta), a.scene, a.camera, img1)          # same image, nothing read in between
+    lib.Raylib_Render(C.byref(stb), b.scene, b.camera, img2)              # another scene and image straight behind
+    lib.Raylib_Render(C.byref(sta), a.scene, a.camera, img3)
+    lib.Raylib_DestroyImage(img3)                                         # destroyed with its frame in flight
+    s = binding.Stats(); lib.RaylibAMD_GetLastStats(C.byref(s))           # of the LAST call (the cornell frame into img3)
+    p1 = np.zeros((64, 64, 4), np.float32); lib.RaylibAMD_DumpImageRGBA(img1, p1.ctypes.data_as(C.POINTER(C.c_float)))
+    p2 = np.zeros((64, 48, 4), np.float32); lib.RaylibAMD_DumpImageRGBA(img2, p2.ctypes.data_as(C.POINTER(C.c_float)))
+    lib.Raylib_Render(C.byref(sta), a.scene, a.camera, img1)
+    lib.Raylib_PostProcess(img1)                                          # works on the frame that was just enqueued
+    p3 = np.zeros((64, 64, 4), np.float32); lib.RaylibAMD_DumpImageRGBA(img1, p3.ctypes.data_as(C.POINTER(C.c_float)))
+    lib.Raylib_DestroyImage(img1); lib.Raylib_DestroyImage(img2)
+    b.close()
+    lib.Raylib_Render(C.byref(sta), a.scene, a.camera, lib.Raylib_CreateImage(64, 64))   # (image leaked on purpose) scene destroyed with a frame in flight:
+    a.close()
+    return {"p1": p1, "p2": p2, "p3": p3, "pstats": np.asarray([s.cameraSamples, s.pixels, s.rays, int(s.kernelMs > 0), int(s.traceKernelMs > 0)], np.int64)}
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 LAYOUTS = [
     dict(RAYLIB_NUM_GPUS="2", RAYLIB_GPU_MAP="0,0"),
+    dict(RAYLIB_NUM_GPUS="2", RAYLIB_GPU_MAP="0,0", RAYLIB_PIPELINE="0"),
     dict(RAYLIB_NUM_GPUS="3", RAYLIB_GPU_MAP="0,0,0"),
     dict(RAYLIB_NUM_GPUS="8", RAYLIB_GPU_MAP="0,0,0,0,0,0,0,0"),
     dict(RAYLIB_NUM_GPUS="1", RAYLIB_GATHER_SELF="1", RAYLIB_GATHER="rccl"),
@@ -58,6 +59,10 @@ def test_raylib_render_over_n_ranks_is_bit_identical(layout, one_rank_frames, wo
     n = int(layout["RAYLIB_NUM_GPUS"])
     for i in range(len(multi_rank_child.FRAMES)):
         assert helpers.same(got["f%d" % i], one_rank_frames["f%d" % i]).all(), multi_rank_child.FRAMES[i]
+    # calls with nothing between them (frames in flight behind Raylib_Render): same pixels, and the last call's counters arrive with GetLastStats
+    for k in ("p1", "p2", "p3"):
+        assert helpers.same(got[k], one_rank_frames[k]).all(), k
+    assert np.array_equal(got["pstats"], one_rank_frames["pstats"]) and got["pstats"][3] == 1 and got["pstats"][4] == 1
     # the same camera samples, pixels and rays, however they were dealt; `ranks` says who rendered
     assert np.array_equal(got["stats"][:, 1:4], one_rank_frames["stats"][:, 1:4])
     assert (got["stats"][:, 0] == n).all() and (one_rank_frames["stats"][:, 0] == 1).all()

@@ -1,0 +1,21 @@
+"""Phase shares of the Cornell frame's megakernel from the diagnostic builds (make variant VARIANT=stamps EXTRA=-DRL_DIAG_STAMPS=1, =2 for
+wave-step against lane-step counts): RAYLIB_LIB=.../libraylib_stamps.so python tools/gpu_stamps.py [workload]"""
+import os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
+os.environ["RAYLIB_PRINT_STAMPS"] = "1"
+os.environ.pop("RAYLIB_QUIET", None)
+from raylib_amd import binding, scenes
+lib = binding.load(); assert lib.Raylib_Initialize() == 1
+d = tempfile.mkdtemp()
+which = sys.argv[1] if len(sys.argv) > 1 else "cornell"
+if which == "cornell":
+    cam = scenes.CONFIG_CAMERAS["cornell"]; obj, _ = scenes.cornell(os.path.join(d, "c.obj")); spp = 64
+else:
+    cam = scenes.CONFIG_CAMERAS["breakfast"]; obj, _ = scenes.cornell(os.path.join(d, "b.obj"), tess=91, displace_fraction=0.2); spp = 128
+ses = binding.SceneSession(lib, obj, cam["origin"], cam["look_at"], cam["fov"], 1920 / 1080, sun=cam["sun"], sun_dir=cam["sun_dir"])
+ses.render(1920, 1080, 1)
+ses.render(1920, 1080, spp)
+s = ses.stats()
+print("trace %.3f ms; rays %d, samples %d, wave trips %d, nodes %d, tris %d, shaded %d" % (s.traceKernelMs, s.rays, s.cameraSamples, s.waveTrips, s.nodesVisited, s.trisTested, s.shadedHits), flush=True)
+lib.Raylib_FlushLogThread()
