@@ -131,6 +131,11 @@ RAYLIB_API int32_t RaylibAMD_EvalTexture(SceneHandle scene, int32_t texture, int
  * part), 11 sqrtf, 12 x / y, 13 fmodf(x, 1).  y may be NULL for one-argument functions. */
 RAYLIB_API int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int32_t n, float* out);
 
+/* Test hook: the device's short exact sequences for 1.0f / x (which = 0) and sqrtf(x) (which = 1) -- csrc/rl_glibc_math.h rcp1_ / sqrtf_, used by
+ * normalize and every reciprocal of the shading code -- against the compiler's IEEE expansions on ALL 2^32 float bit patterns, on the device.
+ * outMismatches: inputs whose results differ (a NaN may differ in payload); outFirstBits: the smallest such bit pattern.  Returns 1 when the sweep ran. */
+RAYLIB_API int32_t RaylibAMD_VerifyExactMath(int32_t which, uint64_t* outMismatches, uint64_t* outFirstBits);
+
 /* ---- host-logic introspection (no GPU needed) ---------------------------------- */
 /* Flattened scene as the kernels see it.  Triangle record = 26 words, material record =
  * 19 words, both laid out as oracle/flat_scene.h FlatTriangle / FlatMaterial. */

@@ -453,6 +453,12 @@ int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int
 	return DeviceEvalMath(fn, x, y, n, out) ? 1 : 0;
 }
 
+int32_t RaylibAMD_VerifyExactMath(int32_t which, uint64_t* outMismatches, uint64_t* outFirstBits)
+{
+	if (which < 0 || which > 1) return 0;
+	return DeviceVerifyExactMath(which, outMismatches, outFirstBits) ? 1 : 0;
+}
+
 int32_t RaylibAMD_ClosestHit(SceneHandle sh, const float* rays, int32_t n, float tMin, void* outHits)
 {
 	Scene* s = (Scene*)sh;

@@ -257,7 +257,7 @@ static void QuantizeWide(BVH& out)
 	auto run = [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) {
 		const DNode4& n = out.nodes4[i];
 		DNode4Q q; memset(&q, 0, sizeof(q));
-		uint32_t exps = 0;
+		float steps[3] = { 0.0f, 0.0f, 0.0f };
 		for (int a = 0; a < 3; ++a) {
 			float lo = FLT_MAX, hi = -FLT_MAX;
 			for (int k = 0; k < 4; ++k) if (n.child[k] != DNODE_EMPTY) { lo = std::min(lo, n.lo[a][k]); hi = std::max(hi, n.hi[a][k]); }
@@ -269,7 +269,7 @@ static void QuantizeWide(BVH& out)
 			if (extent > 0.0) { int x; (void)frexp(extent / 255.0, &x); e = std::max(1, std::min(254, x + 127)); }   // 2^x >= extent / 255
 			double step = ldexp(1.0, e - 127);
 			while (255.0 * step < extent && e < 254) { ++e; step *= 2.0; }
-			exps |= (uint32_t)e << (8 * a);
+			steps[a] = (float)step;   // a power of two between 2^-126 and 2^127: exact
 			for (int k = 0; k < 4; ++k) {
 				if (n.child[k] == DNODE_EMPTY) { q.qlo[a] |= 255u << (8 * k); continue; }   // inverted: lower 255, upper 0
 				double l = floor(((double)n.lo[a][k] - (double)lo) / step), h = ceil(((double)n.hi[a][k] - (double)lo) / step);
@@ -280,7 +280,7 @@ static void QuantizeWide(BVH& out)
 				q.qhi[a] |= (uint32_t)h << (8 * k);
 			}
 		}
-		q.exps = exps;
+		q.stepX = steps[0]; q.stepY = steps[1]; q.stepZ = steps[2];
 		for (int k = 0; k < 4; ++k) q.child[k] = n.child[k];
 		out.nodes4q[i] = q;
 	} };
@@ -599,7 +599,8 @@ bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris)
 				if (q.child[k] != n.child[k]) return false;
 				if (n.child[k] == DNODE_EMPTY) continue;
 				for (int a = 0; a < 3; ++a) {
-					const double step = ldexp(1.0, (int)((q.exps >> (8 * a)) & 255u) - 127);
+					const double step = (double)(a == 0 ? q.stepX : (a == 1 ? q.stepY : q.stepZ));
+					{ int e2 = 0; if (!(step > 0.0) || frexp(step, &e2) != 0.5) return false; }   // a power of two
 					const double lo = (double)q.origin[a] + (double)((q.qlo[a] >> (8 * k)) & 255u) * step, hi = (double)q.origin[a] + (double)((q.qhi[a] >> (8 * k)) & 255u) * step;
 					if (!(lo <= (double)n.lo[a][k] && hi >= (double)n.hi[a][k])) return false;
 				}

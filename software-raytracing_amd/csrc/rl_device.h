@@ -40,12 +40,13 @@ static_assert(sizeof(DNode4) == 128, "DNode4");
 // Child k's box along axis a is [origin[a] + qlo_a,k * step_a, origin[a] + qhi_a,k * step_a], step_a = 2^(e_a - 127): the grid is
 // anchored at the minimum corner of the node's own box, lower planes are rounded down and upper planes up, so a child's grid box
 // CONTAINS its float box.  The closest hit does not depend on how tight a box is (candidate rule, rl_render.hip OwnBoxPass): the
-// image stays bit-identical.  exps: byte a = e_a, the biased exponent of a float (step_a = as_float(e_a << 23)).
+// image stays bit-identical.  stepX / stepY / stepZ: the grid steps as floats (powers of two), in the fourth word of the three 16-byte rows (round 3:
+// one word of packed exponents before -- three shifts and three masks per node step to unpack, on a kernel that is bound by VALU issue).
 // qlo[a] / qhi[a]: byte k = child k.  An unused child has child[k] == DNODE_EMPTY (and an inverted grid box).
 struct alignas(64) DNode4Q {
-	float origin[3]; uint32_t exps;
-	uint32_t qlo[3]; uint32_t pad0;
-	uint32_t qhi[3]; uint32_t pad1;
+	float origin[3]; float stepX;
+	uint32_t qlo[3]; float stepY;
+	uint32_t qhi[3]; float stepZ;
 	int32_t child[4];
 };
 static_assert(sizeof(DNode4Q) == 64, "DNode4Q");

@@ -79,4 +79,18 @@ __device__ __forceinline__ void sincos_signs_(float x, bool* sn, bool* cn) { rlm
 #endif
 __device__ __forceinline__ float fmod1_(float x) { return fmodf(x, 1.0f); }
 
+// ---- 1.0f / x and sqrtf(x), correctly rounded, in fewer issue cycles ---------------------------------------------------------------------
+// The compiler's IEEE expansions are long: 1.0f / x = v_div_scale x 2, v_rcp, five fma / mul, v_div_fmas, v_div_fixup = 36 VALU issue cycles per
+// wave64; sqrtf = v_sqrt, both neighbours tried with an fma residual each, compares, selects, scaling for tiny inputs = 57 (tools/valu_calib.hip's
+// cost table; tools/static_profile.py finds 23 sqrtf sites = 8 % of the Cornell kernel's static issue cycles).  Both kernels sit on the VALU issue
+// port, and most divisions of a scattering event are reciprocals: normalize, 1 / tan, 1 / (1 + ...).
+//   rcp1_:  r0 = v_rcp_f32(x) (1 ulp); r = fma(fma(-x, r0, 1), r0, r0)                           -- for 2^-126 <= |x| < 2^126
+//   sqrt_:  y = v_rsq_f32(x); g = x * y; h = y / 2; g = fma(fma(-g, g, x), h, g)                 -- for 2^-101 <= x <= FLT_MAX
+// are the correctly rounded results for EVERY input of those ranges: tools/verify_fastmath.hip compares all 2^32 bit patterns with the compiler's
+// expansions on the device (0 mismatches inside the ranges; outside -- zeros, denormals, the tiny inputs whose residual would underflow, infinities,
+// NaN, negative radicands -- the expansion itself runs), and RaylibAMD_VerifyExactMath repeats that sweep inside the product library
+// (tests/test_math_exact.py).  20 and 22 issue cycles instead of 36 and 57.  The sequences live in rl_glibc_math.h (its acosf / asinf take square roots too).
+__device__ __forceinline__ float rcp1_(float x) { return rlm::rcp1_(x); }
+__device__ __forceinline__ float sqrt_(float x) { return rlm::sqrtf_(x); }
+
 }} // namespace rl::rtm

@@ -55,9 +55,6 @@ __shared__ double rlm_lds_tab[80];
 namespace rl {
 
 #define RL_BLOCK 256
-#ifndef RL_POOL_SHARED_CHUNK
-#define RL_POOL_SHARED_CHUNK 0   /* pool schedule: the workgroup's waves draw 64-job batches from one chunk in LDS (TakeBatch) */
-#endif
 #ifndef RL_ROOTMISS_RCP
 #define RL_ROOTMISS_RCP 1
 #endif
@@ -90,8 +87,9 @@ __device__ __forceinline__ V3 operator+(V3 a, float t) { return v3(a.x + t, a.y 
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float absDot(V3 a, V3 b) { return fabsf(a.x * b.x + a.y * b.y + a.z * b.z); }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
-__device__ __forceinline__ V3 normalize(V3 a) { float k = 1.0f / length(a); return v3(a.x * k, a.y * k, a.z * k); }
+// (rtm::sqrt_ and rtm::rcp1_ are sqrtf and 1.0f / x bit for bit: rl_math.h)
+__device__ __forceinline__ float length(V3 a) { return rtm::sqrt_(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 normalize(V3 a) { float k = rtm::rcp1_(length(a)); return v3(a.x * k, a.y * k, a.z * k); }
 __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; }
 __device__ __forceinline__ V3 mix(V3 a, V3 b, float t) { return (1.0f - t) * a + t * b; }
 __device__ __forceinline__ V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
@@ -145,7 +143,7 @@ __device__ __forceinline__ V3 RandomInUnitSphere(Rng& g)
 	float u1 = Next(g);
 	float u2 = Next(g);
 	float z = 1.0f - 2.0f * u1;
-	float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+	float r = rtm::sqrt_(fmaxf(0.0f, 1.0f - z * z));
 	float phi = 2.0f * 3.141592f * u2;
 	float sn, cs; rtm::sincos_(phi, &sn, &cs);
 	return v3(r * cs, r * sn, z);
@@ -155,7 +153,7 @@ __device__ __forceinline__ V3 RandomInUnitDisk(Rng& g)
 {
 	float u1 = Next(g);
 	float u2 = Next(g);
-	float r = sqrtf(u1);
+	float r = rtm::sqrt_(u1);
 	float theta = 2.0f * 3.14159265358979323846f * u2;
 	float sn, cs; rtm::sincos_(theta, &sn, &cs);
 	return v3(r * cs, r * sn, 0.0f);
@@ -374,7 +372,7 @@ __device__ __forceinline__ bool RootMiss(const DSceneView& S, V3 o, V3 d, float 
 #if RL_ROOTMISS_RCP
 	const V3 inv = v3(FastRcp(d.x), FastRcp(d.y), FastRcp(d.z));
 #else
-	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const V3 inv = v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z));
 #endif
 	const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
 	const float4* np = LDS ? sm + RL_LDS_ROOT : (const float4*)(S.nodes);
@@ -402,9 +400,9 @@ __device__ __noinline__ float SphereHit(const DSphere* spheres, int index, V3 o,
 	float c = dot(oc, oc) - radius * radius;
 	float D = b * b - a * c;
 	if (D > 0.0f) {
-		float temp = (-b - sqrtf(b * b - a * c)) / a;
+		float temp = (-b - rtm::sqrt_(b * b - a * c)) / a;
 		if (t_min < temp && temp < FLT_MAX) return (temp < tBest) ? temp : NAN;   // the reference takes this root and compares later
-		temp = (-b + sqrtf(b * b - a * c)) / a;
+		temp = (-b + rtm::sqrt_(b * b - a * c)) / a;
 		if (t_min < temp && temp < FLT_MAX) return (temp < tBest) ? temp : NAN;
 	}
 	return NAN;
@@ -455,7 +453,7 @@ template <int STACK, bool ANYHIT, bool PRIMS>
 __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c)
 {
 	c.rays++;
-	const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const V3 inv = v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z));
 	const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
 	best.t = INFINITY; best.tri = -1; best.a = 0.0f; best.b = 0.0f;
 	int sp = 0;
@@ -550,8 +548,7 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 	const float4* np_ = (const float4*)((S_).nodes4 + (cur_)); \
 	const float4 h0_ = np_[0]; const uint4 l_ = ((const uint4*)np_)[1]; const uint4 u_ = ((const uint4*)np_)[2]; \
 	const int4 ch = ((const int4*)np_)[3]; \
-	const uint32_t ex_ = __float_as_uint(h0_.w); \
-	const float Ax_ = __uint_as_float((ex_ & 0xffu) << 23) * (inv_).x, Ay_ = __uint_as_float(((ex_ >> 8) & 0xffu) << 23) * (inv_).y, Az_ = __uint_as_float(((ex_ >> 16) & 0xffu) << 23) * (inv_).z; \
+	const float Ax_ = h0_.w * (inv_).x, Ay_ = __uint_as_float(l_.w) * (inv_).y, Az_ = __uint_as_float(u_.w) * (inv_).z; \
 	const float Bx_ = (h0_.x - (o_).x) * (inv_).x, By_ = (h0_.y - (o_).y) * (inv_).y, Bz_ = (h0_.z - (o_).z) * (inv_).z; \
 	const float Ex_ = __builtin_fmaf(255.0f, fabsf(Ax_), fabsf(Bx_)) * 4.76837158e-7f, Ey_ = __builtin_fmaf(255.0f, fabsf(Ay_), fabsf(By_)) * 4.76837158e-7f, Ez_ = __builtin_fmaf(255.0f, fabsf(Az_), fabsf(Bz_)) * 4.76837158e-7f; \
 	const float Bnx_ = Bx_ - Ex_, Bfx_ = Bx_ + Ex_, Bny_ = By_ - Ey_, Bfy_ = By_ + Ey_, Bnz_ = Bz_ - Ez_, Bfz_ = Bz_ + Ez_; \
@@ -596,7 +593,7 @@ template <bool ANYHIT>
 __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d, float tMin, HitRec& best, Counters& c, const float4* sm)
 {
 	c.rays++;
-	const V3 invb = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const V3 invb = v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z));
 	const bool nx = invb.x < 0.0f, ny = invb.y < 0.0f, nz = invb.z < 0.0f;
 	best.t = INFINITY; best.tri = -1; best.a = 0.0f; best.b = 0.0f;
 	uint32_t key[4 * RL_LEAFLIST_RECORDS];
@@ -679,7 +676,7 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const float wv = dot(w, T.v), wu = dot(w, T.u);
 			const float pa = (T.uv * wv - T.vv * wu) / T.denom;
 			const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPassMnMx(tr, o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tMin, t)) {
+			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPassMnMx(tr, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
 				if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 				best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 				if (ANYHIT) return true;
@@ -696,7 +693,7 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 {
 	if constexpr (LDS == 2) return TraverseLeafList<ANYHIT>(S, o, d, tMin, best, c, sm);
 	c.rays++;
-	V3 invb = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // for the box tests (the candidate rule divides again: exact, and rare)
+	V3 invb = v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z));   // for the box tests (the candidate rule divides again: exact, and rare)
 	if (!FULL) invb = ClampInv(invb);
 	const bool nx = invb.x < 0.0f, ny = invb.y < 0.0f, nz = invb.z < 0.0f;
 	best.t = INFINITY; best.tri = -1; best.a = 0.0f; best.b = 0.0f;
@@ -741,7 +738,7 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 				const float wv = dot(w, T.v), wu = dot(w, T.u);
 				const float pa = (T.uv * wv - T.vv * wu) / T.denom;
 				const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tMin, t)) {
+				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
 					if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 					best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 					if (ANYHIT) return true;
@@ -839,7 +836,7 @@ __device__ RL_ERFINV_ATTR float ErfInv(float x)
 		p = 0.246640727f + p * w;
 		p = 1.50140941f + p * w;
 	} else {
-		w = sqrtf(w) - 3;
+		w = rtm::sqrt_(w) - 3;
 		p = -0.000200214257f;
 		p = 0.000100950558f + p * w;
 		p = 0.00134934322f + p * w;
@@ -859,11 +856,11 @@ __device__ RL_ERF_ATTR float Erf(float x)
 	int sign = 1;
 	if (x < 0) sign = -1;
 	x = fabsf(x);
-	float t = 1 / (1 + p * x);
+	float t = rtm::rcp1_(1 + p * x);
 	float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * rtm::exp_(-x * x);
 	return sign * y;
 }
-__device__ __forceinline__ float SinThetaL(V3 w) { return sqrtf(fmaxf(0.0f, 1.0f - w.z * w.z)); }
+__device__ __forceinline__ float SinThetaL(V3 w) { return rtm::sqrt_(fmaxf(0.0f, 1.0f - w.z * w.z)); }
 __device__ __forceinline__ float CosPhi(V3 w) { float s = SinThetaL(w); return (s == 0) ? 1 : Clampf(w.x / s, -1, 1); }
 __device__ __forceinline__ float SinPhi(V3 w) { float s = SinThetaL(w); return (s == 0) ? 0 : Clampf(w.y / s, -1, 1); }
 
@@ -873,15 +870,15 @@ __device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slo
 	(void)cn;   // diagnostic builds count Newton iterations
 	const float Pi = RL_PI;
 	if ((double)cosThetaI > .9999) {
-		float r = sqrtf(-rtm::log_(1.0f - U1));
+		float r = rtm::sqrt_(-rtm::log_(1.0f - U1));
 		float sinPhi, cosPhi; rtm::sincos_(2 * Pi * U2, &sinPhi, &cosPhi);
 		*slope_x = r * cosPhi;
 		*slope_y = r * sinPhi;
 		return;
 	}
-	float sinThetaI = sqrtf(fmaxf((float)0, (float)1 - cosThetaI * cosThetaI));
+	float sinThetaI = rtm::sqrt_(fmaxf((float)0, (float)1 - cosThetaI * cosThetaI));
 	float tanThetaI = sinThetaI / cosThetaI;
-	float cotThetaI = 1 / tanThetaI;
+	float cotThetaI = rtm::rcp1_(tanThetaI);
 
 	float a = -1, c = Erf(cotThetaI);
 	float sample_x = fmaxf(U1, (float)1e-6f);
@@ -891,7 +888,7 @@ __device__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slo
 	float b = c - (1 + c) * rtm::pow_(1 - sample_x, fit);
 
 	const float SQRT_PI_INV = 1.f / sqrtf(Pi);
-	float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * rtm::exp_(-cotThetaI * cotThetaI));
+	float normalization = rtm::rcp1_(1 + c + SQRT_PI_INV * tanThetaI * rtm::exp_(-cotThetaI * cotThetaI));
 
 	int it = 0;
 	float invErf = 0.0f;
@@ -945,7 +942,7 @@ __device__ __forceinline__ float GeometryBeckmann(V3 N, V3 H, V3 V, float roughn
 {
 	float thetaV = rtm::acos_(dot(N, V));
 	float tanThetaV = rtm::tan_(thetaV);
-	float a = 1.0f / (roughness * tanThetaV);
+	float a = rtm::rcp1_(roughness * tanThetaV);
 	float aa = a * a;
 	if (dot(V, H) / dot(V, N) <= 0.0f) return 0.0f;
 	if (a < 1.6f) {
@@ -1049,7 +1046,7 @@ __device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 in
 				cosine = m.ior * dot(inD, s.n) / length(inD);
 			} else {
 				outward_normal = s.n;
-				ni_over_nt = 1.0f / m.ior;
+				ni_over_nt = rtm::rcp1_(m.ior);
 				cosine = -dot(inD, s.n) / length(inD);
 			}
 			bool bRefract;
@@ -1058,7 +1055,7 @@ __device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 in
 				float dt = dot(uv, outward_normal);
 				float D = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
 				bRefract = D > 0.0f;
-				if (bRefract) refracted = ni_over_nt * (uv - outward_normal * dt) - outward_normal * sqrtf(D);
+				if (bRefract) refracted = ni_over_nt * (uv - outward_normal * dt) - outward_normal * rtm::sqrt_(D);
 			}
 			if (bRefract) {
 				float r0 = (1.0f - m.ior) / (1.0f + m.ior);
@@ -1097,7 +1094,7 @@ __device__ __forceinline__ bool Scatter(const DSceneView& S, const Mat& m, V3 in
 			V3 F = F0 + (1.0f - F0) * rtm::pow_(1.0f - absDot(Wh, Wo), 5.0f);
 			float ggx2 = GeometryBeckmann(N, Wh, Wo, roughness);
 			float ggx1 = GeometryBeckmann(N, Wh, Wi, roughness);
-			float G = 1.0f / (1.0f + ggx1 * ggx2);
+			float G = rtm::rcp1_(1.0f + ggx1 * ggx2);
 			float NDF = DistributionBeckmann(N, Wh, roughness);
 
 			V3 kS = F;
@@ -1274,42 +1271,6 @@ __device__ __forceinline__ bool TakeJobs(const DRenderParams& P, unsigned int* _
 		key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
 		if (key < 64u) return false;
 		js.cur = key & 7u; js.left = key & ~63u;
-	}
-}
-
-// The workgroup's share of the job list: its waves draw BATCHES of 64 jobs (one cell at one sample) from one chunk in LDS -- an LDS atomic -- and whoever
-// finds the chunk used up takes the lock, draws the next chunk from the XCD's head (TakeJobs: the one global atomic per chunk) and publishes it.  The
-// chunk is the granule of the global list, the batch the granule of a wave's work: when the list runs dry a wave has a batch in front of it, not a chunk.
-// (k_trace's leaf-list instantiation has the same logic inline, with its bounded-wait test variant; this is the pool schedule's.)
-struct WgJobs { unsigned long long* jobs; unsigned int* lock; unsigned int* done; };   // LDS: (next job | end of the chunk << 32), lock word, "the list is used up"
-__device__ __forceinline__ bool TakeBatch(const DRenderParams& P, unsigned int* __restrict__ heads, JobSource& js, WgJobs w, uint32_t lane, uint32_t& base, uint32_t& end)
-{
-	for (;;) {
-		unsigned long long st = 0ull;
-		if (lane == 0) st = atomicAdd(w.jobs, 64ull);
-		st = __shfl(st, 0);
-		const uint32_t nx = (uint32_t)st, en = (uint32_t)(st >> 32);
-		if (nx < en) { base = nx; end = min(nx + 64u, en); return true; }
-		if (__atomic_load_n(w.done, __ATOMIC_RELAXED) != 0u) return false;
-		uint32_t won = 0;
-		if (lane == 0) won = atomicCAS(w.lock, 0u, 1u) == 0u ? 1u : 0u;
-		won = __shfl(won, 0);
-		if (won) {
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			const unsigned long long cur = __atomic_load_n(w.jobs, __ATOMIC_RELAXED);
-			if ((uint32_t)cur >= (uint32_t)(cur >> 32) && __atomic_load_n(w.done, __ATOMIC_RELAXED) == 0u) {   // still used up: nobody refilled it in between
-				uint32_t b = 0, e = 0;
-				const bool got = TakeJobs(P, heads, js, P.jobChunk, lane, b, e);
-				if (lane == 0) {
-					if (!got) __atomic_store_n(w.done, 1u, __ATOMIC_RELAXED);
-					else __atomic_store_n(w.jobs, (unsigned long long)b | ((unsigned long long)e << 32), __ATOMIC_RELAXED);
-				}
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (lane == 0) __atomic_store_n(w.lock, 0u, __ATOMIC_RELAXED);
-		} else {
-			while (__atomic_load_n(w.lock, __ATOMIC_RELAXED) != 0u) __builtin_amdgcn_s_sleep(2);   // microseconds: one global atomic
-		}
 	}
 }
 
@@ -1819,6 +1780,9 @@ __device__ __forceinline__ bool PopOrFinish(Trav& T, int* stk, int* ovf)
 	T.leafI = 0;
 	return false;
 }
+// min(t, FLT_MAX) for a t that is never NaN (a hit distance, or +inf): one integer minimum on the bit patterns -- floats below FLT_MAX, negative ones
+// included, are below 0x7f7fffff as signed integers too -- where fminf costs the compiler's canonicalising v_max t, t in front of the v_min
+__device__ __forceinline__ float ClampToFltMax(float t) { return __int_as_float(min(__float_as_int(t), 0x7f7fffff)); }
 template <int LSTACK, int STACK>
 __device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c)
 {
@@ -1828,7 +1792,7 @@ __device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMi
 	const int4 k = ((const int4*)np)[3];
 	c.nodes++;
 	float tl, tr;
-	const float tmx = fminf(T.best.t, FLT_MAX);
+	const float tmx = ClampToFltMax(T.best.t);
 	bool hl = Slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tl, RL_POOL_WIDEN);
 	bool hr = Slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tr, RL_POOL_WIDEN);
 	hl = hl && (k.x != DNODE_EMPTY);
@@ -1852,7 +1816,7 @@ __device__ __forceinline__ bool NodeStep4(const DSceneView& S, Trav& T, float tM
 {
 	RL_WSTEP(4);
 	c.nodes += RL_Q4 ? 1 : 2;   // 64-byte records fetched
-	const float tmx = fminf(T.best.t, FLT_MAX);
+	const float tmx = ClampToFltMax(T.best.t);
 #if RL_Q4
 	RL_WIDE_STEP_Q(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)   // T.inv was clamped when the ray was fetched
 #else
@@ -1897,7 +1861,7 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 			const float wv = dot(w, TT.v), wu = dot(w, TT.u);
 			const float pa = (TT.uv * wv - TT.vv * wu) / TT.denom;
 			const float pb = (TT.uv * wu - TT.uu * wv) / TT.denom;
-			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(TT.v0, TT.v1, TT.v2, o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tMin, t)) {
+			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(TT.v0, TT.v1, TT.v2, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
 				if (!alpha || AlphaTestCandidate(S, i, pa, pb, c)) {
 					T.best.t = t; T.best.a = pa; T.best.b = pb; T.best.tri = i;
 					if (T.anyhit) return true;
@@ -2003,15 +1967,10 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 	int* ovf = ovfStore;
 	__shared__ float s_pool[RL_BLOCK / 64][PoolOcc<LSTACK, PRIMS, K>::kFields][PP];
 	__shared__ unsigned char s_free[RL_BLOCK / 64][PP];
-#if RL_POOL_SHARED_CHUNK
-	__shared__ unsigned long long s_jobs;
-	__shared__ unsigned int s_lock, s_done;
-	if (threadIdx.x == 0) { s_jobs = 0ull; s_lock = 0u; s_done = 0u; }
-	__syncthreads();
-	const WgJobs wg = { &s_jobs, &s_lock, &s_done };
-#endif
+
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const float tMinC = __builtin_canonicalizef(P.rayTMin);   // known to be canonical: the box tests' max chains start from it without a v_max x, x per step
 	float (*pool)[PP] = s_pool[wave];
 	unsigned char* freeList = s_free[wave];
 	const uint32_t numSlots = P.numLocalCells * 64u;
@@ -2095,11 +2054,8 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 			for (int round = 0; round < RL_REFILL_ROUNDS && filled < nFree; ++round) {
 				if (chunkNext >= chunkEnd && !globalDone) {
 					uint32_t base = 0, bend = 0;
-#if RL_POOL_SHARED_CHUNK
-					if (!TakeBatch(P, jobCounter, js, wg, lane, base, bend)) { globalDone = true; RL_TIMELINE(1); }
-#else
+					// (a chunk shared by the workgroup's waves in 64-job batches, as in the leaf-list kernel, was measured here too: 44.5 ms against 43.9)
 					if (!TakeJobs(P, jobCounter, js, P.jobChunk, lane, base, bend)) { globalDone = true; RL_TIMELINE(1); }
-#endif
 					else { chunkNext = base; chunkEnd = bend; }
 				}
 				const uint32_t avail = chunkEnd - chunkNext;
@@ -2250,7 +2206,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 					const bool atNode = busy && T.cur >= 0, atLeaf = busy && T.cur < 0;
 					const int nN = (int)__popcll(__ballot(atNode)), nL = (int)__popcll(__ballot(atLeaf));
 					bool fin = false;
-					if (nN * (WIDE ? RL_POOL_WNODE4 : RL_POOL_WNODE) >= nL * (WIDE ? RL_POOL_WLEAF4 : RL_POOL_WLEAF)) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, P.rayTMin, stk, ovf, c); }
+					if (nN * (WIDE ? RL_POOL_WNODE4 : RL_POOL_WNODE) >= nL * (WIDE ? RL_POOL_WLEAF4 : RL_POOL_WLEAF)) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(S, T, tMinC, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, tMinC, stk, ovf, c); }
 					else { if (atLeaf) fin = LeafStep<LSTACK, STACK, PRIMS>(S, T, P.rayTMin, stk, ovf, c); }
 					if (fin) {
 						const bool hit = T.best.tri >= 0;
@@ -2436,7 +2392,7 @@ k_resolve(const DRenderParams P, const SampleRGB* __restrict__ samples, float4* 
 			a.x += v.x; a.y += v.y; a.z += v.z;
 		}
 		if (lastBatch) {
-			const float k = 1.0f / (float)P.spp;
+			const float k = rtm::rcp1_((float)P.spp);
 			a.x *= k; a.y *= k; a.z *= k; a.w = 1.0f;
 		} else {
 			accum[slot] = a;
@@ -2672,9 +2628,28 @@ k_eval_math(int fn, const float* __restrict__ x, const float* __restrict__ y, in
 		case 11: r = sqrtf(a); break;
 		case 12: r = a / b; break;
 		case 13: r = rtm::fmod1_(a); break;
+		case 14: r = rtm::rcp1_(a); break;
+		case 15: r = rtm::sqrt_(a); break;
 		default: break;
 	}
 	out[i] = r;
+}
+
+// Test hook: rtm::rcp1_ / rtm::sqrt_ (the short exact sequences of rl_glibc_math.h) against the compiler's IEEE expansions of 1.0f / x and sqrtf(x)
+// on EVERY float bit pattern, inside the product library.  out[0] = mismatching inputs, out[1] = the smallest mismatching bit pattern.
+__global__ void __launch_bounds__(RL_BLOCK)
+k_verify_exact_math(int which, unsigned long long* __restrict__ out)
+{
+	const unsigned long long tid = (unsigned long long)blockIdx.x * RL_BLOCK + threadIdx.x, n = (unsigned long long)gridDim.x * RL_BLOCK;
+	unsigned long long bad = 0, first = ~0ull;
+	for (unsigned long long b = tid; b < (1ull << 32); b += n) {
+		const float x = __uint_as_float((uint32_t)b);
+		const float want = which == 0 ? 1.0f / x : __builtin_sqrtf(x);
+		const float got = which == 0 ? rtm::rcp1_(x) : rtm::sqrt_(x);
+		const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got);   // a NaN must meet a NaN
+		if (!same) { ++bad; first = min(first, b); }
+	}
+	if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first); }
 }
 
 // The frame from the ranks' cell buffers (N > 1 behind Raylib_Render): cell c was rendered by rank c % N as its (c / N)-th cell.

@@ -1012,6 +1012,26 @@ bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out)
 	return ok;
 }
 
+bool DeviceVerifyExactMath(int which, uint64_t* outMismatches, uint64_t* outFirst)
+{
+	std::lock_guard<std::mutex> lk(g_rt.lock);
+	if (!EnsureRuntime()) return false;
+	RankCtx& R = Rank0();
+	HIP_OK(hipSetDevice(R.device));
+	unsigned long long* d = nullptr;
+	HIP_OK(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+	unsigned long long h[2] = { 0ull, ~0ull };
+	bool ok = hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess;
+	if (ok) {
+		hipLaunchKernelGGL(k_verify_exact_math, dim3(4096), dim3(RL_BLOCK), 0, R.stream, which, d);
+		ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(R.stream) == hipSuccess && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+	}
+	(void)hipFree(d);
+	if (outMismatches) *outMismatches = h[0];
+	if (outFirst) *outFirst = h[1];
+	return ok;
+}
+
 // Images live on rank 0's device.
 void* DeviceImagePixels(Image& img)
 {

@@ -108,6 +108,7 @@ _EXPORTS = {
     "RaylibAMD_EvalTexture": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "RaylibAMD_EvalDeviceMath": (C.c_int32, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "RaylibAMD_ClosestHit": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]),
+    "RaylibAMD_VerifyExactMath": (C.c_int32, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "RaylibAMD_SceneNumTriangles": (C.c_int32, [C.c_void_p]),
     "RaylibAMD_SceneNumMaterials": (C.c_int32, [C.c_void_p]),
     "RaylibAMD_SceneNumTextures": (C.c_int32, [C.c_void_p]),

@@ -84,3 +84,26 @@ def test_device_math_is_bit_identical_to_host_libm(gpu_lib):
     out = np.zeros_like(x)
     gpu_lib.RaylibAMD_EvalDeviceMath(12, x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)), n, out.ctypes.data_as(C.POINTER(C.c_float)))
     assert np.array_equal(out.view(np.uint32), (x / y).astype(np.float32).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_short_exact_reciprocal_and_square_root_on_every_float(gpu_lib):
+    """normalize, 1 / tan, 1 / (1 + ...), the ray's 1 / d: on the device `1.0f / x` and `sqrtf(x)` run as short sequences (csrc/rl_glibc_math.h
+    rcp1_ / sqrtf_: v_rcp + one Newton step, v_rsq + one residual step, inside a range guard) instead of the compiler's 36- and 57-cycle IEEE
+    expansions.  They must BE those expansions' results: all 2^32 bit patterns are compared on the device, inside the product library."""
+    for which, name in ((0, "1.0f / x"), (1, "sqrtf(x)")):
+        bad, first = C.c_uint64(1), C.c_uint64(0)
+        assert gpu_lib.RaylibAMD_VerifyExactMath(which, C.byref(bad), C.byref(first)) == 1
+        print("%s: %d of 2^32 inputs differ from the IEEE expansion" % (name, bad.value))
+        assert bad.value == 0, "%s: %d mismatches, first at bits 0x%08x" % (name, bad.value, first.value)
+    # and through the array hook, against the host: 1 / x and sqrt are correctly rounded on both sides
+    rng = np.random.RandomState(3)
+    x = np.concatenate([rng.uniform(-4, 4, 5000), 10.0 ** rng.uniform(-44, 38, 5000), -(10.0 ** rng.uniform(-44, 38, 2000)),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 1.17549435e-38, 3.4028235e38, 1.7014118e38, 8.5e37, 2 ** -100, 2 ** -101, 2 ** -102])]).astype(np.float32)
+    out = np.zeros_like(x)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    with np.errstate(all="ignore"):
+        assert gpu_lib.RaylibAMD_EvalDeviceMath(14, fp(x), None, len(x), fp(out)) == 1
+        assert helpers.same(out, (np.float32(1.0) / x).astype(np.float32)).all()
+        assert gpu_lib.RaylibAMD_EvalDeviceMath(15, fp(x), None, len(x), fp(out)) == 1
+        assert helpers.same(out, np.sqrt(x).astype(np.float32)).all()
