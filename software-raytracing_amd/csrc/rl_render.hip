@@ -55,6 +55,9 @@ __shared__ double rlm_lds_tab[80];
 namespace rl {
 
 #define RL_BLOCK 256
+#ifndef RL_POOL_NODEPTR_VGPR
+#define RL_POOL_NODEPTR_VGPR 1   /* 298 k-triangle frame 43.0 -> 42.6 ms */
+#endif
 #ifndef RL_ROOTMISS_RCP
 #define RL_ROOTMISS_RCP 1
 #endif
@@ -68,6 +71,11 @@ namespace rl {
 #ifndef RL_FOLD_PREFETCH_POOL
 #define RL_FOLD_PREFETCH_POOL RL_FOLD_PREFETCH
 #endif
+
+// The wave's lane mask of a predicate, as the exec-masked compare it is.  HIP's __ballot(int) reaches the same builtin through an int: the compiler
+// then materialises the bool as 0 / 1 in a VGPR and compares it with zero again (v_cndmask + v_cmp_ne, 8 issue cycles per ballot on kernels that vote
+// several times per traversal step).
+__device__ __forceinline__ unsigned long long Ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // ---------------------------------------------------------------------------
 // device float3 (reference core/vec3.h conventions; see rl_host.h f3)
@@ -122,7 +130,7 @@ struct Counters {
 #define RL_CSTAMP_BEGIN(c) { __builtin_amdgcn_sched_barrier(0); (c).tLast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #define RL_CSTAMP(c, k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (c).tAcc[k] += now_ - (c).tLast; (c).tLast = now_; __builtin_amdgcn_sched_barrier(0); }
 #if RL_DIAG_STAMPS >= 2   /* wave-step against lane-step counts: global atomics in the inner loops, they distort the clock shares */
-#define RL_WLSTEP(c, kw, kl) { const unsigned long long em_ = __ballot(1); if ((c).diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) { atomicAdd(&(c).diag[CNT_COUNT + kw], 1ull); atomicAdd(&(c).diag[CNT_COUNT + kl], (unsigned long long)__popcll(em_)); } }
+#define RL_WLSTEP(c, kw, kl) { const unsigned long long em_ = Ballot(1); if ((c).diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) { atomicAdd(&(c).diag[CNT_COUNT + kw], 1ull); atomicAdd(&(c).diag[CNT_COUNT + kl], (unsigned long long)__popcll(em_)); } }
 #else
 #define RL_WLSTEP(c, kw, kl)
 #endif
@@ -439,7 +447,7 @@ __device__ __noinline__ float2 CubeHit(const DCube* cubes, int index, V3 o, V3 d
 
 // diagnostic build only: count wave-level steps (first active lane adds 1) next to the lane-level counters
 #if defined(RL_DIAG_STAMPS) && RL_DIAG_STAMPS >= 2
-#define RL_WSTEP(k) { const unsigned long long em_ = __ballot(1); if (c.diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) atomicAdd(&c.diag[CNT_COUNT + k], 1ull); }
+#define RL_WSTEP(k) { const unsigned long long em_ = Ballot(1); if (c.diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) atomicAdd(&c.diag[CNT_COUNT + k], 1ull); }
 #else
 #define RL_WSTEP(k)
 #endif
@@ -1370,7 +1378,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 	unsigned long long subLast = 0;
 	#define RL_STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[k] += now_ - stampLast; stampLast = now_; __builtin_amdgcn_sched_barrier(0); }
 	// lane-weighted: clock x lanes that took part in the phase (k: 0 traverse, 1 shade a hit, 2 miss shader, 3 fold)
-	#define RL_LANESTAMP(k, cond) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); laneAcc[k] += (now_ - laneLast) * (unsigned long long)__popcll(__ballot(cond)); laneT[k] += now_ - laneLast; __builtin_amdgcn_sched_barrier(0); }
+	#define RL_LANESTAMP(k, cond) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); laneAcc[k] += (now_ - laneLast) * (unsigned long long)__popcll(Ballot(cond)); laneT[k] += now_ - laneLast; __builtin_amdgcn_sched_barrier(0); }
 	#define RL_LANEBEGIN() { __builtin_amdgcn_sched_barrier(0); laneLast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 	unsigned long long laneLast = 0;
 #else
@@ -1385,7 +1393,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 #endif
 	for (;;) {
 #ifdef RL_WATCHDOG
-		if (++guardMain > 200000u) { if (lane == 0) printf("k_trace main loop stuck: block %u wave %u active %llx exhausted %llx qCount %u globalDone %d chunk %u %u depth %d\n", blockIdx.x, threadIdx.x >> 6, (unsigned long long)__ballot(active), (unsigned long long)__ballot(exhausted), qCount, (int)globalDone, chunkNext, chunkEnd, depth); break; }
+		if (++guardMain > 200000u) { if (lane == 0) printf("k_trace main loop stuck: block %u wave %u active %llx exhausted %llx qCount %u globalDone %d chunk %u %u depth %d\n", blockIdx.x, threadIdx.x >> 6, (unsigned long long)Ballot(active), (unsigned long long)Ballot(exhausted), qCount, (int)globalDone, chunkNext, chunkEnd, depth); break; }
 #endif
 		// ---- refill idle lanes: wave64 ballot + prefix rank ----
 		// Up to RL_REFILL_ROUNDS rounds: a fresh camera ray that misses both boxes of the root node can
@@ -1401,7 +1409,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 			enum { QCAP = 112, QFIELDS = 9 };   // 9 x 112 dwords <= 1024
 			int* q = s_stack + (threadIdx.x >> 6) * (STACK * 64);
 			const bool need = !active && !exhausted;
-			const unsigned long long needMask = __ballot(need);
+			const unsigned long long needMask = Ballot(need);
 			const uint32_t n = (uint32_t)__popcll(needMask);
 			while (n > 0 && qCount < n && qCount <= QCAP - 64 && !(globalDone && chunkNext >= chunkEnd)) {
 #if RL_QUEUE_SHARED_CHUNK
@@ -1493,7 +1501,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 					}
 				}
 				chunkNext += min(64u, avail);
-				const unsigned long long sv = __ballot(survive);
+				const unsigned long long sv = Ballot(survive);
 				if (survive) {
 					const uint32_t at = qCount + (uint32_t)__popcll(sv & ((1ull << lane) - 1ull));
 					q[0 * QCAP + at] = __float_as_int(qo.x); q[1 * QCAP + at] = __float_as_int(qo.y); q[2 * QCAP + at] = __float_as_int(qo.z);
@@ -1521,7 +1529,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 		} else
 		for (int round = 0; round < RL_REFILL_ROUNDS; ++round) {
 			const bool need = !active && !exhausted;
-			const unsigned long long mask = __ballot(need);
+			const unsigned long long mask = Ballot(need);
 			if (mask == 0ull) break;
 			if (chunkNext >= chunkEnd && !globalDone) {
 				uint32_t base = 0, bend = 0;
@@ -1571,8 +1579,8 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 			}
 			chunkNext += min((uint32_t)__popcll(mask), avail);
 		}
-		if (__ballot(active) == 0ull) {
-			if (__ballot(!exhausted) == 0ull) break;
+		if (Ballot(active) == 0ull) {
+			if (Ballot(!exhausted) == 0ull) break;
 			continue;
 		}
 
@@ -1971,6 +1979,14 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const float tMinC = __builtin_canonicalizef(P.rayTMin);   // known to be canonical: the box tests' max chains start from it without a v_max x, x per step
+#if RL_POOL_NODEPTR_VGPR
+	// the wide nodes' base address in a VGPR pair for the kernel's lifetime: as one of ~100 uniform values it is spilled to a VGPR's lanes and read back
+	// (two v_readlane, 4 issue cycles each) at every traversal step
+	DSceneView St = S;
+	{ const DNode4Q* pn = S.nodes4; asm volatile("" : "+v"(pn)); St.nodes4 = pn; }
+#else
+	const DSceneView& St = S;
+#endif
 	float (*pool)[PP] = s_pool[wave];
 	unsigned char* freeList = s_free[wave];
 	const uint32_t numSlots = P.numLocalCells * 64u;
@@ -1997,11 +2013,14 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 	RL_TIMELINE(0);
 	uint32_t surviveQ8 = 256u;                    // share of freshly generated camera samples that reached a pool slot, x 256 (wave-uniform)
 	// traversal state of the ray this lane is tracing; survives trips (a straggler keeps going while the rest of the pool is shaded)
-	bool busy = false;
+	// A lane without a ray has T.cur == IDLE (no node index, not negative like a leaf reference): "busy", "at an inner node", "at a leaf" are then ONE integer
+	// compare each, and a wave vote on a compare is that compare's lane mask.  (A vote on a bool that is not a compare -- `busy && T.cur >= 0` -- makes the
+	// compiler write the bool out as 0 / 1 and compare it with zero again: v_cndmask + v_cmp_ne per vote, four votes per traversal step.)
+	constexpr int IDLE = 0x7fffffff;
 	int mySlot = 0;
 	Trav T;
 	T.o = T.d = T.inv = v3s(0.0f); T.rayTime = 0.0f; T.nx = T.ny = T.nz = T.anyhit = false;
-	T.best.t = INFINITY; T.best.a = T.best.b = 0.0f; T.best.tri = -1; T.cur = 0; T.sp = 0; T.leafI = 0;
+	T.best.t = INFINITY; T.best.a = T.best.b = 0.0f; T.best.tri = -1; T.cur = IDLE; T.sp = 0; T.leafI = 0;
 #ifdef RL_DIAG_STAMPS
 	unsigned long long stampAcc[4] = { 0, 0, 0, 0 };
 	c.diag = counters;
@@ -2016,23 +2035,23 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 #endif
 	for (;;) {
 #ifdef RL_POOL_WATCHDOG
-		if (++wdTrips > 20000u || __ballot(wdAbort) != 0ull) {
+		if (++wdTrips > 20000u || Ballot(wdAbort) != 0ull) {
 			uint32_t nAct = 0, nEmpty = 0, nQ = 0, nH = 0, nPend = 0, nRes = 0;
 			for (int p = 0; p < K; ++p) {
 				const int q = __float_as_int(pool[F_TRI][p * 64 + (int)lane]);
-				nAct += (uint32_t)__popcll(__ballot(stActive[p]));
-				nEmpty += (uint32_t)__popcll(__ballot(stActive[p] && q == Q_EMPTY));
-				nQ += (uint32_t)__popcll(__ballot(stActive[p] && (q == Q_CLOSEST || q == Q_SHADOW)));
-				nH += (uint32_t)__popcll(__ballot(stActive[p] && q >= 0));
-				nPend += (uint32_t)__popcll(__ballot(stActive[p] && (q == Q_PENDING || q == Q_PENDING_SHADOW)));
-				nRes += (uint32_t)__popcll(__ballot(stActive[p] && (q == Q_MISS || q == Q_CLEAR || q == Q_OCCLUDED)));
+				nAct += (uint32_t)__popcll(Ballot(stActive[p]));
+				nEmpty += (uint32_t)__popcll(Ballot(stActive[p] && q == Q_EMPTY));
+				nQ += (uint32_t)__popcll(Ballot(stActive[p] && (q == Q_CLOSEST || q == Q_SHADOW)));
+				nH += (uint32_t)__popcll(Ballot(stActive[p] && q >= 0));
+				nPend += (uint32_t)__popcll(Ballot(stActive[p] && (q == Q_PENDING || q == Q_PENDING_SHADOW)));
+				nRes += (uint32_t)__popcll(Ballot(stActive[p] && (q == Q_MISS || q == Q_CLEAR || q == Q_OCCLUDED)));
 			}
 			if (lane == 0) {
 				atomicAdd(&counters[CNT_COUNT + 21], 1ull);
 				atomicAdd(&counters[CNT_COUNT + 4], (unsigned long long)nAct); atomicAdd(&counters[CNT_COUNT + 5], (unsigned long long)nEmpty);
 				atomicAdd(&counters[CNT_COUNT + 6], (unsigned long long)nQ); atomicAdd(&counters[CNT_COUNT + 7], (unsigned long long)nH);
 				atomicAdd(&counters[CNT_COUNT + 8], (unsigned long long)nPend); atomicAdd(&counters[CNT_COUNT + 9], (unsigned long long)nRes);
-				atomicAdd(&counters[CNT_COUNT + 10], (unsigned long long)(exhausted ? 1 : 0)); atomicAdd(&counters[CNT_COUNT + 11], (unsigned long long)__popcll(__ballot(busy)));
+				atomicAdd(&counters[CNT_COUNT + 10], (unsigned long long)(exhausted ? 1 : 0)); atomicAdd(&counters[CNT_COUNT + 11], (unsigned long long)__popcll(Ballot(T.cur != IDLE)));
 			}
 			break;
 		}
@@ -2044,7 +2063,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 			#pragma unroll
 			for (int p = 0; p < K; ++p) {
 				const bool fr = !stActive[p];
-				const unsigned long long m = __ballot(fr);
+				const unsigned long long m = Ballot(fr);
 				pos[p] = fr ? nFree + (uint32_t)__popcll(m & laneLt) : 0xffffffffu;
 				if (fr) freeList[pos[p]] = (unsigned char)(p * 64 + (int)lane);
 				nFree += (uint32_t)__popcll(m);
@@ -2099,15 +2118,15 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 						}
 					}
 				}
-				unsigned long long am = __ballot(alive);
+				unsigned long long am = Ballot(alive);
 				uint32_t n = (uint32_t)__popcll(am);
 				uint32_t commit = take;                    // lanes [0, commit) are this round's samples
 				if (n > room) {
 					// the lane of the (room + 1)-th survivor: everything from there on goes back to the queue
-					const unsigned long long over = __ballot(alive && (uint32_t)__popcll(am & laneLt) == room);
+					const unsigned long long over = Ballot(alive && (uint32_t)__popcll(am & laneLt) == room);
 					commit = (uint32_t)__ffsll((long long)over) - 1u;
 					if (lane >= commit) { alive = false; quick = false; }
-					am = __ballot(alive);
+					am = Ballot(alive);
 					n = room;
 				}
 				{   // survival rate of the committed samples, 8-bit fixed point, smoothed over the last few rounds
@@ -2155,7 +2174,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 		bool anyActive = false;
 		#pragma unroll
 		for (int p = 0; p < K; ++p) anyActive = anyActive || stActive[p];
-		if (__ballot(anyActive) == 0ull) {
+		if (Ballot(anyActive) == 0ull) {
 			if (exhausted) break;
 			continue;
 		}
@@ -2169,9 +2188,9 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 			uint32_t finished = 0;      // rays completed in this phase (wave-uniform)
 			for (;;) {
 				if (nextSlot < (uint32_t)PP) {
-					const unsigned long long idle = __ballot(!busy);
+					const unsigned long long idle = Ballot(T.cur == IDLE);
 					const uint32_t slot = nextSlot + (uint32_t)__popcll(idle & laneLt);
-					if (!busy && slot < (uint32_t)PP) {
+					if (T.cur == IDLE && slot < (uint32_t)PP) {
 						const int q = __float_as_int(pool[F_TRI][slot]);
 						if (q == Q_CLOSEST || q == Q_SHADOW) {
 							T.o = v3(pool[F_OX][slot], pool[F_OY][slot], pool[F_OZ][slot]);
@@ -2184,14 +2203,13 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 							T.best.t = INFINITY; T.best.tri = -1; T.best.a = 0.0f; T.best.b = 0.0f;
 							T.cur = 0; T.sp = 0; T.leafI = 0;
 							mySlot = (int)slot;
-							busy = true;
 							pool[F_TRI][slot] = __int_as_float(T.anyhit ? Q_PENDING_SHADOW : Q_PENDING);
 							c.rays++;
 						}
 					}
 					nextSlot += (uint32_t)__popcll(idle);
 				}
-				const int nBusy = (int)__popcll(__ballot(busy));
+				const int nBusy = (int)__popcll(Ballot(T.cur != IDLE));
 				if (nBusy == 0) {
 					if (nextSlot >= (uint32_t)PP) break;
 					continue;
@@ -2203,10 +2221,11 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 				// have finished to make a fetch worth it
 				int nb;
 				do {
-					const bool atNode = busy && T.cur >= 0, atLeaf = busy && T.cur < 0;
-					const int nN = (int)__popcll(__ballot(atNode)), nL = (int)__popcll(__ballot(atLeaf));
+					const bool atNode = (uint32_t)T.cur < (uint32_t)IDLE, atLeaf = T.cur < 0;
+					const int nN = (int)__popcll(Ballot(atNode)), nL = (int)__popcll(Ballot(atLeaf));
 					bool fin = false;
-					if (nN * (WIDE ? RL_POOL_WNODE4 : RL_POOL_WNODE) >= nL * (WIDE ? RL_POOL_WLEAF4 : RL_POOL_WLEAF)) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(S, T, tMinC, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, tMinC, stk, ovf, c); }
+					const bool nodeTurn = nN * (WIDE ? RL_POOL_WNODE4 : RL_POOL_WNODE) >= nL * (WIDE ? RL_POOL_WLEAF4 : RL_POOL_WLEAF);
+					if (nodeTurn) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(St, T, tMinC, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, tMinC, stk, ovf, c); }
 					else { if (atLeaf) fin = LeafStep<LSTACK, STACK, PRIMS>(S, T, P.rayTMin, stk, ovf, c); }
 					if (fin) {
 						const bool hit = T.best.tri >= 0;
@@ -2215,14 +2234,13 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 						else if (!hit) q = Q_MISS;
 						pool[F_T][mySlot] = T.best.t; pool[F_TRI][mySlot] = __int_as_float(q);
 						pool[F_A][mySlot] = T.best.a; pool[F_B][mySlot] = T.best.b;
-						busy = false;
+						T.cur = IDLE;
 					}
 #ifdef RL_POOL_WATCHDOG
-					if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); busy = false; wdAbort = true; }
+					if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); T.cur = IDLE; wdAbort = true; }
 #endif
-					const unsigned long long bm = __ballot(busy);
-					nb = (int)__popcll(bm);
-					finished += (uint32_t)__popcll(__ballot(fin));
+					nb = (int)__popcll(Ballot(T.cur != IDLE));
+					finished += (uint32_t)(nN + nL - nb);   // whoever was busy and is not any more has finished its ray
 				} while (nb > (nextSlot < (uint32_t)PP ? RL_POOL_KEEP : (finished > 0 ? cutAt : 0)));
 			}
 			WaveLdsSync();
@@ -2262,7 +2280,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 					pool[F_TRI][slot] = __int_as_float(Q_EMPTY);
 				}
 			}
-			const unsigned long long hm = __ballot(isHit);
+			const unsigned long long hm = Ballot(isHit);
 			hitIdx[p] = isHit ? nHit + (uint32_t)__popcll(hm & laneLt) : 0xffffffffu;
 			if (isHit) freeList[hitIdx[p]] = (unsigned char)slot;
 			nHit += (uint32_t)__popcll(hm);
