@@ -120,5 +120,8 @@ int main()
 	Run<3>("sqrtS3", 0x00800000u, 0x7f7fffffu);
 	Run<4>("sqrtS4", 0x00800000u, 0x7f7fffffu);
 	Run<5>("sqrtS5", 0x00800000u, 0x7f7fffffu);
+	// ... and the pair the product uses, with the product's guards (csrc/rl_glibc_math.h rcp1_ / sqrtf_): both lines must end in "0 mismatches"
+	Run<0>("rcp1_", 0x00800000u, 0x7e7fffffu);
+	Run<3>("sqrtf_", 0x0d000000u, 0x7f7fffffu);
 	return 0;
 }
