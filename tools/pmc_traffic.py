@@ -45,8 +45,9 @@ for arg in sys.argv[1:]:
     cycles = m["GRBM_GUI_ACTIVE"] / 8.0
     # static mix of this instantiation: "void rl::k_trace<16, false, true, 2>" -> "k_traceILi16ELb0ELb1ELi2E"
     args = kern.strip().split("<", 1)[1].rstrip(">").split(",")
-    mangled = ("k_trace_pool" if "k_trace_pool" in kern else "k_trace") + "I" + "".join(("Lb1" if a.strip() == "true" else "Lb0" if a.strip() == "false" else "Li" + a.strip()) + "E" for a in args) + "E"
-    mix = MIX.get(mangled, {}).get("mean_cost", {})
+    mangled = ("k_trace_pool" if "k_trace_pool" in kern else "k_trace") + "I" + "".join(("Lb1" if a.strip() == "true" else "Lb0" if a.strip() == "false" else "Li" + a.strip()) + "E" for a in args)
+    assert mangled in MIX, (mangled, list(MIX)[:4])
+    mix = MIX[mangled]["mean_cost"]
     counts = {c: m.get("SQ_INSTS_VALU_" + c, 0.0) for c in ("ADD_F32", "MUL_F32", "FMA_F32", "ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F32", "TRANS_F64", "CVT", "INT32", "INT64")}
     other = m["SQ_INSTS_VALU"] - sum(counts.values())
     counts["OTHER"] = other
