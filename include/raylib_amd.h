@@ -133,6 +133,10 @@ RAYLIB_API int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const fl
 
 /* Test hook: the device's short exact sequences for 1.0f / x (which = 0) and sqrtf(x) (which = 1) -- csrc/rl_glibc_math.h rcp1_ / sqrtf_, used by
  * normalize and every reciprocal of the shading code -- against the compiler's IEEE expansions on ALL 2^32 float bit patterns, on the device.
+ * which = 2: a / b with the divisor's correctly rounded reciprocal in hand (csrc/rl_math.h div_by_: the pixel -> [0, 1) divisions of a camera ray and the two
+ * barycentric divisions of a triangle test) -- every bit pattern as numerator of a set of divisors and as divisor of a set of numerators, wherever the
+ * sequence's stated conditions hold; which = 3: the triangle test's short barycentric form (csrc/rl_render.hip Barycentric) against the two divisions and
+ * the reference's test, every bit pattern in each of its three operands: same verdict, same quotients.
  * outMismatches: inputs whose results differ (a NaN may differ in payload); outFirstBits: the smallest such bit pattern.  Returns 1 when the sweep ran. */
 RAYLIB_API int32_t RaylibAMD_VerifyExactMath(int32_t which, uint64_t* outMismatches, uint64_t* outFirstBits);
 

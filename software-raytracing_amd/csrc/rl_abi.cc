@@ -455,7 +455,7 @@ int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int
 
 int32_t RaylibAMD_VerifyExactMath(int32_t which, uint64_t* outMismatches, uint64_t* outFirstBits)
 {
-	if (which < 0 || which > 1) return 0;
+	if (which < 0 || which > 3) return 0;
 	return DeviceVerifyExactMath(which, outMismatches, outFirstBits) ? 1 : 0;
 }
 

@@ -61,12 +61,15 @@ static_assert(sizeof(DNode4Q) == 64, "DNode4Q");
 // ray-independent terms of that formula are precomputed here with the reference's
 // own operation order, so the per-ray arithmetic reproduces its t / barycentrics
 // bit for bit:  u = v1-v0, v = v2-v0, uv = dot(u,v), uu, vv, denom = uv*uv - uu*vv.
+// denom itself is three operations on values the record holds (the device forms it the way the host did); the sixteenth float is its correctly
+// rounded reciprocal, with which the two divisions by denom become six issue cycles each (rl_math.h div_by_, rl_render.hip Barycentric).
 struct alignas(64) DTriIsect {
 	float v0[3];
 	float n[3];      // unit geometric normal, normalize(cross(v1-v0, v2-v0)) (geom/triangle.h:34-38)
 	float v1[3];     // the other two vertices: the edges u = v1 - v0, v = v2 - v0 are formed on the device (the reference's own
 	float v2[3];     // subtraction), and the exact AABB of the three vertices is what the candidate rule tests the ray against
-	float uv, uu, vv, denom;
+	float uv, uu, vv;
+	float rden;      // RN(1 / denom) for 2^-63 <= |denom| <= 2^125; NaN for denom == 0 or NaN (never hit either way); any other divisor clears DSceneView::fastBary
 };
 static_assert(sizeof(DTriIsect) == 64, "DTriIsect");
 
@@ -143,7 +146,8 @@ struct DSceneView {
 	int32_t numTriangles;
 	int32_t numNodes4, numMaterials;   // for the LDS-resident copy of a small scene (k_trace<..., LDS>)
 	const DNode4* leafList;    // scenes of few leaves: the leaves' boxes, four to a record (k_trace<..., LDS = 2>); nullptr = none
-	int32_t numLeafRecords, padLeaf;
+	int32_t numLeafRecords;
+	int32_t fastBary;          // every triangle's rden is usable (above): the barycentric divisions take the short form
 };
 
 // Counters written by the kernels (one 64-bit atomic per wave and counter at exit).
@@ -168,6 +172,7 @@ struct DRenderParams {
 	uint32_t jobsPerHead;      // whole cells: a multiple of 64 * sampleCount
 	uint32_t guideShift;       // 0: every draw asks for jobChunk jobs; s > 0: at most (jobs left in the band at the wave's previous draw) >> s (TakeJobs)
 	uint32_t padQueue;
+	float    invWidth, invHeight;   // RN(1 / (float)width), RN(1 / (float)height): the pixel -> [0, 1) divisions of GenerateCell (rl_render.hip PixelUV)
 	uint32_t magicSamples;     // floor(2^32 / sampleCount), floor(2^32 / cellsX): division by multiply-high in DecodeJob
 	uint32_t magicCellsX;
 	uint64_t seedMixed;        // raylib_rng_mix64(seed), hoisted out of the per-sample stream set-up

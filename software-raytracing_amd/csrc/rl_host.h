@@ -218,7 +218,7 @@ bool DeviceReadback(Image& img);            // device copy -> img.rgba (the call
 void* DeviceImagePixels(Image& img);          // (re)allocates img.devPixels for width*height float4; nullptr when no device
 void DeviceFreePixels(void* p);
 bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out);
-bool DeviceVerifyExactMath(int which, uint64_t* outMismatches, uint64_t* outFirst);   // 0: rtm::rcp1_ vs 1.0f / x, 1: rtm::sqrt_ vs sqrtf, all 2^32 inputs
+bool DeviceVerifyExactMath(int which, uint64_t* outMismatches, uint64_t* outFirst);   // 0: rtm::rcp1_ vs 1.0f / x, 1: rtm::sqrt_ vs sqrtf, 2: rtm::div_by_ vs a / b, 3: Barycentric short vs divisions; all 2^32 inputs
 bool DeviceEvalHook(int kind, Scene* sc, const DCamera* cam, int a, int b, const float* in, int n, uint64_t seed, float* out);
 void DeviceReleaseScene(DeviceScene* dev);
 

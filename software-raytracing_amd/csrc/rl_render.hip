@@ -40,9 +40,11 @@ __shared__ double rlm_lds_tab[80];
 #include "raylib_amd_rng.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -263,7 +265,7 @@ __device__ __forceinline__ Mat MatFrom(const float4* p)
 // Closest hit on the flat BVH2.
 struct HitRec { float t, a, b; int tri; };   // tri: triangle slot, or (kind << 28) | index for sphere (1) / cube (2, with the face in a)
 
-struct Tri { V3 v0, n, v1, v2, u, v; float uv, uu, vv, denom; };
+struct Tri { V3 v0, n, v1, v2, u, v; float uv, uu, vv, denom, rden; };
 __device__ __forceinline__ Tri TriFrom(const float4* p)
 {
 	float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
@@ -271,7 +273,8 @@ __device__ __forceinline__ Tri TriFrom(const float4* p)
 	t.v0 = v3(q0.x, q0.y, q0.z); t.n = v3(q0.w, q1.x, q1.y);
 	t.v1 = v3(q1.z, q1.w, q2.x); t.v2 = v3(q2.y, q2.z, q2.w);
 	t.u = t.v1 - t.v0; t.v = t.v2 - t.v0;   // geom/triangle.cc:30-31
-	t.uv = q3.x; t.uu = q3.y; t.vv = q3.z; t.denom = q3.w;
+	t.uv = q3.x; t.uu = q3.y; t.vv = q3.z; t.rden = q3.w;
+	t.denom = t.uv * t.uv - t.uu * t.vv;    // geom/triangle.cc:39-41, the host's own three operations (rl_runtime.inl UploadScene): the record's slot holds 1 / denom
 	return t;
 }
 __device__ __forceinline__ Tri LoadTri(const DSceneView& S, int i) { return TriFrom((const float4*)(S.isect + i)); }
@@ -445,6 +448,34 @@ __device__ __noinline__ float2 CubeHit(const DCube* cubes, int index, V3 o, V3 d
 	return make_float2(NAN, 0.0f);
 }
 
+// The barycentric coordinates of a plane hit and their test, reference geom/triangle.cc:41-47:  pa = X / denom, pb = Y / denom, inside <=> 0 <= pa, 0 <= pb,
+// pa + pb <= 1.  Two IEEE divisions are 72 of the ~380 issue cycles of a triangle step, and the divisor is a constant of the triangle: with rden = RN(1 / denom)
+// from the record, rtm::div_by_ gives the same two quotients in 12 (all 2^46 significand pairs checked: tools/verify_fastdiv.hip).  Its conditions -- the ones
+// v_div_scale tests -- are met like this:
+//   * S.fastBary (host, rl_runtime.inl UploadScene): every triangle of the scene has denom == 0 or NaN (rden = NaN: both quotients NaN, "outside", as X / 0 and
+//     X / NaN make it) or 2^-63 <= |denom| <= 2^125; a scene with any other divisor takes the divisions (a uniform branch);
+//   * a quotient of at least 2^-38 then has |X| >= 2^-101: exact.  Anything smaller -- tiny, zero (whose sign the short form may get wrong), negative by less
+//     than that -- may be off in the last place, which cannot change "pa + pb <= 1" (a term below 2^-38 moves a sum near 1 by less than a thousandth of its
+//     half-ulp), so: outside by more than 2^-38 is outside, inside by more than 2^-38 on both is inside, and the band between takes the divisions and the
+//     reference's own test.  (A ray through a vertex or along an edge; tests/test_gpu_parity.py aims rays there.)
+#ifndef RL_FAST_BARY
+#define RL_FAST_BARY 1
+#endif
+__device__ __forceinline__ bool Barycentric(bool fast, float X, float Y, float denom, float rden, float& pa, float& pb)
+{
+#if RL_FAST_BARY
+	if (fast) {
+		pa = rtm::div_by_(X, denom, rden); pb = rtm::div_by_(Y, denom, rden);
+		const float eps = 3.637978807091713e-12f;   // 2^-38
+		const float m = __builtin_fminf(pa, pb), sum = pa + pb;   // (a NaN quotient: the sum is NaN)
+		if (!(sum <= 1.0f && m >= -eps)) return false;
+		if (m >= eps) return true;
+	}
+#endif
+	pa = X / denom; pb = Y / denom;
+	return 0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f;
+}
+
 // diagnostic build only: count wave-level steps (first active lane adds 1) next to the lane-level counters
 #if defined(RL_DIAG_STAMPS) && RL_DIAG_STAMPS >= 2
 #define RL_WSTEP(k) { const unsigned long long em_ = Ballot(1); if (c.diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) atomicAdd(&c.diag[CNT_COUNT + k], 1ull); }
@@ -513,9 +544,8 @@ __device__ __forceinline__ bool Traverse(const DSceneView& S, V3 o, V3 d, float 
 					const V3 p = o + t * d;
 					const V3 w = p - T.v0;
 					const float wv = dot(w, T.v), wu = dot(w, T.u);
-					const float pa = (T.uv * wv - T.vv * wu) / T.denom;
-					const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-					if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, inv, tMin, t)) {
+					float pa, pb;
+					if (Barycentric(S.fastBary != 0, T.uv * wv - T.vv * wu, T.uv * wu - T.uu * wv, T.denom, T.rden, pa, pb) && OwnBoxPass(T.v0, T.v1, T.v2, o, inv, tMin, t)) {
 						if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 						best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 						if (ANYHIT) return true;
@@ -672,9 +702,9 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 		for (int i = 0; i < count; ++i) {
 			const float4* tr = sm + LdsAt<2>::ISECT + (first + i) * 6;
 			const float4 q0 = tr[0], q1 = tr[1], q2 = tr[2], q3 = tr[3];
-			struct { V3 v0, n, u, v; float uv, uu, vv, denom; } T;
+			struct { V3 v0, n, u, v; float uv, uu, vv, denom, rden; } T;
 			T.v0 = v3(q0.x, q0.y, q0.z); T.n = v3(q0.w, q1.x, q1.y); T.u = v3(q1.z, q1.w, q2.x); T.v = v3(q2.y, q2.z, q2.w);
-			T.uv = q3.x; T.uu = q3.y; T.vv = q3.z; T.denom = q3.w;
+			T.uv = q3.x; T.uu = q3.y; T.vv = q3.z; T.denom = q3.w; T.rden = tr[5].z;
 			c.tris++;
 			RL_WSTEP(5);
 			const float t = dot((T.v0 - o), T.n) / dot(d, T.n);
@@ -682,9 +712,8 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const V3 p = o + t * d;
 			const V3 w = p - T.v0;
 			const float wv = dot(w, T.v), wu = dot(w, T.u);
-			const float pa = (T.uv * wv - T.vv * wu) / T.denom;
-			const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPassMnMx(tr, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
+			float pa, pb;
+			if (Barycentric(S.fastBary != 0, T.uv * wv - T.vv * wu, T.uv * wu - T.uu * wv, T.denom, T.rden, pa, pb) && OwnBoxPassMnMx(tr, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
 				if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 				best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 				if (ANYHIT) return true;
@@ -744,9 +773,8 @@ __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float
 				const V3 p = o + t * d;
 				const V3 w = p - T.v0;
 				const float wv = dot(w, T.v), wu = dot(w, T.u);
-				const float pa = (T.uv * wv - T.vv * wu) / T.denom;
-				const float pb = (T.uv * wu - T.uu * wv) / T.denom;
-				if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(T.v0, T.v1, T.v2, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
+				float pa, pb;
+				if (Barycentric(S.fastBary != 0, T.uv * wv - T.vv * wu, T.uv * wu - T.uu * wv, T.denom, T.rden, pa, pb) && OwnBoxPass(T.v0, T.v1, T.v2, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
 					if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 					best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 					if (ANYHIT) return true;
@@ -1154,6 +1182,21 @@ __device__ __forceinline__ void CameraRay(const DCamera& k, float s, float t, Rn
 	d = normalize(ld3(k.top_left) + s * ld3(k.horizontal) + (1.0f - t) * ld3(k.vertical) - origin - offset);
 }
 
+// GenerateCell's pixel -> [0, 1) coordinates, reference render/renderer.cc:232-239:  u = x / W, v = y / H, each plus (Next() - 0.5) * 2 / W resp. H from the second
+// sample on: four divisions by two constants of the launch, 144 issue cycles per camera ray.  With P.invWidth = RN(1 / W) they are rtm::div_by_'s 6 each, and its
+// conditions hold without a guard: W, H are integers in [1, 2^32] as floats, the numerators are +0 or integers below 2^32 or multiples of 2^-23 in (-1, 1)
+// (Next() is a multiple of 2^-24; x - 0.5 == 0 is +0) -- every quotient is +0 or at least 2^-55 in magnitude.
+__device__ __forceinline__ void PixelUV(const DRenderParams& P, uint32_t x, uint32_t y, uint32_t sampleIndex, Rng& g, float& u, float& v)
+{
+	const float imageWidth = (float)P.width, imageHeight = (float)P.height;
+	u = rtm::div_by_((float)x, imageWidth, P.invWidth);
+	v = rtm::div_by_((float)y, imageHeight, P.invHeight);
+	if (sampleIndex != 0) {
+		u += rtm::div_by_((Next(g) - 0.5f) * 2.0f, imageWidth, P.invWidth);
+		v += rtm::div_by_((Next(g) - 0.5f) * 2.0f, imageHeight, P.invHeight);
+	}
+}
+
 struct SkyRot { float m0[3], m1[3], m2[3]; };   // Rotator(yaw 90).rotate rows, computed on the host (renderer.cc:166-168)
 
 // Miss shader: sky panorama + sun (reference render/renderer.cc:155-199)
@@ -1336,7 +1379,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 				const V3 mx = v3(fmaxf(fmaxf(T.v0.x, T.v1.x), T.v2.x), fmaxf(fmaxf(T.v0.y, T.v1.y), T.v2.y), fmaxf(fmaxf(T.v0.z, T.v1.z), T.v2.z));
 				float4* r = s_scene + LdsAt<LDS>::ISECT + t * 6u;
 				r[0] = make_float4(T.v0.x, T.v0.y, T.v0.z, T.n.x); r[1] = make_float4(T.n.y, T.n.z, T.u.x, T.u.y); r[2] = make_float4(T.u.z, T.v.x, T.v.y, T.v.z);
-				r[3] = make_float4(T.uv, T.uu, T.vv, T.denom); r[4] = make_float4(mn.x, mn.y, mn.z, mx.x); r[5] = make_float4(mx.y, mx.z, 0.0f, 0.0f);
+				r[3] = make_float4(T.uv, T.uu, T.vv, T.denom); r[4] = make_float4(mn.x, mn.y, mn.z, mx.x); r[5] = make_float4(mx.y, mx.z, T.rden, 0.0f);
 			}
 		} else {
 			for (uint32_t i = threadIdx.x; i < nT; i += RL_BLOCK) { const uint32_t at = (i >> 2) * RL_LDS_TSTRIDE + (i & 3u); s_scene[LdsAt<LDS>::ISECT + at] = ((const float4*)S.isect)[i]; s_scene[LdsAt<LDS>::SHADE + at] = ((const float4*)S.shade)[i]; }
@@ -1475,13 +1518,8 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 						// GenerateCell body, reference render/renderer.cc:232-239
 						const uint32_t sm_ = P.sampleBegin + j.sample;
 						qg.s = raylib_rng_begin_mixed(P.seedMixed, j.y * P.width + j.x, sm_);
-						const float imageWidth = (float)P.width, imageHeight = (float)P.height;
-						float u = (float)j.x / imageWidth;
-						float v = (float)j.y / imageHeight;
-						if (sm_ != 0) {
-							u += (Next(qg) - 0.5f) * 2.0f / imageWidth;
-							v += (Next(qg) - 0.5f) * 2.0f / imageHeight;
-						}
+						float u, v;
+						PixelUV(P, j.x, j.y, sm_, qg, u, v);
 						float qTime;
 						CameraRay(P.camera, u, v, qg, qo, qd, qTime);
 						qOut = j.sample * numSlots + j.slot;
@@ -1548,13 +1586,8 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 						// GenerateCell body, reference render/renderer.cc:232-239
 						const uint32_t s = P.sampleBegin + j.sample;
 						g.s = raylib_rng_begin_mixed(P.seedMixed, j.y * P.width + j.x, s);
-						const float imageWidth = (float)P.width, imageHeight = (float)P.height;
-						float u = (float)j.x / imageWidth;
-						float v = (float)j.y / imageHeight;
-						if (s != 0) {
-							u += (Next(g) - 0.5f) * 2.0f / imageWidth;
-							v += (Next(g) - 0.5f) * 2.0f / imageHeight;
-						}
+						float u, v;
+						PixelUV(P, j.x, j.y, s, g, u, v);
 						CameraRay(P.camera, u, v, g, o, d, rayTime);
 						depth = 0;
 						outIndex = j.sample * numSlots + j.slot;
@@ -1867,9 +1900,8 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 			const V3 pp = o + t * d;
 			const V3 w = pp - TT.v0;
 			const float wv = dot(w, TT.v), wu = dot(w, TT.u);
-			const float pa = (TT.uv * wv - TT.vv * wu) / TT.denom;
-			const float pb = (TT.uv * wu - TT.uu * wv) / TT.denom;
-			if (0.0f <= pa && 0.0f <= pb && pa + pb <= 1.0f && OwnBoxPass(TT.v0, TT.v1, TT.v2, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
+			float pa, pb;
+			if (Barycentric(S.fastBary != 0, TT.uv * wv - TT.vv * wu, TT.uv * wu - TT.uu * wv, TT.denom, TT.rden, pa, pb) && OwnBoxPass(TT.v0, TT.v1, TT.v2, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
 				if (!alpha || AlphaTestCandidate(S, i, pa, pb, c)) {
 					T.best.t = t; T.best.a = pa; T.best.b = pb; T.best.tri = i;
 					if (T.anyhit) return true;
@@ -2100,13 +2132,8 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 						// GenerateCell body, reference render/renderer.cc:232-239
 						const uint32_t sidx = P.sampleBegin + j.sample;
 						g.s = raylib_rng_begin_mixed(P.seedMixed, j.y * P.width + j.x, sidx);
-						const float imageWidth = (float)P.width, imageHeight = (float)P.height;
-						float u = (float)j.x / imageWidth;
-						float v = (float)j.y / imageHeight;
-						if (sidx != 0) {
-							u += (Next(g) - 0.5f) * 2.0f / imageWidth;
-							v += (Next(g) - 0.5f) * 2.0f / imageHeight;
-						}
+						float u, v;
+						PixelUV(P, j.x, j.y, sidx, g, u, v);
 						CameraRay(P.camera, u, v, g, o, d, rayTime);
 						outIndex = j.sample * numSlots + j.slot;
 						alive = true;
@@ -2653,19 +2680,63 @@ k_eval_math(int fn, const float* __restrict__ x, const float* __restrict__ y, in
 	out[i] = r;
 }
 
-// Test hook: rtm::rcp1_ / rtm::sqrt_ (the short exact sequences of rl_glibc_math.h) against the compiler's IEEE expansions of 1.0f / x and sqrtf(x)
-// on EVERY float bit pattern, inside the product library.  out[0] = mismatching inputs, out[1] = the smallest mismatching bit pattern.
+// Test hook: the short exact sequences against the compiler's IEEE expansions, inside the product library.  out[0] = mismatching cases, out[1] = the
+// smallest bit pattern of the swept operand with a mismatch.
+//   which 0 / 1: rtm::rcp1_ / rtm::sqrt_ (rl_glibc_math.h) against 1.0f / x and sqrtf(x) on EVERY float bit pattern;
+//   which 2: rtm::div_by_(a, b, RN(1 / b)) against a / b -- every bit pattern as the numerator of a set of divisors, and as the divisor of a set of
+//            numerators, wherever div_by_'s stated conditions hold (rl_math.h; all significand PAIRS are tools/verify_fastdiv.hip's sweep: this one walks the
+//            exponents, the signs and the edges of the conditions);
+//   which 3: Barycentric() in its short form against the two divisions and the reference's test -- every bit pattern as X, as Y and as denom of a set of
+//            (X, Y, denom) triples, with rden as the host makes it: same verdict, and the same two quotients bit for bit when inside.
+__device__ __forceinline__ bool SameBits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+__device__ __forceinline__ bool DivByHolds(float a, float b)
+{
+	const float ma = fabsf(a), mb = fabsf(b);
+	if (!(mb >= 0x1p-126f && mb <= 0x1p126f)) return false;
+	if (!(ma >= 0x1p-103f && ma <= FLT_MAX)) return false;
+	const float q = fabsf(a / b);
+	return q >= 0x1p-126f && q < 0x1p127f;
+}
+__device__ __forceinline__ bool BaryDiffers(float X, float Y, float denom)
+{
+	const float mag = fabsf(denom);
+	float rden;
+	if (denom == 0.0f || denom != denom) rden = __uint_as_float(0x7fc00000u);
+	else if (mag >= 0x1p-63f && mag <= 0x1p125f) rden = 1.0f / denom;
+	else return false;   // such a divisor clears DSceneView::fastBary: the whole scene takes the divisions
+	float fa, fb, ea, eb;
+	const bool f = Barycentric(true, X, Y, denom, rden, fa, fb), e = Barycentric(false, X, Y, denom, rden, ea, eb);
+	return f != e || (f && !(SameBits(fa, ea) && SameBits(fb, eb)));
+}
 __global__ void __launch_bounds__(RL_BLOCK)
 k_verify_exact_math(int which, unsigned long long* __restrict__ out)
 {
 	const unsigned long long tid = (unsigned long long)blockIdx.x * RL_BLOCK + threadIdx.x, n = (unsigned long long)gridDim.x * RL_BLOCK;
 	unsigned long long bad = 0, first = ~0ull;
+	// operands the sweeps pair every bit pattern with: ordinary values, the launch's and the triangles' kinds of constants, and the edges of the conditions
+	const float fixedB[12] = { 3.0f, 1920.0f, 1080.0f, 0.1f, -7.0f, 3.14159274f, 9.5e10f, 2.4e-9f, 0x1.8p-63f, 0x1.fffffep125f, 0x1p-126f, 0x1p126f };
+	const float fixedA[10] = { 1.0f, -3.3f, 1e-20f, 5e20f, 0x1p-103f, 0x1.fffffep-104f, 0x1.234568p-100f, 0.75f, 1919.0f, 0x1.fffffep127f };
 	for (unsigned long long b = tid; b < (1ull << 32); b += n) {
 		const float x = __uint_as_float((uint32_t)b);
-		const float want = which == 0 ? 1.0f / x : __builtin_sqrtf(x);
-		const float got = which == 0 ? rtm::rcp1_(x) : rtm::sqrt_(x);
-		const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got);   // a NaN must meet a NaN
-		if (!same) { ++bad; first = min(first, b); }
+		bool differs = false;
+		if (which <= 1) {
+			const float want = which == 0 ? 1.0f / x : __builtin_sqrtf(x);
+			const float got = which == 0 ? rtm::rcp1_(x) : rtm::sqrt_(x);
+			differs = !SameBits(want, got);   // a NaN must meet a NaN
+		} else if (which == 2) {
+			for (int k = 0; k < 12; ++k) { const float d = fixedB[k]; if (DivByHolds(x, d) && !SameBits(rtm::div_by_(x, d, 1.0f / d), x / d)) differs = true; }
+			for (int k = 0; k < 10; ++k) { const float a = fixedA[k]; if (DivByHolds(a, x) && !SameBits(rtm::div_by_(a, x, 1.0f / x), a / x)) differs = true; }
+		} else {
+			// (X, Y, denom) of ordinary hits, of hits on an edge and at a vertex, of misses by a hair, with tiny, huge and special members
+			const float T[14][3] = { { 1.0e9f, 2.0e9f, 9.5e10f }, { -1.0e9f, -2.0e9f, -9.5e10f }, { 0.0f, 4.0e10f, 9.5e10f }, { -0.0f, 0.0f, 9.5e10f }, { 1e-3f, 9.4999e10f, 9.5e10f },
+			                         { 3e-12f, 1.0f, 2.4e-9f }, { -3e-12f, 1.0e-10f, 2.4e-9f }, { 1e-30f, 1e-31f, 0x1p-63f }, { 5e-20f, 2e-21f, 0x1.8p-60f }, { 1e-42f, 1e-10f, 1e-9f },
+			                         { 0x1p100f, 0x1p99f, 0x1p125f }, { 0x1.fffffep127f, 1.0f, 2.0f }, { 4.75e10f, 4.75e10f, 9.5e10f }, { 4.7500004e10f, 4.75e10f, 9.5e10f } };
+			for (int k = 0; k < 14; ++k) {
+				differs = differs || BaryDiffers(x, T[k][1], T[k][2]) || BaryDiffers(T[k][0], x, T[k][2]) || BaryDiffers(T[k][0], T[k][1], x);
+				differs = differs || BaryDiffers(x, -T[k][1], -T[k][2]) || BaryDiffers(x, x, T[k][2]);
+			}
+		}
+		if (differs) { ++bad; first = min(first, b); }
 	}
 	if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first); }
 }

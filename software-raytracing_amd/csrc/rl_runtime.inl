@@ -256,6 +256,8 @@ bool UploadScene(Scene& sc)
 	if (sc.device) return true;
 	const size_t n = sc.triangles.size();
 	std::vector<DTriIsect> isect(n);
+	std::atomic<int> fastBary(1);
+	if (const char* e = getenv("RAYLIB_FAST_BARY")) fastBary.store(atoi(e) != 0 ? 1 : 0);   // 0: the divisions, whatever the scene (parity tests compare the two)
 	std::vector<DTriShade> shade(n);
 	auto flatten = [&](size_t k0, size_t k1) { for (size_t k = k0; k < k1; ++k) {
 		const HostTriangle& t = sc.triangles[sc.bvh.triOrder[k]];
@@ -268,7 +270,13 @@ bool UploadScene(Scene& sc)
 		I.n[0] = nrm.x; I.n[1] = nrm.y; I.n[2] = nrm.z;
 		I.v1[0] = t.v1.x; I.v1[1] = t.v1.y; I.v1[2] = t.v1.z;
 		I.v2[0] = t.v2.x; I.v2[1] = t.v2.y; I.v2[2] = t.v2.z;
-		I.uv = uv; I.uu = uu; I.vv = vv; I.denom = uvuv - uuvv;
+		I.uv = uv; I.uu = uu; I.vv = vv;
+		{   // the reciprocal of denom = uvuv - uuvv for the short barycentric divisions (rl_render.hip Barycentric, which states the conditions)
+			const float denom = uvuv - uuvv, mag = fabsf(denom);
+			if (denom == 0.0f || denom != denom) I.rden = std::numeric_limits<float>::quiet_NaN();
+			else if (mag >= 0x1p-63f && mag <= 0x1p125f) I.rden = 1.0f / denom;
+			else { I.rden = std::numeric_limits<float>::quiet_NaN(); fastBary.store(0, std::memory_order_relaxed); }
+		}
 		DTriShade& Sh = shade[k];
 		Sh.n0[0] = t.n0.x; Sh.n0[1] = t.n0.y; Sh.n0[2] = t.n0.z;
 		Sh.n1[0] = t.n1.x; Sh.n1[1] = t.n1.y; Sh.n1[2] = t.n1.z;
@@ -385,7 +393,8 @@ bool UploadScene(Scene& sc)
 		V.hasSun = !(sc.sunIlluminance.x == 0.0f && sc.sunIlluminance.y == 0.0f && sc.sunIlluminance.z == 0.0f);   // renderer.cc:192
 		V.numTriangles = (int32_t)n;
 		V.numNodes4 = (int32_t)sc.bvh.nodes4.size(); V.numMaterials = (int32_t)mats.size();
-		V.leafList = C->leafList; V.numLeafRecords = C->leafList ? (int32_t)sc.bvh.leafList.size() : 0; V.padLeaf = 0;
+		V.leafList = C->leafList; V.numLeafRecords = C->leafList ? (int32_t)sc.bvh.leafList.size() : 0;
+		V.fastBary = fastBary.load();
 	}
 	HIP_OK(hipSetDevice(g_rt.devices[0]));
 	sc.device = D;
@@ -483,6 +492,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 
 	DRenderParams P; memset(&P, 0, sizeof(P));
 	P.width = W; P.height = H; P.spp = SPP; P.maxPathLength = st.maxPathLength; P.rayTMin = st.rayTMin;
+	P.invWidth = 1.0f / (float)W; P.invHeight = 1.0f / (float)H;   // correctly rounded (IEEE division on the host): rl_render.hip PixelUV
 	P.renderMode = st.renderMode; P.seed = req.seed; P.cellsX = cellsX; P.cellsY = cellsY;
 	P.cellFirst = req.cellFirst; P.cellStride = stride; P.numLocalCells = numLocalCells;
 	P.rowMajorOutput = rowMajor ? 1u : 0u; P.camera = req.camera;

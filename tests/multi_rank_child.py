@@ -1,6 +1,8 @@
 """Child process of tests/test_gpu_multi_rank.py: the library reads RAYLIB_NUM_GPUS / RAYLIB_GPU_MAP / RAYLIB_GATHER* once, when it
 initialises, so every rank layout needs its own process.  Renders a fixed list of frames through Raylib_Render (the reference's
-own entry point, nothing rank-aware in the call) and stores them.   usage: python multi_rank_child.py <workdir> <out.npz>"""
+own entry point, nothing rank-aware in the call) and stores them.   usage: python multi_rank_child.py <workdir> <out.npz>
+or, for one frame of an OBJ scene at a BASELINE config's size (tests/test_gpu_configs.py):
+python multi_rank_child.py <workdir> <out.npz> obj <file.obj> <camera name> <width> <height> <spp>"""
 import os
 import sys
 import numpy as np
@@ -57,8 +59,21 @@ def back_to_back(lib, workdir):
     return {"p1": p1, "p2": p2, "p3": p3, "pstats": np.asarray([s.cameraSamples, s.pixels, s.rays, int(s.kernelMs > 0), int(s.traceKernelMs > 0)], np.int64)}
 
 
+def render_obj(lib, obj, camera, w, h, spp):
+    from raylib_amd import scenes
+    cam = scenes.CONFIG_CAMERAS[camera]
+    ses = binding.SceneSession(lib, obj, cam["origin"], cam["look_at"], cam["fov"], w / h, sun=cam["sun"], sun_dir=cam["sun_dir"])
+    img = ses.render(w, h, spp)
+    s = ses.stats()
+    ses.close()
+    return {"img": img, "stats": np.asarray([s.ranks, s.cameraSamples, s.pixels, s.rays, s.gatherMode, s.devices], np.int64)}
+
+
 if __name__ == "__main__":
     lib = binding.load()
     assert lib.Raylib_Initialize() == 1
     lib.RaylibAMD_SetSeed(1)
-    np.savez(sys.argv[2], **render_all(lib, sys.argv[1]))
+    if len(sys.argv) > 3 and sys.argv[3] == "obj":
+        np.savez(sys.argv[2], **render_obj(lib, sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])))
+    else:
+        np.savez(sys.argv[2], **render_all(lib, sys.argv[1]))

@@ -110,6 +110,7 @@ def test_scene_with_tga_bmp_jpeg_png_hdr_maps_and_an_hdr_sky(gpu_lib, oracle, wo
             cn = oracle.counters(scene)
             assert cn["closest_hit_ties"] > 0 or cn["hits_outside_own_box"] > 0, (spp, mode, px, py, got[py, px], want[py, px])
             excused += 1
+        print("spp %d mode %d: %d excused tie pixels of %d" % (spp, mode, excused, 72 * 48))
         assert excused <= 6, excused
     assert got[..., :3].max() > 0
     oracle.scene_destroy(scene)

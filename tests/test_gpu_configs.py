@@ -6,10 +6,14 @@ path (Raylib_LoadOBJModel).  What is checked at full size:
   * the product loaded exactly the flat scene the generator's arrays are (every triangle, every material);
   * windows of the full-resolution, full-spp frame recomputed by the CPU oracle with the same pixel keys: bit-equal, except pixels one
     of whose samples met two surfaces at exactly the same t (reference-undefined, DESIGN section 4; the oracle counts those events);
-  * the 8-rank cell split (what `--gpus 8` renders) assembles to the one-GPU frame bit for bit (configs[3], [4]: "8 x MI355X").
+  * the 8-rank cell split (what `--gpus 8` renders) assembles to the one-GPU frame bit for bit (configs[3], [4]: "8 x MI355X");
+  * configs[3] through Raylib_Render itself with RAYLIB_NUM_GPUS=2 (two ranks on the one device, in a child process: the library reads its
+    rank layout when it initialises): the gathered frame is the one-rank frame bit for bit, with the same ray count.
 The oracle's tree for the multi-million-triangle scene is its n log n median build (oracle.cc BuildBVHFast): the closest hit does not
 depend on the tree."""
 import os
+import subprocess
+import sys
 import time
 import numpy as np
 import pytest
@@ -91,9 +95,23 @@ def test_config3_167k_triangles_1080p_256spp_whole_frame_and_8_rank_split(gpu_li
     assert len(flat.triangles) == 167328
     ses = load_and_check(gpu_lib, obj, flat, cam, 1920 / 1080)
     img = ses.render(1920, 1080, 256)
-    assert ses.stats().cameraSamples == 1920 * 1080 * 256 and np.isfinite(img).all()
+    one = ses.stats()
+    assert one.cameraSamples == 1920 * 1080 * 256 and np.isfinite(img).all()
     bufs = [ses.render_cells(1920, 1080, 256, r, 8) for r in range(8)]
     assert np.array_equal(bits(tiling.assemble(1920, 1080, 8, bufs)), bits(img))
+    del bufs
+    # the same frame through Raylib_Render with two ranks behind it
+    out = os.path.join(d, "two_ranks.npz")
+    env = dict(os.environ, RAYLIB_NUM_GPUS="2", RAYLIB_GPU_MAP="0,0")
+    for k in ("RAYLIB_POOL", "RAYLIB_LIB"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "multi_rank_child.py"), str(workdir), out, "obj", obj, "sponza", "1920", "1080", "256"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    two = np.load(out)
+    assert np.array_equal(bits(two["img"]), bits(img)), "Raylib_Render over two ranks differs from the one-rank frame"
+    assert two["stats"][0] == 2 and two["stats"][1] == one.cameraSamples and two["stats"][3] == one.rays, two["stats"]
+    os.remove(out)
     scene = oracle.scene_create(flat, 1)
     check_windows(oracle, scene, cam, 1920 / 1080, 1920, 1080, 256, img, ((952, 536), (300, 700), (1500, 400), (1200, 900), (640, 300), (1700, 760)), 8,
                   max_tied=8, min_with_geometry=5)

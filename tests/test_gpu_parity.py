@@ -209,6 +209,111 @@ def test_soup_closest_hit_10k(gpu_lib, workdir):
     ses.close()
 
 
+def test_rays_through_vertices_and_along_edges_short_barycentrics_against_the_divisions(gpu_lib, workdir, oracle, monkeypatch):
+    """The triangle test's two divisions by `denom` run as six-cycle sequences with the reciprocal from the triangle record (csrc/rl_render.hip
+    Barycentric), and a quotient below 2^-38 -- a ray through a vertex, along an edge, or past one by a hair -- sends the lane to the divisions
+    themselves.  Random rays never get there; these do: aimed at every vertex, at points ON every edge (exact in float for the axis-aligned
+    Cornell walls) and a few ulps to either side.  The same scene uploaded with RAYLIB_FAST_BARY=0 (divisions only) must give the same records
+    bit for bit, and both must be the CPU oracle's."""
+    from raylib_amd import binding
+    obj, c = helpers.build_case("cornell", workdir)
+    fast = binding.SceneSession(gpu_lib, obj, c["origin"], c["look_at"], c["fov"], c["aspect"])
+    monkeypatch.setenv("RAYLIB_FAST_BARY", "0")
+    slow = binding.SceneSession(gpu_lib, obj, c["origin"], c["look_at"], c["fov"], c["aspect"])
+    monkeypatch.delenv("RAYLIB_FAST_BARY")
+    tris, _ = fast.export_flat()
+    rng = np.random.RandomState(21)
+    targets = [tris["v0"], tris["v1"], tris["v2"]]
+    for a, b in (("v0", "v1"), ("v1", "v2"), ("v2", "v0")):
+        for w in (0.5, 0.25, 0.125, 0.75):                      # on the edge, exactly, where the coordinates allow
+            targets.append((tris[a].astype(np.float64) * (1 - w) + tris[b].astype(np.float64) * w).astype(np.float32))
+    targets = np.concatenate(targets)
+    nudged = [targets]
+    for k in (1, -1, 3, -3):                                     # ... and a few ulps off in every coordinate
+        nudged.append((targets.view(np.int32) + k).view(np.float32))
+    targets = np.concatenate(nudged)
+    targets = targets[np.isfinite(targets).all(1)]
+    rays = []
+    for origin in ((0.0, 1.0, 4.0), (0.1, 0.9, 0.3), (-0.4, 1.6, -0.2)):
+        o = np.broadcast_to(np.asarray(origin, np.float32), targets.shape)
+        rays.append(np.concatenate([o, (targets - o).astype(np.float32)], axis=1))     # unnormalised: t = 1 at the target
+        d = (targets - o).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        rays.append(np.concatenate([o, d], axis=1))
+    rays = np.ascontiguousarray(np.concatenate(rays), np.float32)
+    rays = rays[np.isfinite(rays).all(1)]
+    outs = []
+    for ses in (fast, slow):
+        out = np.zeros(len(rays), ffi.HIT_DTYPE)
+        assert gpu_lib.RaylibAMD_ClosestHit(ses.scene, rays.ctypes.data_as(C.POINTER(C.c_float)), len(rays), 1e-4, out.ctypes.data) == 1
+        outs.append(out)
+    raw = [o.view(np.uint8).reshape(len(rays), -1) for o in outs]
+    assert outs[0].tobytes() == outs[1].tobytes(), "short barycentric form and divisions disagree on %d rays" % (raw[0] != raw[1]).any(1).sum()
+    assert outs[0]["hit"].sum() > len(rays) // 2
+    # the frame too, on both schedules' code (the leaf-list kernel reads the reciprocal from its LDS record)
+    a, b = fast.render(64, 64, 4), slow.render(64, 64, 4)
+    assert np.array_equal(bits(a), bits(b))
+    # and the oracle.  A ray through an edge or a vertex meets two or more triangles within an ulp of the same distance, on the boundary of each: the
+    # reference's barycentric test lets some of them in although the ray misses that triangle's own box, and which one its traversal returns
+    # depends on its tree (DESIGN.md section 4: the device only takes candidates whose own box the ray passes).  The oracle counts those events:
+    # every ray whose record differs must have met one.
+    _, _, flat = helpers.flat_for_case("cornell", workdir, oracle)
+    scene = oracle.scene_create(flat, 1)
+    want = oracle.closest_hit(scene, rays, 1e-4)
+    differ = np.nonzero((outs[0]["hit"] != want["hit"]) | (bits(outs[0]["t"]) != bits(want["t"])))[0]
+    for i in differ:
+        oracle.closest_hit(scene, rays[i:i + 1], 1e-4)
+        cn = oracle.counters(scene)
+        assert cn["closest_hit_ties"] > 0 or cn["hits_outside_own_box"] > 0, "ray %d %s: device hit %d t %r | oracle hit %d t %r | %s" % (
+            i, rays[i].tolist(), outs[0]["hit"][i], float(outs[0]["t"][i]), want["hit"][i], float(want["t"][i]), cn)
+    print("%d rays at vertices / on edges: %d hits; %d differ from the oracle's tree walk, every one with a tie or a hit outside its triangle's own box on the way" % (
+        len(rays), outs[0]["hit"].sum(), len(differ)))
+    assert len(differ) < len(rays) // 20
+    oracle.scene_destroy(scene)
+    fast.close(); slow.close()
+
+
+def test_triangles_too_small_or_too_large_for_the_short_barycentric_form(gpu_lib, workdir, oracle):
+    """A divisor outside 2^-63 .. 2^125 (triangle edges below ~2e-5 or above ~2e9 scene units) or a degenerate triangle (denom 0): the first kind makes
+    the whole scene take the divisions (DSceneView::fastBary), the second can never be hit either way.  Rays aimed into each of them: the oracle's
+    records, bit for bit."""
+    from raylib_amd import binding, scenes
+    d = os.path.join(str(workdir), "extreme"); os.makedirs(d, exist_ok=True)
+    for tag, special in (("ordinary", []),
+                         ("degenerate", [((0.2, 0.2, 0.5), (0.2, 0.2, 0.5), (0.4, 0.3, 0.5)), ((0.0, 0.0, 0.6), (0.1, 0.1, 0.6), (0.2, 0.2, 0.6))]),
+                         ("tiny", [((0.3, 0.3, 0.5), (0.3 + 6e-6, 0.3, 0.5), (0.3, 0.3 + 6e-6, 0.5))]),
+                         ("huge", [((-3e9, -3e9, -7.0), (3e9, -3e9, -7.0), (0.0, 3e9, -7.0))])):
+        tri = [((-1.0, -1.0, 0.0), (1.0, -1.0, 0.0), (0.0, 1.0, 0.0)), ((-1.0, -1.0, -2.0), (1.5, -1.0, -2.0), (0.0, 1.5, -2.5))] + special
+        obj = os.path.join(d, tag + ".obj")
+        with open(obj, "w") as f:
+            f.write("mtllib %s.mtl\nusemtl white\n" % tag)
+            for k, t in enumerate(tri):
+                f.write("usemtl %s\n" % ("light" if k == 1 else "white"))      # something to see: the far triangle glows
+                for v in t:
+                    f.write("v %.9g %.9g %.9g\n" % v)
+                f.write("f %d %d %d\n" % (3 * k + 1, 3 * k + 2, 3 * k + 3))
+        with open(os.path.join(d, tag + ".mtl"), "w") as f:
+            f.write(scenes.CORNELL_MTL)
+        ses = binding.SceneSession(gpu_lib, obj, (0.0, 0.0, 3.0), (0.0, 0.0, 0.0), 45.0, 1.0)
+        rng = np.random.RandomState(5)
+        o = np.tile(np.asarray([[0.1, 0.2, 3.0]], np.float32), (4000, 1))
+        tg = np.concatenate([rng.uniform(-1.2, 1.2, (3000, 3)) * (1, 1, 0), np.asarray(tri[-1][0]) + rng.uniform(-1, 1, (1000, 3)) * (1.2e-5, 1.2e-5, 0)]).astype(np.float32)
+        rays = np.ascontiguousarray(np.concatenate([o, tg - o], axis=1), np.float32)
+        out = np.zeros(len(rays), ffi.HIT_DTYPE)
+        assert gpu_lib.RaylibAMD_ClosestHit(ses.scene, rays.ctypes.data_as(C.POINTER(C.c_float)), len(rays), 1e-4, out.ctypes.data) == 1
+        flat = helpers.objflat.load_obj(obj, oracle)
+        scene = oracle.scene_create(flat, 1)
+        want = oracle.closest_hit(scene, rays, 1e-4)
+        for f in ("hit", "t", "p", "n"):
+            a, b = out[f], want[f]
+            assert np.array_equal(bits(a) if a.dtype == np.float32 else a, bits(b) if b.dtype == np.float32 else b), (tag, f)
+        img = ses.render(48, 48, 2)
+        ref = oracle.render(scene, ffi.make_camera((0.0, 0.0, 3.0), (0.0, 0.0, 0.0), 45.0, 1.0), ffi.make_settings(48, 48, 2), seed=1)
+        assert helpers.same(img[..., :3], ref[..., :3]).all(), tag
+        print("%s: %d of %d rays hit" % (tag, out["hit"].sum(), len(rays)))
+        oracle.scene_destroy(scene)
+        ses.close()
+
+
 def test_sample_zero_is_unjittered_and_matches_per_sample_golden(sessions):
     g = golden("cornell")
     img = sessions["cornell"].render(64, 64, 1)

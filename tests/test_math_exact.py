@@ -91,7 +91,7 @@ def test_short_exact_reciprocal_and_square_root_on_every_float(gpu_lib):
     """normalize, 1 / tan, 1 / (1 + ...), the ray's 1 / d: on the device `1.0f / x` and `sqrtf(x)` run as short sequences (csrc/rl_glibc_math.h
     rcp1_ / sqrtf_: v_rcp + one Newton step, v_rsq + one residual step, inside a range guard) instead of the compiler's 36- and 57-cycle IEEE
     expansions.  They must BE those expansions' results: all 2^32 bit patterns are compared on the device, inside the product library."""
-    for which, name in ((0, "1.0f / x"), (1, "sqrtf(x)")):
+    for which, name in ((0, "1.0f / x"), (1, "sqrtf(x)"), (2, "a / b with RN(1 / b) in hand (div_by_)"), (3, "the triangle test's short barycentric form")):
         bad, first = C.c_uint64(1), C.c_uint64(0)
         assert gpu_lib.RaylibAMD_VerifyExactMath(which, C.byref(bad), C.byref(first)) == 1
         print("%s: %d of 2^32 inputs differ from the IEEE expansion" % (name, bad.value))
