@@ -1352,11 +1352,45 @@ __device__ __forceinline__ void WaveLdsSync()
 // FULL: the wide tree, if the launch carries one, has float boxes (S.nodes4f) -- small scenes; else grid nodes (S.nodes4)
 // LDS (with FULL, triangle scenes within the RL_LDS_MAX* limits): the scene's records are copied to LDS at the start and read from there;
 //     LDS == 2: a scene of <= 16 leaves, walked through its leaf list (TraverseLeafList) instead of its tree
+// The megakernels' arguments are ~110 dwords of scalars (render parameters, camera, scene view, sky rotation, pointers).  The compiler loads them
+// all at the kernel's entry and keeps them for its whole life -- in 102 SGPRs that the loops' own masks and counters need too: 50 of them went straight
+// to VGPR lanes (v_writelane), and every later use was a v_readlane, four VALU issue cycles each, ~400 of them in k_trace's code (6 per record of the
+// leaf list's box loop, 7 per pick, 9 per Newton iteration of the sampler ...), on a kernel that is bound by exactly that port.  RL_ARGS() reads them
+// again from the kernel-argument segment where a part of the loop needs them (s_load through the scalar cache: no VALU slot, and three other waves
+// to cover its latency): the offset goes through an empty asm statement, so that the loads can neither be hoisted out of the loop nor merged with
+// the previous part's, and what they fetch dies with the block.  RL_KARG_RELOAD=0: the arguments as the compiler delivers them.
+#ifndef RL_KARG_RELOAD
+#define RL_KARG_RELOAD 1
+#endif
+struct KTraceArgs { DRenderParams P; DSceneView S; SkyRot R; SampleRGB* samples; float* pathStack; unsigned long long* counters; unsigned int* jobCounter; };
+template <class T> __device__ __forceinline__ T KArg(uint32_t offset)
+{
+	uint32_t z = 0u;
+	asm volatile("" : "+s"(z));
+	T v;
+	__builtin_memcpy(&v, (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offset + (z << 2), sizeof(T));   // (z << 2: the compiler must see a dword-aligned address to take the scalar path)
+	return v;
+}
+#if RL_KARG_RELOAD
+#define RL_ARGS() \
+	const DRenderParams P = KArg<DRenderParams>((uint32_t)offsetof(KTraceArgs, P)); const DSceneView S = KArg<DSceneView>((uint32_t)offsetof(KTraceArgs, S)); \
+	const SkyRot R = KArg<SkyRot>((uint32_t)offsetof(KTraceArgs, R)); SampleRGB* const samples = KArg<SampleRGB*>((uint32_t)offsetof(KTraceArgs, samples)); \
+	float* const pathStack = KArg<float*>((uint32_t)offsetof(KTraceArgs, pathStack)); unsigned long long* const counters = KArg<unsigned long long*>((uint32_t)offsetof(KTraceArgs, counters)); \
+	unsigned int* const jobCounter = KArg<unsigned int*>((uint32_t)offsetof(KTraceArgs, jobCounter)); \
+	(void)P; (void)S; (void)R; (void)samples; (void)pathStack; (void)counters; (void)jobCounter
+#else
+#define RL_ARGS() \
+	const DRenderParams& P = Pk; const DSceneView& S = Sk; const SkyRot& R = Rk; SampleRGB* const samples = samplesK; float* const pathStack = pathStackK; \
+	unsigned long long* const counters = countersK; unsigned int* const jobCounter = jobCounterK; \
+	(void)P; (void)S; (void)R; (void)samples; (void)pathStack; (void)counters; (void)jobCounter
+#endif
+
 template <int STACK, bool PRIMS, bool FULL, int LDS = 0>
 __global__ void __launch_bounds__(RL_BLOCK, (STACK <= 32 ? RL_TRACE_MIN_WAVES : 2))
-k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __restrict__ samples,
-        float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
+k_trace(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB* __restrict__ samplesK,
+        float* __restrict__ pathStackK, unsigned long long* __restrict__ countersK, unsigned int* __restrict__ jobCounterK)
 {
+	(void)Pk; (void)Sk; (void)Rk; (void)samplesK; (void)pathStackK; (void)countersK; (void)jobCounterK;
 	RL_MATH_PROLOGUE();
 	__shared__ int s_stack[STACK * RL_BLOCK];
 	__shared__ float4 s_scene[LDS ? LdsAt<LDS>::TOTAL : 1];
@@ -1368,6 +1402,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 	if (LDS == 2 && threadIdx.x == 0) { s_jobs = 0ull; s_lock = 0u; s_done = 0u; }   // empty: the first wave to ask draws the workgroup's first chunk from its XCD's head
 #endif
 	if (LDS) {
+		RL_ARGS();
 		const uint32_t nN = (uint32_t)(LDS == 2 ? S.numLeafRecords : S.numNodes4) * 8u, nT = (uint32_t)S.numTriangles * 4u, nM = (uint32_t)S.numMaterials * 5u;
 		for (uint32_t i = threadIdx.x; i < 4u; i += RL_BLOCK) s_scene[RL_LDS_ROOT + i] = ((const float4*)S.nodes)[i];
 		for (uint32_t i = threadIdx.x; i < nN; i += RL_BLOCK) s_scene[RL_LDS_NODES + (i >> 3) * RL_LDS_NSTRIDE + (i & 7u)] = ((const float4*)(LDS == 2 ? S.leafList : S.nodes4f))[i];
@@ -1390,7 +1425,9 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t gtid = blockIdx.x * RL_BLOCK + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t numSlots = P.numLocalCells * 64u;
+	uint32_t numSlots;
+	JobSource js;
+	{ RL_ARGS(); numSlots = P.numLocalCells * 64u; js = JobSourceInit(P); }
 
 	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);
 	Rng g; g.s.state = 0;
@@ -1408,14 +1445,13 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 	// (Round 2 gave every wave its first chunk without an atomic, because 4096 waves asking ONE counter at the same instant stood in line for ~45 us; with a
 	// head per XCD the line is an eighth as long and the first chunk comes from the wave's own band like every other.)
 	uint32_t chunkNext = 0, chunkEnd = 0;
-	JobSource js = JobSourceInit(P);
 	bool globalDone = false;
 	uint32_t qCount = 0;   // LDS == 2: camera rays waiting in the wave's queue
 	RL_TIMELINE(0);
 #ifdef RL_DIAG_STAMPS
 	// diagnostic build only: shader-clock time per phase (refill | traverse | shade | fold), summed per wave
 	unsigned long long stampAcc[4] = { 0, 0, 0, 0 }, subAcc[4] = { 0, 0, 0, 0 }, laneAcc[4] = { 0, 0, 0, 0 }, laneT[4] = { 0, 0, 0, 0 };
-	c.diag = counters;
+	{ RL_ARGS(); c.diag = counters; }
 	unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 	#define RL_SUBSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); subAcc[k] += now_ - subLast; subLast = now_; __builtin_amdgcn_sched_barrier(0); }
 	unsigned long long subLast = 0;
@@ -1444,6 +1480,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 		// once instead of occupying a lane slot through a whole bounce trip (in a 16:9 Cornell frame
 		// more than half of the camera samples never touch the scene).
 		if constexpr (LDS == 2) {
+			RL_ARGS();
 			// Leaf-list scenes need no traversal stack, and its LDS (1024 dwords per wave) is a QUEUE of camera rays instead: rays are
 			// generated 64 at a time -- every lane takes a job, the same code for all of them -- the ones that cannot hit anything are finished
 			// on the spot as in the rounds below, the others are written to the queue back to back (ballot + prefix rank), and the idle
@@ -1566,6 +1603,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 			WaveLdsSync();
 		} else
 		for (int round = 0; round < RL_REFILL_ROUNDS; ++round) {
+			RL_ARGS();
 			const bool need = !active && !exhausted;
 			const unsigned long long mask = Ballot(need);
 			if (mask == 0ull) break;
@@ -1622,12 +1660,15 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 		RL_STAMP(0);
 		RL_LANEBEGIN();
 		HitRec h; h.tri = -1;
-		const bool doTrace = active && depth < P.maxPathLength;   // renderer.cc:120-123 otherwise
-		bool hit = false;
+		bool doTrace, hit = false;
+		{
+		RL_ARGS();
+		doTrace = active && depth < P.maxPathLength;   // renderer.cc:120-123 otherwise
 		// the 4-wide tree when the launch carries it (triangle scenes; half the steps: 24.6 -> 22.4 ms on the Cornell frame)
 		if (doTrace) {
 			if constexpr (LDS != 0) hit = Traverse4<STACK, false, PRIMS, FULL, LDS>(S, o, d, rayTime, P.rayTMin, h, stk, c, sm);   // an LDS-resident scene has its wide tree
 			else hit = (!PRIMS && (FULL ? (const void*)S.nodes4f : (const void*)S.nodes4)) ? Traverse4<STACK, false, PRIMS, FULL, LDS>(S, o, d, rayTime, P.rayTMin, h, stk, c, sm) : Traverse<STACK, false, PRIMS>(S, o, d, rayTime, P.rayTMin, h, stk, c);
+		}
 		}
 		RL_LANESTAMP(0, doTrace);
 		RL_STAMP(1);
@@ -1638,6 +1679,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 			if (!doTrace) {
 				done = true;
 			} else if (hit) {
+				RL_ARGS();
 				Surf s;
 				RL_LANEBEGIN();
 #ifdef RL_DIAG_STAMPS
@@ -1676,6 +1718,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 				RL_SUBSTAMP(2);
 				RL_LANESTAMP(1, true);
 			} else {
+				RL_ARGS();
 				RL_LANEBEGIN();
 				L = MissShader<STACK, PRIMS, FULL, LDS>(S, R, o, d, rayTime, P.rayTMin, stk, c, sm);
 				done = true;
@@ -1683,6 +1726,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 			}
 			RL_STAMP(2);
 			if (done) {
+				RL_ARGS();
 				RL_LANEBEGIN();
 				// fold back to the camera: radiance = (0 + refl*Li*sp/pdf) + E at every vertex
 #if RL_FOLD_PREFETCH > 0
@@ -1725,6 +1769,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 				RL_LANESTAMP(3, true);
 			}
 			if (store) {
+				RL_ARGS();
 				// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
 				float4* st = (float4*)pathStack + ((size_t)depth * P.stackStride + gtid) * 2u;
 				st[0] = rec0; st[1] = rec1;
@@ -1734,6 +1779,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 		RL_STAMP(3);
 	}
 
+	RL_ARGS();
 #ifdef RL_DIAG_STAMPS
 	if (lane == 0) for (int k = 0; k < 4; ++k) { atomicAdd(&counters[CNT_COUNT + k], stampAcc[k]); atomicAdd(&counters[CNT_COUNT + 8 + k], subAcc[k]); atomicAdd(&counters[CNT_COUNT + 12 + k], c.tAcc[k]); atomicAdd(&counters[CNT_COUNT + 20 + k], laneAcc[k]); if (RL_DIAG_STAMPS < 2) atomicAdd(&counters[CNT_COUNT + 4 + k], laneT[k]); }
 #endif
@@ -1746,6 +1792,7 @@ k_trace(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __
 		if (lane == 0 && v) atomicAdd(&counters[k], v);
 	}
 }
+#undef RL_ARGS
 
 // ---------------------------------------------------------------------------
 // The pool megakernel.  Same job queue, same per-path arithmetic and the same outputs as k_trace, but a wave
