@@ -1792,7 +1792,6 @@ k_trace(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB*
 		if (lane == 0 && v) atomicAdd(&counters[k], v);
 	}
 }
-#undef RL_ARGS
 
 // ---------------------------------------------------------------------------
 // The pool megakernel.  Same job queue, same per-path arithmetic and the same outputs as k_trace, but a wave
@@ -2040,12 +2039,13 @@ template <int LSTACK, bool PRIMS, int K> struct PoolOcc {
 // WIDE: traverse the BVH4 (S.nodes4) instead of the BVH2
 template <int STACK, bool PRIMS, int K, int LSTACK = STACK, bool WIDE = false>
 __global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<LSTACK, PRIMS, K>::kBlocks))
-k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRGB* __restrict__ samples,
-             float* __restrict__ pathStack, unsigned long long* __restrict__ counters, unsigned int* __restrict__ jobCounter)
+k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB* __restrict__ samplesK,
+             float* __restrict__ pathStackK, unsigned long long* __restrict__ countersK, unsigned int* __restrict__ jobCounterK)
 #ifndef RL_TU_POOL
 ;   // defined in the translation unit of rl_render_pool.hip: this same source, compiled with a scheduler strategy of its own (Makefile); instances below
 #else
 {
+	(void)Pk; (void)Sk; (void)Rk; (void)samplesK; (void)pathStackK; (void)countersK; (void)jobCounterK;   // read through RL_ARGS() where a part of the loop needs them (k_trace)
 	RL_MATH_PROLOGUE();
 	constexpr int PP = 64 * K;
 	static_assert(LSTACK <= STACK, "the LDS part cannot exceed the stack");
@@ -2057,18 +2057,11 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const float tMinC = __builtin_canonicalizef(P.rayTMin);   // known to be canonical: the box tests' max chains start from it without a v_max x, x per step
-#if RL_POOL_NODEPTR_VGPR
-	// the wide nodes' base address in a VGPR pair for the kernel's lifetime: as one of ~100 uniform values it is spilled to a VGPR's lanes and read back
-	// (two v_readlane, 4 issue cycles each) at every traversal step
-	DSceneView St = S;
-	{ const DNode4Q* pn = S.nodes4; asm volatile("" : "+v"(pn)); St.nodes4 = pn; }
-#else
-	const DSceneView& St = S;
-#endif
 	float (*pool)[PP] = s_pool[wave];
 	unsigned char* freeList = s_free[wave];
-	const uint32_t numSlots = P.numLocalCells * 64u;
+	uint32_t numSlots;
+	JobSource js;
+	{ RL_ARGS(); numSlots = P.numLocalCells * 64u; js = JobSourceInit(P); }
 	const unsigned long long laneLt = (1ull << lane) - 1ull;
 	// path-stack column of home slot p: consecutive lanes -> consecutive columns
 	const uint32_t homeBase = blockIdx.x * (RL_BLOCK * K) + threadIdx.x;
@@ -2084,7 +2077,6 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 	// (Round 2 gave every wave its first chunk without an atomic, because 4096 waves asking ONE counter at the same instant stood in line for ~45 us; with a
 	// head per XCD the line is an eighth as long and the first chunk comes from the wave's own band like every other.)
 	uint32_t chunkNext = 0, chunkEnd = 0;
-	JobSource js = JobSourceInit(P);
 	bool globalDone = false, exhausted = false;   // wave-uniform
 #ifdef RL_DIAG_TIMELINE
 	const uint32_t gtid = blockIdx.x * RL_BLOCK + threadIdx.x;
@@ -2102,7 +2094,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 	T.best.t = INFINITY; T.best.a = T.best.b = 0.0f; T.best.tri = -1; T.cur = IDLE; T.sp = 0; T.leafI = 0;
 #ifdef RL_DIAG_STAMPS
 	unsigned long long stampAcc[4] = { 0, 0, 0, 0 };
-	c.diag = counters;
+	{ RL_ARGS(); c.diag = counters; }
 	unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 	#define RL_PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[k] += now_ - stampLast; stampLast = now_; __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -2126,6 +2118,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 				nRes += (uint32_t)__popcll(Ballot(stActive[p] && (q == Q_MISS || q == Q_CLEAR || q == Q_OCCLUDED)));
 			}
 			if (lane == 0) {
+				RL_ARGS();
 				atomicAdd(&counters[CNT_COUNT + 21], 1ull);
 				atomicAdd(&counters[CNT_COUNT + 4], (unsigned long long)nAct); atomicAdd(&counters[CNT_COUNT + 5], (unsigned long long)nEmpty);
 				atomicAdd(&counters[CNT_COUNT + 6], (unsigned long long)nQ); atomicAdd(&counters[CNT_COUNT + 7], (unsigned long long)nH);
@@ -2137,6 +2130,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 #endif
 		// ---- refill: deal new camera samples to the free slots (wave64 ballot + prefix ranks) ----
 		if (!exhausted) {
+			RL_ARGS();
 			uint32_t pos[K];
 			uint32_t nFree = 0;
 			#pragma unroll
@@ -2257,6 +2251,16 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 
 		// ---- traversal phase: every waiting query of the pool; a lane takes the next slot whenever its ray is finished ----
 		{
+			RL_ARGS();
+			const float tMinC = __builtin_canonicalizef(P.rayTMin);   // known to be canonical: the box tests' max chains start from it without a v_max x, x per step
+#if RL_POOL_NODEPTR_VGPR
+			// the wide nodes' base address in a VGPR pair for the phase: as one of the loop's many uniform values it would be spilled to a VGPR's lanes and
+			// read back (two v_readlane, 4 issue cycles each) at every traversal step
+			DSceneView St = S;
+			{ const DNode4Q* pn = S.nodes4; asm volatile("" : "+v"(pn)); St.nodes4 = pn; }
+#else
+			const DSceneView& St = S;
+#endif
 			WaveLdsSync();
 			uint32_t nextSlot = 0;
 			uint32_t finished = 0;      // rays completed in this phase (wave-uniform)
@@ -2326,6 +2330,8 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 		//     into an occlusion query, a returned occlusion query ends the path.  Hits are only LISTED.
 		uint32_t nHit = 0;
 		uint32_t hitIdx[K];
+		{
+		RL_ARGS();
 		#pragma unroll
 		for (int p = 0; p < K; ++p) {
 			const int slot = p * 64 + (int)lane;
@@ -2359,12 +2365,14 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 			if (isHit) freeList[hitIdx[p]] = (unsigned char)slot;
 			nHit += (uint32_t)__popcll(hm);
 		}
+		}
 		WaveLdsSync();
 		// (2) hits are shaded 64 at a time by whichever lane: the expensive material code always runs with a full wave.
 		//     A remainder below 64 waits in its slots for the next trip's hits (until the job queue is empty).
 		//     The path registers come from the home lane by ds_bpermute and return through the slot's hit fields.
 		uint32_t shadedEnd = 0;
 		for (;;) {
+			RL_ARGS();
 			if (shadedEnd >= nHit) break;
 			if (nHit - shadedEnd < 64u && !exhausted) break;   // once the job queue is empty no refill will top the list up: waiting only stretches the tail
 #ifdef RL_POOL_WATCHDOG
@@ -2438,6 +2446,7 @@ k_trace_pool(const DRenderParams P, const DSceneView S, const SkyRot R, SampleRG
 		RL_PSTAMP(2);
 	}
 
+	RL_ARGS();
 #ifdef RL_DIAG_STAMPS
 	if (lane == 0) for (int k = 0; k < 4; ++k) { atomicAdd(&counters[CNT_COUNT + k], stampAcc[k]); atomicAdd(&counters[CNT_COUNT + 12 + k], c.tAcc[k]); }
 #endif
