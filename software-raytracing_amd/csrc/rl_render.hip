@@ -342,12 +342,14 @@ __device__ __forceinline__ bool OwnBoxPassMnMx(const float4* rec, V3 o, V3 inv, 
 }
 __device__ __forceinline__ bool OwnBoxPassBox(V3 mn, V3 mx, V3 o, V3 inv /* exact 1/d */, float tMin, float t)
 {
+	// (lo = t0 > lo ? t0 : lo and hi = t1 < hi ? t1 : hi -- a NaN keeps the old bound -- are fmaxf(lo, t0) and fminf(hi, t1), one v_max / v_min each
+	// instead of a compare and a select; the sign of a zero, the one thing the two forms may disagree on, plays no part in the comparisons below)
 	float lo = tMin, hi = FLT_MAX;
-	{ float t0 = (mn.x - o.x) * inv.x, t1 = (mx.x - o.x) * inv.x; if (inv.x < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = t0 > lo ? t0 : lo; hi = t1 < hi ? t1 : hi; }
+	{ float t0 = (mn.x - o.x) * inv.x, t1 = (mx.x - o.x) * inv.x; if (inv.x < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = fmaxf(lo, t0); hi = fminf(hi, t1); }
 	bool ok = !(hi < lo);
-	{ float t0 = (mn.y - o.y) * inv.y, t1 = (mx.y - o.y) * inv.y; if (inv.y < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = t0 > lo ? t0 : lo; hi = t1 < hi ? t1 : hi; }
+	{ float t0 = (mn.y - o.y) * inv.y, t1 = (mx.y - o.y) * inv.y; if (inv.y < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = fmaxf(lo, t0); hi = fminf(hi, t1); }
 	ok = ok && !(hi < lo);
-	{ float t0 = (mn.z - o.z) * inv.z, t1 = (mx.z - o.z) * inv.z; if (inv.z < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = t0 > lo ? t0 : lo; hi = t1 < hi ? t1 : hi; }
+	{ float t0 = (mn.z - o.z) * inv.z, t1 = (mx.z - o.z) * inv.z; if (inv.z < 0.0f) { const float q = t0; t0 = t1; t1 = q; } lo = fmaxf(lo, t0); hi = fminf(hi, t1); }
 	// ... and the candidate's t must not lie before the ray enters that box (by more than the slack the box tests are
 	// widened by): then "this box starts beyond the best hit so far" implies "nothing in it is closer", whatever the order
 	return ok && !(hi < lo) && t * RL_CANDIDATE_SLACK >= lo;
@@ -659,12 +661,19 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const float4 nZ = *(const float4*)(rec + oNZ), fZ = *(const float4*)(rec + oFZ);
 			// (Round 3, measured and not kept: the same test in fewer issue cycles by the cost table of tools/valu_calib.hip -- entry = max(tMin, max3), exit = min3 without
 			// the clamp, culled <=> sign of fma(exit, widen, -entry) smeared into the key: 34 cycles per box for 44 on paper, 14.80 ms for 14.31 on the GPU, twice.)
+			// One box: six fma, max + max3, min3, and the key.  The exit needs no clamp to FLT_MAX (an axis without a constraint gives +inf or NaN, which min3 skips;
+			// "NaN * widen < tn" is false: the box counts as met), and the entry no clamp to 0: this kernel only runs with rayTMin >= 0 (rl_runtime.inl picks the
+			// tree walk otherwise), so tn >= tMin >= 0 is a sortable key as it is.  RL_LL_SMEAR: "culled" as the sign of fma(exit, widen, -entry) smeared over the key.
+			#ifndef RL_LL_SMEAR
+			#define RL_LL_SMEAR 1
+			#endif
 			#define RL_LSLAB(k, slot) { \
-				float tn = tMin, tf = FLT_MAX; \
-				tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = fminf(tf, __builtin_fmaf(fX.k, invb.x, cf.x)); \
+				float tn = tMin, tf; \
+				tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = __builtin_fmaf(fX.k, invb.x, cf.x); \
 				tn = fmaxf(tn, __builtin_fmaf(nY.k, invb.y, cn.y)); tf = fminf(tf, __builtin_fmaf(fY.k, invb.y, cf.y)); \
 				tn = fmaxf(tn, __builtin_fmaf(nZ.k, invb.z, cn.z)); tf = fminf(tf, __builtin_fmaf(fZ.k, invb.z, cf.z)); \
-				if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(fmaxf(tn, 0.0f)) & ~31u) | (uint32_t)(slot); }
+				if (RL_LL_SMEAR) key[slot] = ((__float_as_uint(tn) & ~31u) | (uint32_t)(slot)) | (uint32_t)((int32_t)__float_as_uint(__builtin_fmaf(tf, RL_BOX_WIDEN, -tn)) >> 31); \
+				else if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(tn) & ~31u) | (uint32_t)(slot); }
 			RL_LSLAB(x, 4 * g) RL_LSLAB(y, 4 * g + 1) RL_LSLAB(z, 4 * g + 2) RL_LSLAB(w, 4 * g + 3)
 			#undef RL_LSLAB
 		}
@@ -675,22 +684,22 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 #ifdef RL_WATCHDOG
 	int guardSel = 0;
 #endif
+	// the smallest key >= from, as the smallest (key - from) in unsigned arithmetic: an unused key (0xffffffff) lands on 0xffffffff - from and
+	// a key below `from` (a leaf already visited) wraps around to more than that -- so "nothing left" is "the smallest is not below
+	// 0xffffffff - from".  (Comparing the re-based minimum with 0xffffffff instead is wrong exactly when all 24 slots are candidates and
+	// all have been visited: the minimum is then a wrapped one, never equals 0xffffffff, and the loop does not end.  tools/gpu_fuzz.py found it.)
+	// The first pick (from == 0) needs no subtractions; the next one is made at the end of the loop's body.
+	uint32_t m = 0xffffffffu;
+	#pragma unroll
+	for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j]);
 	for (;;) {
 #ifdef RL_WATCHDOG
 		if (++guardSel > 200) { printf("leaf-list pick stuck: lane %u from %u tMin %g best %g keys %u %u %u %u\n", threadIdx.x, from, tMin, best.t, key[0], key[1], key[2], key[3]); break; }
 #endif
-		// the smallest key >= from, as the smallest (key - from) in unsigned arithmetic: an unused key (0xffffffff) lands on 0xffffffff - from and
-		// a key below `from` (a leaf already visited) wraps around to more than that -- so "nothing left" is "the smallest is not below
-		// 0xffffffff - from".  (Comparing the re-based minimum with 0xffffffff instead is wrong exactly when all 24 slots are candidates and
-		// all have been visited: the minimum is then a wrapped one, never equals 0xffffffff, and the loop does not end.  tools/gpu_fuzz.py found it.)
-		uint32_t m = 0xffffffffu;
-		#pragma unroll
-		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] - from);
 		if (m >= 0xffffffffu - from) break;
 		m += from;
-		// the nearest leaf left starts behind the hit (the slab test's own cut: tf * widen < tn).  Not with a negative rayTMin: the keys hold
-		// max(entry, 0), and a leaf entered behind the origin may still hold a hit nearer (more negative) than a negative best one
-		if (tMin >= 0.0f && best.t * RL_BOX_WIDEN < __uint_as_float(m & ~31u)) break;
+		// the nearest leaf left starts behind the hit (the slab test's own cut: tf * widen < tn; the keys are entry distances, rayTMin >= 0 here)
+		if (best.t * RL_BOX_WIDEN < __uint_as_float(m & ~31u)) break;
 		from = m + 1u;
 		RL_WSTEP(6);
 		const uint32_t j = m & 31u;
@@ -719,6 +728,9 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 				if (ANYHIT) return true;
 			}
 		}
+		m = 0xffffffffu;
+		#pragma unroll
+		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] - from);
 	}
 	return best.tri >= 0;
 }

@@ -551,7 +551,8 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				lds = full && (e ? atoi(e) != 0 : true) && sc.bvh.nodes4.size() <= RL_LDS_MAXNODES && sc.triangles.size() <= RL_LDS_MAXTRIS && sc.materials.size() <= RL_LDS_MAXMATS;
 				// ... and a scene of few leaves without a tree (rl_bvh.cc "the leaf list"); RAYLIB_LEAF_LIST=0 walks its BVH4 instead
 				const char* f = getenv("RAYLIB_LEAF_LIST");
-				const bool flat = lds && traceView.leafList != nullptr && traceView.numLeafRecords <= RL_LEAFLIST_RECORDS && sc.triangles.size() <= RL_LEAFLIST_MAXTRIS && (f ? atoi(f) != 0 : true);
+				const bool flat = lds && traceView.leafList != nullptr && traceView.numLeafRecords <= RL_LEAFLIST_RECORDS && sc.triangles.size() <= RL_LEAFLIST_MAXTRIS && (f ? atoi(f) != 0 : true)
+				                  && st.rayTMin >= 0.0f;   // its sortable keys are entry distances, never negative (rl_render.hip TraverseLeafList)
 				if (flat) traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, 2>;
 				else if (lds) traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, 1>;
 			}
