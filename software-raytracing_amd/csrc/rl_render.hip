@@ -584,10 +584,16 @@ __device__ __forceinline__ V3 ClampInv(V3 inv)
 	// only infinities: a finite reciprocal, however large, scales its axis' parameters exactly as the reference's arithmetic does
 	return v3(isinf(inv.x) ? copysignf(1e30f, inv.x) : inv.x, isinf(inv.y) ? copysignf(1e30f, inv.y) : inv.y, isinf(inv.z) ? copysignf(1e30f, inv.z) : inv.z);
 }
+typedef float rl_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t rl_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 GLoadF4(const void* p, int i) { const rl_v4f v = ((const __attribute__((address_space(1))) rl_v4f*)p)[i]; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 GLoadU4(const void* p, int i) { const rl_v4u v = ((const __attribute__((address_space(1))) rl_v4u*)p)[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 #define RL_WIDE_STEP_Q(S_, cur_, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
-	const float4* np_ = (const float4*)((S_).nodes4 + (cur_)); \
-	const float4 h0_ = np_[0]; const uint4 l_ = ((const uint4*)np_)[1]; const uint4 u_ = ((const uint4*)np_)[2]; \
-	const int4 ch = ((const int4*)np_)[3]; \
+	/* (the loads spell the global address space out: the pool kernel keeps the base in a VGPR pair behind an empty asm statement, which hides where it */ \
+	/*  points -- and a flat_load counts against the LDS counter as well and waits for both) */ \
+	const DNode4Q* np_ = (S_).nodes4 + (cur_); \
+	const float4 h0_ = GLoadF4(np_, 0); const uint4 l_ = GLoadU4(np_, 1); const uint4 u_ = GLoadU4(np_, 2); \
+	const uint4 chu_ = GLoadU4(np_, 3); const int4 ch = make_int4((int)chu_.x, (int)chu_.y, (int)chu_.z, (int)chu_.w); \
 	const float Ax_ = h0_.w * (inv_).x, Ay_ = __uint_as_float(l_.w) * (inv_).y, Az_ = __uint_as_float(u_.w) * (inv_).z; \
 	const float Bx_ = (h0_.x - (o_).x) * (inv_).x, By_ = (h0_.y - (o_).y) * (inv_).y, Bz_ = (h0_.z - (o_).z) * (inv_).z; \
 	const float Ex_ = __builtin_fmaf(255.0f, fabsf(Ax_), fabsf(Bx_)) * 4.76837158e-7f, Ey_ = __builtin_fmaf(255.0f, fabsf(Ay_), fabsf(By_)) * 4.76837158e-7f, Ez_ = __builtin_fmaf(255.0f, fabsf(Az_), fabsf(Bz_)) * 4.76837158e-7f; \
@@ -1870,12 +1876,24 @@ __device__ __forceinline__ void StackPush(Trav& T, int* stk, int* ovf, int v)
 	if (T.sp < LSTACK) { stk[T.sp * RL_BLOCK] = v; ++T.sp; }
 	else if (LSTACK < STACK && T.sp < STACK) { ovf[T.sp - LSTACK] = v; ++T.sp; }
 }
+#ifndef RL_POP_SPLIT
+#define RL_POP_SPLIT 0
+#endif
 template <int LSTACK, int STACK>
 __device__ __forceinline__ bool PopOrFinish(Trav& T, int* stk, int* ovf)
 {
 	if (T.sp == 0) return true;
 	--T.sp;
+	// (The compiler sinks the two loads, one from scratch and one from LDS, into ONE flat_load through a selected pointer.  RL_POP_SPLIT keeps them apart --
+	//  measured: the colonnade hall, whose rays live above the LDS part of the stack, 402 ms against 377: two divergent arms cost more than the flat load.)
+#if RL_POP_SPLIT
+	int v;
+	if (LSTACK < STACK && T.sp >= LSTACK) { v = ovf[T.sp - LSTACK]; asm volatile("" : "+v"(v)); }
+	else v = stk[T.sp * RL_BLOCK];
+	T.cur = v;
+#else
 	T.cur = (LSTACK < STACK && T.sp >= LSTACK) ? ovf[T.sp - LSTACK] : stk[T.sp * RL_BLOCK];
+#endif
 	T.leafI = 0;
 	return false;
 }
