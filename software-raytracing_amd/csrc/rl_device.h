@@ -69,7 +69,7 @@ struct alignas(64) DTriIsect {
 	float v1[3];     // the other two vertices: the edges u = v1 - v0, v = v2 - v0 are formed on the device (the reference's own
 	float v2[3];     // subtraction), and the exact AABB of the three vertices is what the candidate rule tests the ray against
 	float uv, uu, vv;
-	float rden;      // RN(1 / denom) for 2^-63 <= |denom| <= 2^125; NaN for denom == 0 or NaN (never hit either way); any other divisor clears DSceneView::fastBary
+	float rden;      // RN(1 / denom) for 2^-62 <= |denom| <= 2^125; NaN for denom == 0 or NaN (never hit either way); any other divisor clears DSceneView::fastBary
 };
 static_assert(sizeof(DTriIsect) == 64, "DTriIsect");
 

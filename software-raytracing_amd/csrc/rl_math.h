@@ -99,7 +99,7 @@ __device__ __forceinline__ float sqrt_(float x) { return rlm::sqrtf_(x); }
 // compiler's IEEE expansion (0 mismatches; with the raw v_rcp_f32 for y, or a y that is not the correctly rounded reciprocal, it is not).  6 issue
 // cycles instead of 36.  Every step scales exactly with a power of two, so the significand proof carries to all operands that keep the intermediate
 // values in the normal range -- the conditions v_div_scale_f32 tests for, and which the CALLER has to guarantee:
-//   2^-126 <= |b| <= 2^126 (y normal),  |a| >= 2^-103 (the residual a - q0 b, a multiple of 2^(exponent(a) - 47), is exact),  2^-126 <= |a / b| < 2^127.
+//   2^-126 <= |b| <= 2^126 (y normal),  |a| >= 2^-102 (the residual a - q0 b, a multiple of 2^(exponent(a) - 47), is exact: RaylibAMD_VerifyExactMath's sweep fails at 2^-103),  2^-126 <= |a / b| < 2^127.
 // a = +0 gives +0 like the division (for positive b); other zeros, infinities and NaN are the caller's to keep away or to not care about.
 __device__ __forceinline__ float div_by_(float a, float b, float y) { const float q0 = a * y; return __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0); }
 

@@ -455,8 +455,8 @@ __device__ __noinline__ float2 CubeHit(const DCube* cubes, int index, V3 o, V3 d
 // from the record, rtm::div_by_ gives the same two quotients in 12 (all 2^46 significand pairs checked: tools/verify_fastdiv.hip).  Its conditions -- the ones
 // v_div_scale tests -- are met like this:
 //   * S.fastBary (host, rl_runtime.inl UploadScene): every triangle of the scene has denom == 0 or NaN (rden = NaN: both quotients NaN, "outside", as X / 0 and
-//     X / NaN make it) or 2^-63 <= |denom| <= 2^125; a scene with any other divisor takes the divisions (a uniform branch);
-//   * a quotient of at least 2^-38 then has |X| >= 2^-101: exact.  Anything smaller -- tiny, zero (whose sign the short form may get wrong), negative by less
+//     X / NaN make it) or 2^-62 <= |denom| <= 2^125; a scene with any other divisor takes the divisions (a uniform branch);
+//   * a quotient of at least 2^-38 then has |X| > 2^-101 (div_by_ wants 2^-102): exact.  Anything smaller -- tiny, zero (whose sign the short form may get wrong), negative by less
 //     than that -- may be off in the last place, which cannot change "pa + pb <= 1" (a term below 2^-38 moves a sum near 1 by less than a thousandth of its
 //     half-ulp), so: outside by more than 2^-38 is outside, inside by more than 2^-38 on both is inside, and the band between takes the divisions and the
 //     reference's own test.  (A ray through a vertex or along an edge; tests/test_gpu_parity.py aims rays there.)
@@ -2779,7 +2779,7 @@ __device__ __forceinline__ bool DivByHolds(float a, float b)
 {
 	const float ma = fabsf(a), mb = fabsf(b);
 	if (!(mb >= 0x1p-126f && mb <= 0x1p126f)) return false;
-	if (!(ma >= 0x1p-103f && ma <= FLT_MAX)) return false;
+	if (!(ma >= 0x1p-102f && ma <= FLT_MAX)) return false;
 	const float q = fabsf(a / b);
 	return q >= 0x1p-126f && q < 0x1p127f;
 }
@@ -2788,7 +2788,7 @@ __device__ __forceinline__ bool BaryDiffers(float X, float Y, float denom)
 	const float mag = fabsf(denom);
 	float rden;
 	if (denom == 0.0f || denom != denom) rden = __uint_as_float(0x7fc00000u);
-	else if (mag >= 0x1p-63f && mag <= 0x1p125f) rden = 1.0f / denom;
+	else if (mag >= 0x1p-62f && mag <= 0x1p125f) rden = 1.0f / denom;
 	else return false;   // such a divisor clears DSceneView::fastBary: the whole scene takes the divisions
 	float fa, fb, ea, eb;
 	const bool f = Barycentric(true, X, Y, denom, rden, fa, fb), e = Barycentric(false, X, Y, denom, rden, ea, eb);
@@ -2800,8 +2800,8 @@ k_verify_exact_math(int which, unsigned long long* __restrict__ out)
 	const unsigned long long tid = (unsigned long long)blockIdx.x * RL_BLOCK + threadIdx.x, n = (unsigned long long)gridDim.x * RL_BLOCK;
 	unsigned long long bad = 0, first = ~0ull;
 	// operands the sweeps pair every bit pattern with: ordinary values, the launch's and the triangles' kinds of constants, and the edges of the conditions
-	const float fixedB[12] = { 3.0f, 1920.0f, 1080.0f, 0.1f, -7.0f, 3.14159274f, 9.5e10f, 2.4e-9f, 0x1.8p-63f, 0x1.fffffep125f, 0x1p-126f, 0x1p126f };
-	const float fixedA[10] = { 1.0f, -3.3f, 1e-20f, 5e20f, 0x1p-103f, 0x1.fffffep-104f, 0x1.234568p-100f, 0.75f, 1919.0f, 0x1.fffffep127f };
+	const float fixedB[12] = { 3.0f, 1920.0f, 1080.0f, 0.1f, -7.0f, 3.14159274f, 9.5e10f, 2.4e-9f, 0x1.8p-62f, 0x1.fffffep125f, 0x1p-126f, 0x1p126f };
+	const float fixedA[10] = { 1.0f, -3.3f, 1e-20f, 5e20f, 0x1p-102f, 0x1.fffffep-103f, 0x1.234568p-100f, 0.75f, 1919.0f, 0x1.fffffep127f };
 	for (unsigned long long b = tid; b < (1ull << 32); b += n) {
 		const float x = __uint_as_float((uint32_t)b);
 		bool differs = false;
@@ -2815,7 +2815,7 @@ k_verify_exact_math(int which, unsigned long long* __restrict__ out)
 		} else {
 			// (X, Y, denom) of ordinary hits, of hits on an edge and at a vertex, of misses by a hair, with tiny, huge and special members
 			const float T[14][3] = { { 1.0e9f, 2.0e9f, 9.5e10f }, { -1.0e9f, -2.0e9f, -9.5e10f }, { 0.0f, 4.0e10f, 9.5e10f }, { -0.0f, 0.0f, 9.5e10f }, { 1e-3f, 9.4999e10f, 9.5e10f },
-			                         { 3e-12f, 1.0f, 2.4e-9f }, { -3e-12f, 1.0e-10f, 2.4e-9f }, { 1e-30f, 1e-31f, 0x1p-63f }, { 5e-20f, 2e-21f, 0x1.8p-60f }, { 1e-42f, 1e-10f, 1e-9f },
+			                         { 3e-12f, 1.0f, 2.4e-9f }, { -3e-12f, 1.0e-10f, 2.4e-9f }, { 1e-30f, 1e-31f, 0x1p-62f }, { 5e-20f, 2e-21f, 0x1.8p-60f }, { 1e-42f, 1e-10f, 1e-9f },
 			                         { 0x1p100f, 0x1p99f, 0x1p125f }, { 0x1.fffffep127f, 1.0f, 2.0f }, { 4.75e10f, 4.75e10f, 9.5e10f }, { 4.7500004e10f, 4.75e10f, 9.5e10f } };
 			for (int k = 0; k < 14; ++k) {
 				differs = differs || BaryDiffers(x, T[k][1], T[k][2]) || BaryDiffers(T[k][0], x, T[k][2]) || BaryDiffers(T[k][0], T[k][1], x);

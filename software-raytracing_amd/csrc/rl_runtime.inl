@@ -274,7 +274,7 @@ bool UploadScene(Scene& sc)
 		{   // the reciprocal of denom = uvuv - uuvv for the short barycentric divisions (rl_render.hip Barycentric, which states the conditions)
 			const float denom = uvuv - uuvv, mag = fabsf(denom);
 			if (denom == 0.0f || denom != denom) I.rden = std::numeric_limits<float>::quiet_NaN();
-			else if (mag >= 0x1p-63f && mag <= 0x1p125f) I.rden = 1.0f / denom;
+			else if (mag >= 0x1p-62f && mag <= 0x1p125f) I.rden = 1.0f / denom;
 			else { I.rden = std::numeric_limits<float>::quiet_NaN(); fastBary.store(0, std::memory_order_relaxed); }
 		}
 		DTriShade& Sh = shade[k];

@@ -273,7 +273,7 @@ def test_rays_through_vertices_and_along_edges_short_barycentrics_against_the_di
 
 
 def test_triangles_too_small_or_too_large_for_the_short_barycentric_form(gpu_lib, workdir, oracle):
-    """A divisor outside 2^-63 .. 2^125 (triangle edges below ~2e-5 or above ~2e9 scene units) or a degenerate triangle (denom 0): the first kind makes
+    """A divisor outside 2^-62 .. 2^125 (triangle edges below ~2e-5 or above ~2e9 scene units) or a degenerate triangle (denom 0): the first kind makes
     the whole scene take the divisions (DSceneView::fastBary), the second can never be hit either way.  Rays aimed into each of them: the oracle's
     records, bit for bit."""
     from raylib_amd import binding, scenes
@@ -500,8 +500,8 @@ def test_small_scene_walks_agree(name, sessions, gpu_lib, monkeypatch):
     monkeypatch.setenv("RAYLIB_POOL", "0")
     has_list = gpu_lib.RaylibAMD_SceneLeafListInfo(ses.scene, None) > 0
     assert has_list                                         # every fixture scene is that small
-    # rayTMin 0 and a negative one too: hits behind the origin are then legal (t >= rayTMin, triangle.cc:37), and the leaf list orders its leaves by
-    # an entry distance it clamps at 0
+    # rayTMin 0 and a negative one too: hits behind the origin are then legal (t >= rayTMin, triangle.cc:37); the leaf list orders its leaves by
+    # entry distances that must not be negative, so the runtime walks the tree for such a frame (csrc/rl_runtime.inl)
     for mode, spp, tmin in ((0, 16, 1e-4), (1, 1, 1e-4), (4, 1, 1e-4), (0, 4, 0.0), (0, 4, -0.25)):
         base = ses.render(64, 64, spp, mode=mode, tmin=tmin)
         st0 = ses.stats().as_dict()
@@ -515,7 +515,10 @@ def test_small_scene_walks_agree(name, sessions, gpu_lib, monkeypatch):
             assert helpers.same(img, base).all(), (name, mode, tmin, env)
             assert st0["rays"] == st1["rays"] and st0["cameraSamples"] == st1["cameraSamples"], (name, mode, tmin, env)
             if mode == 0 and "RAYLIB_LEAF_LIST" in env:
-                assert st0["nodesVisited"] != st1["nodesVisited"], "the leaf list was not the walk that ran"
+                if tmin >= 0.0:
+                    assert st0["nodesVisited"] != st1["nodesVisited"], "the leaf list was not the walk that ran"
+                else:
+                    assert st0["nodesVisited"] == st1["nodesVisited"], "a negative rayTMin must take the tree walk"
 
 
 @pytest.mark.timeout(120)
