@@ -596,7 +596,9 @@ __device__ __forceinline__ uint4 GLoadU4(const void* p, int i) { const rl_v4u v 
 	const uint4 chu_ = GLoadU4(np_, 3); const int4 ch = make_int4((int)chu_.x, (int)chu_.y, (int)chu_.z, (int)chu_.w); \
 	const float Ax_ = h0_.w * (inv_).x, Ay_ = __uint_as_float(l_.w) * (inv_).y, Az_ = __uint_as_float(u_.w) * (inv_).z; \
 	const float Bx_ = (h0_.x - (o_).x) * (inv_).x, By_ = (h0_.y - (o_).y) * (inv_).y, Bz_ = (h0_.z - (o_).z) * (inv_).z; \
-	const float Ex_ = __builtin_fmaf(255.0f, fabsf(Ax_), fabsf(Bx_)) * 4.76837158e-7f, Ey_ = __builtin_fmaf(255.0f, fabsf(Ay_), fabsf(By_)) * 4.76837158e-7f, Ez_ = __builtin_fmaf(255.0f, fabsf(Az_), fabsf(Bz_)) * 4.76837158e-7f; \
+	/* (|B| + 255 |A|) * 2^-21 as |A * c1| + |B * c2|: two multiplies by literals and an add with |.| modifiers, 2 issue cycles each -- as an fma with 255 the */ \
+	/* constant sat in an SGPR (the three-operand encoding takes no literal) next to the |.| modifiers, and an SGPR operand makes it 4 */ \
+	const float Ex_ = fabsf(Ax_ * 1.21593475e-4f) + fabsf(Bx_ * 4.76837158e-7f), Ey_ = fabsf(Ay_ * 1.21593475e-4f) + fabsf(By_ * 4.76837158e-7f), Ez_ = fabsf(Az_ * 1.21593475e-4f) + fabsf(Bz_ * 4.76837158e-7f); \
 	const float Bnx_ = Bx_ - Ex_, Bfx_ = Bx_ + Ex_, Bny_ = By_ - Ey_, Bfy_ = By_ + Ey_, Bnz_ = Bz_ - Ez_, Bfz_ = Bz_ + Ez_; \
 	const uint32_t nX_ = (nx_) ? u_.x : l_.x, fX_ = (nx_) ? l_.x : u_.x, nY_ = (ny_) ? u_.y : l_.y, fY_ = (ny_) ? l_.y : u_.y, nZ_ = (nz_) ? u_.z : l_.z, fZ_ = (nz_) ? l_.z : u_.z; \
 	const float tMinL_ = (tMin_), tmxL_ = (tmx_), widenL_ = (widen_); \
@@ -635,7 +637,21 @@ __device__ __forceinline__ uint4 GLoadU4(const void* p, int i) { const rl_v4u v 
 // same reason every widened box test here is: an accepted hit has t * RL_CANDIDATE_SLACK >= the entry into its triangle's own box (OwnBoxPass),
 // which lies inside the leaf's box, and RL_BOX_WIDEN exceeds RL_CANDIDATE_SLACK by 1e-6 -- four times the rounding of either side.
 // Measured on the Cornell frame: DESIGN.md section 2.
-template <bool ANYHIT>
+// DEFER (closest hit only): the candidate rule -- the ray passes the triangle's own box, OwnBoxPass, ~35 instructions -- is not applied to every candidate
+// that passes the barycentric test (five wave steps per bounce reach it, each with a handful of lanes) but ONCE, to the winner.  The search then finds
+// the nearest of a LARGER set (candidates that pass the triangle test) -- a cut on one of their distances cannot hide a nearer one --, and if that
+// winner also passes the rule it is the nearest of the smaller set too, tie rule included: the same hit.  If it does not (a hit on a sliver's rim, outside
+// the triangle's own box: 0 of the fuzz's 10^9 rays) the lane asks the walk that applies the rule to every candidate, out of line
+// (LeafListExact).  RL_LL_FORCE_EXACT=1 sends every hit there (test builds: the out-of-line walk must give the same frame).
+#ifndef RL_LL_DEFER_OWNBOX
+#define RL_LL_DEFER_OWNBOX 1
+#endif
+#ifndef RL_LL_FORCE_EXACT
+#define RL_LL_FORCE_EXACT 0
+#endif
+__device__ __noinline__ float4 LeafListExact(float ox, float oy, float oz, float dx, float dy, float dz, float tMin, const float4* sm, int numLeafRecords, int fastBary,
+                                             const DTriShade* shade, const DMaterial* materials, const DTexture* textures, const float* texels);
+template <bool ANYHIT, bool DEFER = false>
 __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d, float tMin, HitRec& best, Counters& c, const float4* sm)
 {
 	c.rays++;
@@ -673,13 +689,22 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			#ifndef RL_LL_SMEAR
 			#define RL_LL_SMEAR 1
 			#endif
+			// (The smeared form works on the NEGATED entry distance, ntn = min(-tMin, -planes): the sign test is then fma(tf, widen, ntn) with the constant as the
+			//  instruction's literal -- v_fmamk, 2 issue cycles; with "- tn" the compiler needs the three-operand encoding, which takes no literal, parks the
+			//  constant in an SGPR and pays the 4 cycles of an SGPR operand -- and the key drops ntn's sign bit with the mask it applies anyway.)
 			#define RL_LSLAB(k, slot) { \
 				float tn = tMin, tf; \
-				tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = __builtin_fmaf(fX.k, invb.x, cf.x); \
-				tn = fmaxf(tn, __builtin_fmaf(nY.k, invb.y, cn.y)); tf = fminf(tf, __builtin_fmaf(fY.k, invb.y, cf.y)); \
-				tn = fmaxf(tn, __builtin_fmaf(nZ.k, invb.z, cn.z)); tf = fminf(tf, __builtin_fmaf(fZ.k, invb.z, cf.z)); \
-				if (RL_LL_SMEAR) key[slot] = ((__float_as_uint(tn) & ~31u) | (uint32_t)(slot)) | (uint32_t)((int32_t)__float_as_uint(__builtin_fmaf(tf, RL_BOX_WIDEN, -tn)) >> 31); \
-				else if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(tn) & ~31u) | (uint32_t)(slot); }
+				if (RL_LL_SMEAR) { \
+					float ntn = -tMin; \
+					ntn = fminf(ntn, -__builtin_fmaf(nX.k, invb.x, cn.x)); tf = __builtin_fmaf(fX.k, invb.x, cf.x); \
+					ntn = fminf(ntn, -__builtin_fmaf(nY.k, invb.y, cn.y)); tf = fminf(tf, __builtin_fmaf(fY.k, invb.y, cf.y)); \
+					ntn = fminf(ntn, -__builtin_fmaf(nZ.k, invb.z, cn.z)); tf = fminf(tf, __builtin_fmaf(fZ.k, invb.z, cf.z)); \
+					key[slot] = ((__float_as_uint(ntn) & 0x7fffffe0u) | (uint32_t)(slot)) | (uint32_t)((int32_t)__float_as_uint(__builtin_fmaf(tf, RL_BOX_WIDEN, ntn)) >> 31); \
+				} else { \
+					tn = fmaxf(tn, __builtin_fmaf(nX.k, invb.x, cn.x)); tf = __builtin_fmaf(fX.k, invb.x, cf.x); \
+					tn = fmaxf(tn, __builtin_fmaf(nY.k, invb.y, cn.y)); tf = fminf(tf, __builtin_fmaf(fY.k, invb.y, cf.y)); \
+					tn = fmaxf(tn, __builtin_fmaf(nZ.k, invb.z, cn.z)); tf = fminf(tf, __builtin_fmaf(fZ.k, invb.z, cf.z)); \
+					if (!(tf * RL_BOX_WIDEN < tn)) key[slot] = (__float_as_uint(tn) & ~31u) | (uint32_t)(slot); } }
 			RL_LSLAB(x, 4 * g) RL_LSLAB(y, 4 * g + 1) RL_LSLAB(z, 4 * g + 2) RL_LSLAB(w, 4 * g + 3)
 			#undef RL_LSLAB
 		}
@@ -728,7 +753,7 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const V3 w = p - T.v0;
 			const float wv = dot(w, T.v), wu = dot(w, T.u);
 			float pa, pb;
-			if (Barycentric(S.fastBary != 0, T.uv * wv - T.vv * wu, T.uv * wu - T.uu * wv, T.denom, T.rden, pa, pb) && OwnBoxPassMnMx(tr, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
+			if (Barycentric(S.fastBary != 0, T.uv * wv - T.vv * wu, T.uv * wu - T.uu * wv, T.denom, T.rden, pa, pb) && (DEFER || OwnBoxPassMnMx(tr, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t))) {
 				if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 				best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 				if (ANYHIT) return true;
@@ -738,7 +763,23 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 		#pragma unroll
 		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] - from);
 	}
+	if (DEFER && !ANYHIT && best.tri >= 0) {
+		if (RL_LL_FORCE_EXACT || !OwnBoxPassMnMx(sm + LdsAt<2>::ISECT + best.tri * 6, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, best.t)) {
+			const float4 r = LeafListExact(o.x, o.y, o.z, d.x, d.y, d.z, tMin, sm, S.numLeafRecords, S.fastBary, S.shade, S.materials, S.textures, S.texels);
+			best.t = r.x; best.a = r.y; best.b = r.z; best.tri = __float_as_int(r.w);
+		}
+	}
 	return best.tri >= 0;
+}
+__device__ __noinline__ float4 LeafListExact(float ox, float oy, float oz, float dx, float dy, float dz, float tMin, const float4* sm, int numLeafRecords, int fastBary,
+                                             const DTriShade* shade, const DMaterial* materials, const DTexture* textures, const float* texels)
+{
+	DSceneView S; memset(&S, 0, sizeof(S));
+	S.numLeafRecords = numLeafRecords; S.fastBary = fastBary; S.shade = shade; S.materials = materials; S.textures = textures; S.texels = texels;
+	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);   // (the walk that asked has counted this ray)
+	HitRec best;
+	TraverseLeafList<false, false>(S, v3(ox, oy, oz), v3(dx, dy, dz), tMin, best, c, sm);
+	return make_float4(best.t, best.a, best.b, __int_as_float(best.tri));
 }
 
 // The same closest-hit search on the BVH4 (DNode4): four slab tests per step, hit children ordered by entry distance.
@@ -746,7 +787,7 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 template <int STACK, bool ANYHIT, bool PRIMS, bool FULL, int LDS = 0>
 __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c, const float4* sm = nullptr)
 {
-	if constexpr (LDS == 2) return TraverseLeafList<ANYHIT>(S, o, d, tMin, best, c, sm);
+	if constexpr (LDS == 2) return TraverseLeafList<ANYHIT, !ANYHIT && RL_LL_DEFER_OWNBOX>(S, o, d, tMin, best, c, sm);
 	c.rays++;
 	V3 invb = v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z));   // for the box tests (the candidate rule divides again: exact, and rare)
 	if (!FULL) invb = ClampInv(invb);
