@@ -157,6 +157,10 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
         source = ("STALE: " if stale else "") + "replayed from profiles/pmc_traffic.json (%s, build %s; loaded library is build %s)" % (rec.get("round"), rec.get("build_id"), build_id)
     traffic = rec["hbm_bytes_per_launch"] if rec else None
     hbm = None
+    if rec and stale and rec.get("cycles_per_launch"):
+        # counters of another build: priced against THAT build's launch (its cycles at the spec clock), not against this run's time -- old counts over a
+        # new time are a fraction of nothing; the line says STALE and the headline falls back to this run's algorithmic bytes
+        sec = rec["cycles_per_launch"] / 2.4e9
     if rec and sec > 0:
         gbs = traffic / sec / 1e9
         hbm = {"measured_bytes_per_launch": traffic, "gbs": gbs, "frac": gbs / HBM_PEAK_GBS, "tcc_hit_rate": rec.get("tcc_hit_rate")}

@@ -173,6 +173,13 @@ struct DRenderParams {
 	uint32_t guideShift;       // 0: every draw asks for jobChunk jobs; s > 0: at most (jobs left in the band at the wave's previous draw) >> s (TakeJobs)
 	uint32_t padQueue;
 	float    invWidth, invHeight;   // RN(1 / (float)width), RN(1 / (float)height): the pixel -> [0, 1) divisions of GenerateCell (rl_render.hip PixelUV)
+	// Cells no camera ray of which can meet the scene's bounding box (host, rl_runtime.inl CullCells: pinhole camera, no sky panorama, the frame's box on the
+	// image plane with a margin) are not in the job list: activeCells[i] is the i-th listed local cell (nullptr: all numLocalCells cells, in order), and
+	// k_resolve sums the constant every one of their samples would have come to -- emptyL, the sun's illuminance or nothing -- for cells flagged in cellEmpty.
+	const uint32_t* activeCells;
+	const uint8_t*  cellEmpty;
+	uint32_t numActiveCells;
+	float    emptyL[3];
 	uint32_t magicSamples;     // floor(2^32 / sampleCount), floor(2^32 / cellsX): division by multiply-high in DecodeJob
 	uint32_t magicCellsX;
 	uint64_t seedMixed;        // raylib_rng_mix64(seed), hoisted out of the per-sample stream set-up

@@ -1307,12 +1307,36 @@ __device__ __forceinline__ JobPixel DecodeJob(const DRenderParams& P, uint32_t j
 		cellLocal = (ii / sw) * P.cellsX + hh * sw + ii % sw;
 	}
 #endif
+	if (P.activeCells) cellLocal = P.activeCells[cellLocal];   // the job list holds the cells that can see the scene only (rl_device.h)
 	const uint32_t cell = P.cellFirst + cellLocal * P.cellStride;
 	uint32_t cy = __umulhi(cell, P.magicCellsX);
 	uint32_t cx = cell - cy * P.cellsX;
 	while (cx >= P.cellsX) { cx -= P.cellsX; ++cy; }
 	j.x = cx * 8u + (p & 7u); j.y = cy * 8u + (p >> 3);
 	j.slot = cellLocal * 64u + p;
+	j.sample = sLocal;
+	j.valid = (j.x < P.width) && (j.y < P.height);
+	return j;
+}
+
+// The same for 64 consecutive jobs from a base that is a multiple of 64 (the leaf-list kernel's batches): one cell at one sample, the lane is the pixel.
+// Everything but the pixel's coordinates is wave-uniform -- scalar arithmetic and, for the list of cells that can see the scene, a scalar load (the list
+// is written before the launch: constant address space) -- where the per-lane form spends ~25 VALU instructions and a vector load whose s_waitcnt
+// also waits for the wave's stores in flight.
+__device__ __forceinline__ JobPixel DecodeJobBatch(const DRenderParams& P, uint32_t base, uint32_t lane)
+{
+	JobPixel j;
+	const uint32_t rest = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) >> 6;
+	uint32_t cellLocal = __umulhi(rest, P.magicSamples);
+	uint32_t sLocal = rest - cellLocal * P.sampleCount;
+	while (sLocal >= P.sampleCount) { sLocal -= P.sampleCount; ++cellLocal; }
+	if (P.activeCells) cellLocal = *(const __attribute__((address_space(4))) uint32_t*)(P.activeCells + cellLocal);
+	const uint32_t cell = P.cellFirst + cellLocal * P.cellStride;
+	uint32_t cy = __umulhi(cell, P.magicCellsX);
+	uint32_t cx = cell - cy * P.cellsX;
+	while (cx >= P.cellsX) { cx -= P.cellsX; ++cy; }
+	j.x = cx * 8u + (lane & 7u); j.y = cy * 8u + (lane >> 3);
+	j.slot = cellLocal * 64u + lane;
 	j.sample = sLocal;
 	j.valid = (j.x < P.width) && (j.y < P.height);
 	return j;
@@ -1609,7 +1633,7 @@ k_trace(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB*
 				bool survive = false;
 				V3 qo = v3s(0.0f), qd = v3s(0.0f); Rng qg; qg.s.state = 0; uint32_t qOut = 0;
 				if (lane < avail) {
-					const JobPixel j = DecodeJob(P, chunkNext + lane);
+					const JobPixel j = DecodeJobBatch(P, chunkNext, lane);
 					if (j.valid) {
 						// GenerateCell body, reference render/renderer.cc:232-239
 						const uint32_t sm_ = P.sampleBegin + j.sample;
@@ -2559,6 +2583,10 @@ k_resolve(const DRenderParams P, const SampleRGB* __restrict__ samples, float4* 
 	float4 a = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
 	if (valid) {
 		if (!firstBatch) a = accum[slot];
+		if (P.cellEmpty && P.cellEmpty[cellLocal]) {
+			// a cell outside the scene's silhouette: every sample is the miss shader's constant, added up sample by sample as if it had been stored
+			for (uint32_t s = 0; s < P.sampleCount; ++s) { a.x += P.emptyL[0]; a.y += P.emptyL[1]; a.z += P.emptyL[2]; }
+		} else
 		for (uint32_t s = 0; s < P.sampleCount; ++s) {
 			const SampleRGB v = samples[(size_t)s * numSlots + slot];
 			a.x += v.x; a.y += v.y; a.z += v.z;

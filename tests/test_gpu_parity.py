@@ -314,6 +314,48 @@ def test_triangles_too_small_or_too_large_for_the_short_barycentric_form(gpu_lib
         ses.close()
 
 
+def test_cells_outside_the_scenes_silhouette_are_not_traced_and_nothing_changes(gpu_lib, workdir, oracle, monkeypatch):
+    """With a pinhole camera and no sky panorama, cells whose pixels (jitter and margin included) lie outside the projected bounding box of the scene are
+    dropped from the megakernel's job list; k_resolve adds up the miss shader's constant for them (csrc/rl_runtime.inl CullCells).  The frame and the
+    counters must be what they are with every cell traced (RAYLIB_CULL_CELLS=0) -- cameras far away (most cells dropped), close, inside the box's slab
+    (nothing can be dropped), off-axis, with and without a sun -- and the oracle's on a window that straddles the silhouette."""
+    from raylib_amd import binding
+    obj, c = helpers.build_case("cornell", workdir)
+    _, _, flat = helpers.flat_for_case("cornell", workdir, oracle)
+    views = [((0.0, 1.0, 4.0), (0.0, 1.0, -1.0), 45.0), ((0.0, 1.0, 14.0), (0.0, 1.0, -1.0), 45.0), ((3.5, 2.5, 6.0), (0.0, 1.0, 0.0), 30.0),
+             ((0.0, 1.0, 0.5), (0.0, 1.0, -1.0), 70.0), ((-6.0, 0.3, 0.0), (0.0, 1.0, 0.0), 25.0), ((0.0, 9.0, 0.01), (0.0, 0.0, 0.0), 40.0)]
+    dropped_somewhere = 0
+    for sun, sun_dir in (((0.0, 0.0, 0.0), (0.0, -1.0, -0.5)), ((9.0, 8.0, 7.0), (-1.0, -1.0, 0.0)), ((5.0, 5.0, 5.0), (0.0, -1.0, -0.9))):
+        for (origin, look, fov) in views:
+            ses = binding.SceneSession(gpu_lib, obj, origin, look, fov, 200 / 120, sun=sun, sun_dir=sun_dir)
+            for (w, h, spp) in ((200, 120, 3), (67, 41, 1)):
+                img = ses.render(w, h, spp)
+                st1 = ses.stats().as_dict()
+                monkeypatch.setenv("RAYLIB_CULL_CELLS", "0")
+                ref = ses.render(w, h, spp)
+                st0 = ses.stats().as_dict()
+                monkeypatch.delenv("RAYLIB_CULL_CELLS")
+                assert np.array_equal(bits(img), bits(ref)), (origin, sun, w, h)
+                for k in ("rays", "cameraSamples", "shadedHits", "nodesVisited", "trisTested", "pixels"):
+                    assert st0[k] == st1[k], (k, st0[k], st1[k], origin, sun)
+                assert st1["cameraSamples"] == w * h * spp
+            # which frames actually dropped cells: the megakernel's trip count falls with the job list
+            dropped_somewhere += int(st1["waveTrips"] < st0["waveTrips"])
+            ses.close()
+    assert dropped_somewhere >= 3, dropped_somewhere
+    # the oracle on the far view: a window across the box's left edge
+    ses = binding.SceneSession(gpu_lib, obj, (0.0, 1.0, 14.0), (0.0, 1.0, -1.0), 45.0, 200 / 120, sun=(9.0, 8.0, 7.0), sun_dir=(-1.0, -1.0, 0.0))
+    img = ses.render(200, 120, 2)
+    flat.sun_illuminance = (9.0, 8.0, 7.0); flat.sun_direction = (-1.0, -1.0, 0.0)
+    scene = oracle.scene_create(flat, 1)
+    cam = ffi.make_camera((0.0, 1.0, 14.0), (0.0, 1.0, -1.0), 45.0, 200 / 120)
+    same, tied, untied, err = window_mismatches_without_a_tie(oracle, scene, cam, ffi.make_settings(200, 120, 2), img, 72, 32, 56)   # the whole silhouette and its surroundings
+    print("far view with a sun: %d of %d window pixels bit-equal to the oracle, %d tie pixels" % (same, 56 * 56, tied))
+    assert untied == 0 and same + tied == 56 * 56 and tied <= 8, (same, tied, untied, err)
+    oracle.scene_destroy(scene)
+    ses.close()
+
+
 def test_sample_zero_is_unjittered_and_matches_per_sample_golden(sessions):
     g = golden("cornell")
     img = sessions["cornell"].render(64, 64, 1)

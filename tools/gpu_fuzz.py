@@ -11,7 +11,8 @@ d = tempfile.mkdtemp()
 MODES = [dict(RAYLIB_POOL="0"), dict(), dict(RAYLIB_BVH4="0"), dict(RAYLIB_POOL_SHORT_STACK="0"), dict(RAYLIB_BVH4="0", RAYLIB_POOL_SHORT_STACK="4"),
          dict(RAYLIB_POOL="3", RAYLIB_BVH4="0"), dict(RAYLIB_POOL="2", RAYLIB_SAMPLE_BATCH="1"),
          dict(RAYLIB_POOL="0", RAYLIB_LEAF_LIST="0"), dict(RAYLIB_POOL="0", RAYLIB_LDS_SCENE="0"),
-         dict(RAYLIB_JOB_HEADS="1"), dict(RAYLIB_POOL="0", RAYLIB_JOB_HEADS="3", RAYLIB_JOB_CHUNK="64")]   # round 3: one head; three heads with the smallest chunks (every wave steals)
+         dict(RAYLIB_JOB_HEADS="1"), dict(RAYLIB_POOL="0", RAYLIB_JOB_HEADS="3", RAYLIB_JOB_CHUNK="64"),
+         dict(RAYLIB_CULL_CELLS="0")]   # round 3: one head; three heads with the smallest chunks (every wave steals)
 if os.environ.get("FUZZ_MODES_JSON"): import json; MODES = json.loads(os.environ["FUZZ_MODES_JSON"])   # debugging: the schedules to run, e.g. '[{"RAYLIB_POOL": "0"}]'
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 bad = 0
