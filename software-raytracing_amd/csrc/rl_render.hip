@@ -637,21 +637,11 @@ __device__ __forceinline__ uint4 GLoadU4(const void* p, int i) { const rl_v4u v 
 // same reason every widened box test here is: an accepted hit has t * RL_CANDIDATE_SLACK >= the entry into its triangle's own box (OwnBoxPass),
 // which lies inside the leaf's box, and RL_BOX_WIDEN exceeds RL_CANDIDATE_SLACK by 1e-6 -- four times the rounding of either side.
 // Measured on the Cornell frame: DESIGN.md section 2.
-// DEFER (closest hit only): the candidate rule -- the ray passes the triangle's own box, OwnBoxPass, ~35 instructions -- is not applied to every candidate
-// that passes the barycentric test (five wave steps per bounce reach it, each with a handful of lanes) but ONCE, to the winner.  The search then finds
-// the nearest of a LARGER set (candidates that pass the triangle test) -- a cut on one of their distances cannot hide a nearer one --, and if that
-// winner also passes the rule it is the nearest of the smaller set too, tie rule included: the same hit.  If it does not (a hit on a sliver's rim, outside
-// the triangle's own box: 0 of the fuzz's 10^9 rays) the lane asks the walk that applies the rule to every candidate, out of line
-// (LeafListExact).  RL_LL_FORCE_EXACT=1 sends every hit there (test builds: the out-of-line walk must give the same frame).
-#ifndef RL_LL_DEFER_OWNBOX
-#define RL_LL_DEFER_OWNBOX 1
-#endif
-#ifndef RL_LL_FORCE_EXACT
-#define RL_LL_FORCE_EXACT 0
-#endif
-__device__ __noinline__ float4 LeafListExact(float ox, float oy, float oz, float dx, float dy, float dz, float tMin, const float4* sm, int numLeafRecords, int fastBary,
-                                             const DTriShade* shade, const DMaterial* materials, const DTexture* textures, const float* texels);
-template <bool ANYHIT, bool DEFER = false>
+// (Round 3, measured and not kept: the candidate rule applied once, to the winner of the search, instead of to every candidate that passes the barycentric
+// test, with an out-of-line walk that applies it per candidate for the lane whose winner fails it.  Sound -- the search finds the nearest of a larger set, and
+// a winner that passes the rule is the nearest of the smaller one too -- and 0.5 % faster, but the call made the register allocator keep the 24 keys in
+// scratch memory: 28 GB of spill traffic per frame, three times everything else the kernel moves.)
+template <bool ANYHIT>
 __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d, float tMin, HitRec& best, Counters& c, const float4* sm)
 {
 	c.rays++;
@@ -753,7 +743,7 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const V3 w = p - T.v0;
 			const float wv = dot(w, T.v), wu = dot(w, T.u);
 			float pa, pb;
-			if (Barycentric(S.fastBary != 0, T.uv * wv - T.vv * wu, T.uv * wu - T.uu * wv, T.denom, T.rden, pa, pb) && (DEFER || OwnBoxPassMnMx(tr, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t))) {
+			if (Barycentric(S.fastBary != 0, T.uv * wv - T.vv * wu, T.uv * wu - T.uu * wv, T.denom, T.rden, pa, pb) && OwnBoxPassMnMx(tr, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
 				if (alpha && !AlphaTestCandidate(S, first + i, pa, pb, c)) continue;
 				best.t = t; best.a = pa; best.b = pb; best.tri = first + i;
 				if (ANYHIT) return true;
@@ -763,23 +753,7 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 		#pragma unroll
 		for (int j = 0; j < 4 * RL_LEAFLIST_RECORDS; ++j) m = min(m, key[j] - from);
 	}
-	if (DEFER && !ANYHIT && best.tri >= 0) {
-		if (RL_LL_FORCE_EXACT || !OwnBoxPassMnMx(sm + LdsAt<2>::ISECT + best.tri * 6, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, best.t)) {
-			const float4 r = LeafListExact(o.x, o.y, o.z, d.x, d.y, d.z, tMin, sm, S.numLeafRecords, S.fastBary, S.shade, S.materials, S.textures, S.texels);
-			best.t = r.x; best.a = r.y; best.b = r.z; best.tri = __float_as_int(r.w);
-		}
-	}
 	return best.tri >= 0;
-}
-__device__ __noinline__ float4 LeafListExact(float ox, float oy, float oz, float dx, float dy, float dz, float tMin, const float4* sm, int numLeafRecords, int fastBary,
-                                             const DTriShade* shade, const DMaterial* materials, const DTexture* textures, const float* texels)
-{
-	DSceneView S; memset(&S, 0, sizeof(S));
-	S.numLeafRecords = numLeafRecords; S.fastBary = fastBary; S.shade = shade; S.materials = materials; S.textures = textures; S.texels = texels;
-	Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);   // (the walk that asked has counted this ray)
-	HitRec best;
-	TraverseLeafList<false, false>(S, v3(ox, oy, oz), v3(dx, dy, dz), tMin, best, c, sm);
-	return make_float4(best.t, best.a, best.b, __int_as_float(best.tri));
 }
 
 // The same closest-hit search on the BVH4 (DNode4): four slab tests per step, hit children ordered by entry distance.
@@ -787,7 +761,7 @@ __device__ __noinline__ float4 LeafListExact(float ox, float oy, float oz, float
 template <int STACK, bool ANYHIT, bool PRIMS, bool FULL, int LDS = 0>
 __device__ __forceinline__ bool Traverse4(const DSceneView& S, V3 o, V3 d, float rayTime, float tMin, HitRec& best, int* stk, Counters& c, const float4* sm = nullptr)
 {
-	if constexpr (LDS == 2) return TraverseLeafList<ANYHIT, !ANYHIT && RL_LL_DEFER_OWNBOX>(S, o, d, tMin, best, c, sm);
+	if constexpr (LDS == 2) return TraverseLeafList<ANYHIT>(S, o, d, tMin, best, c, sm);
 	c.rays++;
 	V3 invb = v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z));   // for the box tests (the candidate rule divides again: exact, and rare)
 	if (!FULL) invb = ClampInv(invb);

@@ -13,6 +13,8 @@ cp $SRC/static_mix.json profiles/${TAG}_static_mix.json
 cp $SRC/pmc_traffic.json profiles/pmc_traffic.json
 cp $SRC/valu_calib.json profiles/valu_calib.json
 [ -f gpurun_out/r3final/pytest_gpu_s.log ] && cp gpurun_out/r3final/pytest_gpu_s.log profiles/${TAG}_pytest_gpu.log
-[ -f gpurun_out/r3final/fuzz_2000x11.log ] && cp gpurun_out/r3final/fuzz_2000x11.log profiles/${TAG}_fuzz_2000x11.log
+[ -f gpurun_out/r3final/fuzz_2000x12.log ] && cp gpurun_out/r3final/fuzz_2000x12.log profiles/${TAG}_fuzz_2000x12.log
 [ -f gpurun_out/r3final/scenes.log ] && cp gpurun_out/r3final/scenes.log profiles/${TAG}_scenes.log
 ls -la profiles | grep ${TAG}
+[ -f gpurun_out/r3final/verify_fastdiv.txt ] && cp gpurun_out/r3final/verify_fastdiv.txt profiles/${TAG}_verify_fastdiv.txt
+[ -f gpurun_out/r3final/verify_fastmath.txt ] && cp gpurun_out/r3final/verify_fastmath.txt profiles/${TAG}_verify_fastmath.txt
