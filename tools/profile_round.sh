@@ -12,7 +12,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv
 python3 /root/repo/tools/valu_calib_pmc.py $OUT/calib_pmc /root/repo/profiles/valu_calib.json > $OUT/valu_calib.txt 2>&1
 cp /root/repo/profiles/valu_calib.json $OUT/valu_calib.json
 for WL in cornell_1080p_64spp breakfast_300k_1080p_128spp; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/stats_$WL.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -- python3 /root/repo/bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-extra --workload $WL > $OUT/stats_$WL.log 2>&1
   /root/repo/tools/pmc_profile.sh $WL $OUT/pmc_$WL > $OUT/pmc_$WL.log 2>&1
   python3 /root/repo/tools/pmc_summarize.py $OUT/pmc_$WL > $OUT/pmc_$WL.txt 2>&1
 done
