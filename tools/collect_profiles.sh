@@ -5,7 +5,7 @@ SRC=gpurun_out/round_$TAG
 cp $SRC/bench_default.json profiles/${TAG}_bench_default.json
 cp $SRC/bench_breakfast_300k_1080p_128spp.json profiles/${TAG}_bench_breakfast_300k_1080p_128spp.json
 for WL in cornell_1080p_64spp breakfast_300k_1080p_128spp; do
-  cp $(ls $SRC/stats_$WL/*/*kernel_stats.csv | head -1) profiles/${TAG}_kernel_stats_$WL.csv
+  cp $(ls -t $SRC/stats_$WL/*/*kernel_stats.csv | head -1) profiles/${TAG}_kernel_stats_$WL.csv
   cp $SRC/pmc_$WL.txt profiles/${TAG}_pmc_$WL.txt
 done
 cp $SRC/valu_calib.txt profiles/${TAG}_valu_calib.txt
