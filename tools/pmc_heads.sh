@@ -7,8 +7,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for H in 1 8; do
   export RAYLIB_JOB_HEADS=$H
-  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/h$H/tcc -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/h${H}_tcc.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/h$H/fetch -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/h${H}_fetch.log 2>&1
-  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/h$H/sq -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/h${H}_sq.log 2>&1
+  timeout 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/h$H/tcc -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/h${H}_tcc.log 2>&1
+  timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/h$H/fetch -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/h${H}_fetch.log 2>&1
+  timeout 240 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/h$H/sq -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/h${H}_sq.log 2>&1
   echo "== heads $H"; python3 /root/repo/tools/pmc_summarize.py $OUT/h$H | awk '/k_trace/{p=1} /k_resolve/{p=0} p'
 done

@@ -1,12 +1,13 @@
 #!/bin/bash
 # PMC passes for the dominant kernel (k_trace).  Separate passes: FETCH_SIZE takes 3 of the 4 TCC
 # slots and WRITE_SIZE 2 (MI355X_MICROARCH.md, rocprofv3 PMC slots).  No tracing domains are combined
-# with --pmc.  Usage: tools/pmc_profile.sh <workload> <outdir>
+# with --pmc, and every pass runs under `timeout`: asked for FETCH_SIZE and WRITE_SIZE in ONE pass rocprofv3 aborts ("exceeds the capabilities of the
+# hardware") and then sits in its signal handler until it is killed -- 50 GPU-minutes of round 3 went that way.  Usage: tools/pmc_profile.sh <workload> <outdir>
 WL=${1:-cornell_1080p_64spp}
 OUT=${2:-/root/repo/gpurun_out/pmc_$WL}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/$name.log 2>&1; }
+run() { name=$1; shift; timeout 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --workload $WL > $OUT/$name.log 2>&1; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY

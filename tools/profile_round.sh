@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, in one call on the GPU box (about 6 minutes):
-#   VALU issue costs (tools/valu_calib under rocprofv3 --pmc), bench JSON lines, rocprofv3 --kernel-trace --stats summaries,
+#   VALU issue costs (tools/valu_calib under timeout 240 rocprofv3 --pmc), bench JSON lines, timeout 240 rocprofv3 --kernel-trace --stats summaries,
 #   PMC passes (separate --pmc runs, no trace domains), the derived figures (tools/pmc_traffic.py) and the bench lines that replay them.
 # usage: tools/profile_round.sh <round tag, e.g. r03>      (then copy gpurun_out/round_<tag>/... into profiles/, see profiles/README.md)
 TAG=${1:-r03}
@@ -8,11 +8,11 @@ OUT=/root/repo/gpurun_out/round_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # issue cycles per wave64 VALU instruction, by opcode, in counted cycles
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $OUT/calib_pmc -- /root/repo/tools/valu_calib > $OUT/valu_calib_timing.log 2>&1
+timeout 240 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $OUT/calib_pmc -- /root/repo/tools/valu_calib > $OUT/valu_calib_timing.log 2>&1
 python3 /root/repo/tools/valu_calib_pmc.py $OUT/calib_pmc /root/repo/profiles/valu_calib.json > $OUT/valu_calib.txt 2>&1
 cp /root/repo/profiles/valu_calib.json $OUT/valu_calib.json
 for WL in cornell_1080p_64spp breakfast_300k_1080p_128spp; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -- python3 /root/repo/bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-extra --workload $WL > $OUT/stats_$WL.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -- python3 /root/repo/bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-extra --workload $WL > $OUT/stats_$WL.log 2>&1
   /root/repo/tools/pmc_profile.sh $WL $OUT/pmc_$WL > $OUT/pmc_$WL.log 2>&1
   python3 /root/repo/tools/pmc_summarize.py $OUT/pmc_$WL > $OUT/pmc_$WL.txt 2>&1
 done
