@@ -1260,11 +1260,6 @@ __device__ __forceinline__ V3 MissShader(const DSceneView& S, const SkyRot& R, V
 	return missResult;
 }
 
-// The path stack: vertex k of column c is two float4 records (reflectance, sp | pdf, emitted), each in a plane of its own -- [level][half][column] -- so that
-// a wave's store (or load) of either half is 64 x 16 contiguous bytes, whole lines, instead of every other 16 bytes of twice as many lines (the two halves
-// of one 32-byte record arrive in separate instructions, and a line written in parts can be written back in parts: WRITE_SIZE was twice the stored bytes).
-__device__ __forceinline__ size_t StackAt(uint32_t stackStride, int k, uint32_t col, int half) { return ((size_t)(2 * k + half)) * stackStride + col; }
-
 // one path's radiance in the sample buffer: 12 bytes (the buffer is written once and read once per sample: a fourth float would be a quarter more of both)
 struct SampleRGB { float x, y, z; };
 __device__ __forceinline__ SampleRGB make_sample(float x, float y, float z) { SampleRGB s; s.x = x; s.y = y; s.z = z; return s; }
@@ -1798,8 +1793,8 @@ k_trace(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB*
 					#pragma unroll
 					for (int k = 0; k < RL_FOLD_PREFETCH; ++k) {
 						const int kk = k < depth ? k : 0;
-						const float4* st0 = (const float4*)pathStack + StackAt(P.stackStride, kk, gtid, 0); const float4* st1 = (const float4*)pathStack + StackAt(P.stackStride, kk, gtid, 1);
-						q0[k] = *st0; q1[k] = *st1;
+						const float4* st = (const float4*)pathStack + ((size_t)kk * P.stackStride + gtid) * 2u;
+						q0[k] = st[0]; q1[k] = st[1];
 					}
 					#pragma unroll
 					for (int k = RL_FOLD_PREFETCH - 1; k >= 0; --k) {
@@ -1816,8 +1811,8 @@ k_trace(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB*
 				} else
 #endif
 				for (int k = depth - 1; k >= 0; --k) {
-					const float4* st0 = (const float4*)pathStack + StackAt(P.stackStride, k, gtid, 0); const float4* st1 = (const float4*)pathStack + StackAt(P.stackStride, k, gtid, 1);
-					const float4 r0 = *st0, r1 = *st1;
+					const float4* st = (const float4*)pathStack + ((size_t)k * P.stackStride + gtid) * 2u;
+					const float4 r0 = st[0], r1 = st[1];
 					const V3 refl = v3(r0.x, r0.y, r0.z);
 					const float sp = r0.w, pdf = r1.x;
 					const V3 E = v3(r1.y, r1.z, r1.w);
@@ -1832,9 +1827,11 @@ k_trace(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB*
 			}
 			if (store) {
 				RL_ARGS();
-				// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
-				float4* st0 = (float4*)pathStack + StackAt(P.stackStride, depth, gtid, 0); float4* st1 = (float4*)pathStack + StackAt(P.stackStride, depth, gtid, 1);
-				*st0 = rec0; *st1 = rec1;
+				// path vertex record: 32 contiguous bytes per lane, two 16-byte stores.  (Round 3, measured and not kept: the two halves in planes of their own, so
+				// that a full wave's store of either is whole lines -- with the lanes that store being a sparse subset, two half-records in two lines move more than
+				// one record in one: WRITE_SIZE 10.5 -> 13.2 GB and FETCH_SIZE 2.7 -> 6.7 GB per Cornell frame, TCC hit rate 0.91 -> 0.80, same time.)
+				float4* st = (float4*)pathStack + ((size_t)depth * P.stackStride + gtid) * 2u;
+				st[0] = rec0; st[1] = rec1;
 				depth++;
 			}
 		}
@@ -2070,8 +2067,8 @@ __device__ __forceinline__ V3 FoldPath(const float* __restrict__ pathStack, uint
 		#pragma unroll
 		for (int k = 0; k < RL_FOLD_PREFETCH_POOL; ++k) {
 			const int kk = k < depth ? k : 0;
-			const float4* rec0 = (const float4*)pathStack + StackAt(stackStride, kk, home, 0); const float4* rec1 = (const float4*)pathStack + StackAt(stackStride, kk, home, 1);
-			q0[k] = *rec0; q1[k] = *rec1;
+			const float4* rec = (const float4*)pathStack + ((size_t)kk * stackStride + home) * 2u;
+			q0[k] = rec[0]; q1[k] = rec[1];
 		}
 		#pragma unroll
 		for (int k = RL_FOLD_PREFETCH_POOL - 1; k >= 0; --k) {
@@ -2089,8 +2086,8 @@ __device__ __forceinline__ V3 FoldPath(const float* __restrict__ pathStack, uint
 	}
 #endif
 	for (int k = depth - 1; k >= 0; --k) {
-		const float4* rec0 = (const float4*)pathStack + StackAt(stackStride, k, home, 0); const float4* rec1 = (const float4*)pathStack + StackAt(stackStride, k, home, 1);
-		const float4 r0 = *rec0, r1 = *rec1;
+		const float4* rec = (const float4*)pathStack + ((size_t)k * stackStride + home) * 2u;
+		const float4 r0 = rec[0], r1 = rec[1];
 		const V3 refl = v3(r0.x, r0.y, r0.z);
 		const float sp = r0.w, pdf = r1.x;
 		const V3 E = v3(r1.y, r1.z, r1.w);
@@ -2480,9 +2477,9 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 				bool done = false;
 				V3 L = v3s(0.0f);
 				if (scattered && pdf > 0.0f) {
-					float4* rec0 = (float4*)pathStack + StackAt(P.stackStride, depth, home, 0); float4* rec1 = (float4*)pathStack + StackAt(P.stackStride, depth, home, 1);
-					*rec0 = make_float4(refl.x, refl.y, refl.z, sp);
-					*rec1 = make_float4(pdf, E.x, E.y, E.z);
+					float4* rec = (float4*)pathStack + ((size_t)depth * P.stackStride + home) * 2u;
+					rec[0] = make_float4(refl.x, refl.y, refl.z, sp);
+					rec[1] = make_float4(pdf, E.x, E.y, E.z);
 					depth++;
 					if (depth >= P.maxPathLength) done = true;   // the next TraceScene returns 0 at once (renderer.cc:120-123)
 					else {
