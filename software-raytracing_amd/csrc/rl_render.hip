@@ -1827,9 +1827,7 @@ k_trace(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB*
 			}
 			if (store) {
 				RL_ARGS();
-				// path vertex record: 32 contiguous bytes per lane, two 16-byte stores.  (Round 3, measured and not kept: the two halves in planes of their own, so
-				// that a full wave's store of either is whole lines -- with the lanes that store being a sparse subset, two half-records in two lines move more than
-				// one record in one: WRITE_SIZE 10.5 -> 13.2 GB and FETCH_SIZE 2.7 -> 6.7 GB per Cornell frame, TCC hit rate 0.91 -> 0.80, same time.)
+				// path vertex record: 32 contiguous bytes per lane, two 16-byte stores
 				float4* st = (float4*)pathStack + ((size_t)depth * P.stackStride + gtid) * 2u;
 				st[0] = rec0; st[1] = rec1;
 				depth++;
