@@ -50,8 +50,15 @@ __device__ __forceinline__ void sincos_signs_(float x, bool* sn, bool* cn) { *sn
 #endif
 RL_MATH_CALL float sin_(float x)  { return rlm::sinf_(x); }
 RL_MATH_CALL float cos_(float x)  { return rlm::cosf_(x); }
+#ifdef RL_MATH_INLINE_TAN
+__device__ __forceinline__ float tan_(float x)  { return rlm::tanf_(x); }
+#else
 RL_MATH_CALL float tan_(float x)  { return rlm::tanf_(x); }
-#ifdef RL_MATH_INLINE_ACOS
+#endif
+#ifndef RL_MATH_INLINE_ACOS
+#define RL_MATH_INLINE_ACOS 1   /* round 3, with Erf / ErfInv: rl_render.hip */
+#endif
+#if RL_MATH_INLINE_ACOS
 __device__ __forceinline__ float acos_(float x) { return rlm::acosf_(x); }
 #else
 RL_MATH_CALL float acos_(float x) { return rlm::acosf_(x); }

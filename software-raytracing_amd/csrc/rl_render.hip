@@ -882,11 +882,14 @@ __device__ __forceinline__ V3 WorldToLocal(const Surf& s, V3 v) { return v3(dot(
 // ---- microfacet BRDF pieces (reference render/brdf.h, render/material.cc:16-190) ----
 __device__ __forceinline__ float Clampf(float val, float lo, float hi) { return fmaxf(lo, fminf(hi, val)); }
 
+// (Inline since the end of round 3: as calls they measured better in round 2 (ErfInv / Erf inline 20.25 ms against 19.9), when the kernel had 400 SGPR reloads
+//  to place around every call; with the arguments re-read per part of the loop, ErfInv + Erf + acosf inline are 12.26 ms against 12.45, 36.9 against 37.2 ms
+//  on the 298 k frame.  powf stays a call: inline 12.65.)
 #ifndef RL_ERFINV_ATTR
-#define RL_ERFINV_ATTR __noinline__
+#define RL_ERFINV_ATTR __forceinline__
 #endif
 #ifndef RL_ERF_ATTR
-#define RL_ERF_ATTR __noinline__
+#define RL_ERF_ATTR __forceinline__
 #endif
 __device__ RL_ERFINV_ATTR float ErfInv(float x)
 {
