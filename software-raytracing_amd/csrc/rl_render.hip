@@ -1896,7 +1896,12 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #endif
 #ifndef RL_POOL_WNODE4
 #define RL_POOL_WNODE4 4  /* the same for a BVH4 step */
-#define RL_POOL_WLEAF4 5
+#endif
+#ifndef RL_POOL_WLEAF4
+// Re-tuned at the end of round 3 (the leaf step is a third cheaper than it was -- two divisions gone, the own-box rule on v_max / v_min -- but above all the lanes at
+// leaves are the ones about to FINISH: serving them first frees lanes for the next fetch).  298 k frame / colonnade / 2.36 M triangles at 4K, ms: 5 -> 36.85 / 373.7 /
+// 114.2; 7 -> 36.0 / 372.9 / --; 8 -> 35.87 / 374.1 / 109.9; 10 -> 35.64 / 377.4 / 108.5; 12 -> 35.6 / -- / --; 16 -> 35.85 / 390.4 / 107.5.
+#define RL_POOL_WLEAF4 8
 #endif
 #ifndef RL_POOL_KEEP
 #define RL_POOL_KEEP 58   /* leave the traversal loop to fetch new rays when no more than this many lanes still traverse */
