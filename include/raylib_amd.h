@@ -131,6 +131,14 @@ RAYLIB_API int32_t RaylibAMD_EvalTexture(SceneHandle scene, int32_t texture, int
  * part), 11 sqrtf, 12 x / y, 13 fmodf(x, 1).  y may be NULL for one-argument functions. */
 RAYLIB_API int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int32_t n, float* out);
 
+/* Test hook (host only, no device needed): which 8 x 8 cells of a width x height frame can no ray of the camera -- pinhole, no sky panorama -- meet the box
+ * bounds = { min x, y, z, max x, y, z } in?  The renderer leaves those cells out of the megakernel's job list and fills them with the miss shader's
+ * constant (csrc/rl_cull.cc).  outEmpty: one byte per cell, row-major, 1 = dropped; outConstant: the constant (the sun's illuminance, or nothing).
+ * The sun direction is the normalised one the scene holds.  Returns the number of dropped cells, 0 when none can be dropped, -1 when the frame is not
+ * eligible (a lens, a corner of the box beside or behind the camera, a sun ray from the camera that may meet the box). */
+RAYLIB_API int32_t RaylibAMD_CullCells(CameraHandle camera, const float* bounds, const float* sunIlluminance, const float* sunDirection,
+                                       int32_t width, int32_t height, uint8_t* outEmpty, float* outConstant);
+
 /* Test hook: the device's short exact sequences for 1.0f / x (which = 0) and sqrtf(x) (which = 1) -- csrc/rl_glibc_math.h rcp1_ / sqrtf_, used by
  * normalize and every reciprocal of the shading code -- against the compiler's IEEE expansions on ALL 2^32 float bit patterns, on the device.
  * which = 2: a / b with the divisor's correctly rounded reciprocal in hand (csrc/rl_math.h div_by_: the pixel -> [0, 1) divisions of a camera ray and the two

@@ -440,6 +440,28 @@ int32_t RaylibAMD_EvalCameraRays(CameraHandle ch, const float* uv, int32_t n, ui
 	const DCamera d = c->ToDevice();
 	return DeviceEvalHook(1, nullptr, &d, 0, 0, uv, n, seed, out) ? 1 : 0;
 }
+int32_t RaylibAMD_CullCells(CameraHandle ch, const float* bounds, const float* sunIlluminance, const float* sunDirection, int32_t width, int32_t height,
+                            uint8_t* outEmpty, float* outConstant)
+{
+	Camera* c = (Camera*)ch;
+	if (!c || !bounds || width <= 0 || height <= 0) return -1;
+	CullScene cs;
+	for (int k = 0; k < 3; ++k) { cs.boundsMin[k] = bounds[k]; cs.boundsMax[k] = bounds[3 + k]; }
+	cs.boundsValid = true;
+	if (sunIlluminance && sunDirection) {
+		for (int k = 0; k < 3; ++k) { cs.sunIlluminance[k] = sunIlluminance[k]; cs.sunDirection[k] = sunDirection[k]; }
+		cs.hasSun = !(sunIlluminance[0] == 0.0f && sunIlluminance[1] == 0.0f && sunIlluminance[2] == 0.0f);
+	}
+	const uint32_t W = (uint32_t)width, H = (uint32_t)height, cellsX = (W + 7) / 8, cellsY = (H + 7) / 8;
+	CullResult r;
+	if (!CullCells(cs, c->ToDevice(), 1, W, H, cellsX, 0, 1, cellsX * cellsY, r)) {
+		if (outEmpty) memset(outEmpty, 0, (size_t)cellsX * cellsY);
+		return r.empty.empty() ? -1 : 0;   // not eligible, or eligible with nothing to drop
+	}
+	if (outEmpty) memcpy(outEmpty, r.empty.data(), (size_t)cellsX * cellsY);
+	if (outConstant) { outConstant[0] = r.L[0]; outConstant[1] = r.L[1]; outConstant[2] = r.L[2]; }
+	return (int32_t)(cellsX * cellsY - (uint32_t)r.active.size());
+}
 int32_t RaylibAMD_EvalTexture(SceneHandle sh, int32_t texture, int32_t bSRGB, const float* uv, int32_t n, float* out)
 {
 	Scene* s = (Scene*)sh;

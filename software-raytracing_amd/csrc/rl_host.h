@@ -217,6 +217,11 @@ bool DevicePostProcess(Image& img);          // Image2D::PostProcess on the devi
 bool DeviceReadback(Image& img);            // device copy -> img.rgba (the caller checked hostStale)
 void* DeviceImagePixels(Image& img);          // (re)allocates img.devPixels for width*height float4; nullptr when no device
 void DeviceFreePixels(void* p);
+// cells outside the scene's silhouette (rl_cull.cc)
+struct CullScene { double boundsMin[3] = { 0, 0, 0 }, boundsMax[3] = { 0, 0, 0 }; bool boundsValid = false, prims = false, hasSky = false, hasSun = false; float sunDirection[3] = { 0, 0, 0 }, sunIlluminance[3] = { 0, 0, 0 }; };
+struct CullResult { std::vector<uint32_t> active; std::vector<unsigned char> empty; uint64_t emptyPixels = 0; float L[3] = { 0, 0, 0 }; uint32_t raysPerSample = 1; };
+bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, uint32_t W, uint32_t H,
+               uint32_t cellsX, uint32_t cellFirst, uint32_t stride, uint32_t numLocalCells, CullResult& out);
 bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out);
 bool DeviceVerifyExactMath(int which, uint64_t* outMismatches, uint64_t* outFirst);   // 0: rtm::rcp1_ vs 1.0f / x, 1: rtm::sqrt_ vs sqrtf, 2: rtm::div_by_ vs a / b, 3: Barycentric short vs divisions; all 2^32 inputs
 bool DeviceEvalHook(int kind, Scene* sc, const DCamera* cam, int a, int b, const float* in, int n, uint64_t seed, float* out);

@@ -109,6 +109,7 @@ _EXPORTS = {
     "RaylibAMD_EvalDeviceMath": (C.c_int32, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "RaylibAMD_ClosestHit": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.c_void_p]),
     "RaylibAMD_VerifyExactMath": (C.c_int32, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "RaylibAMD_CullCells": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_float)]),
     "RaylibAMD_SceneNumTriangles": (C.c_int32, [C.c_void_p]),
     "RaylibAMD_SceneNumMaterials": (C.c_int32, [C.c_void_p]),
     "RaylibAMD_SceneNumTextures": (C.c_int32, [C.c_void_p]),

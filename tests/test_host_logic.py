@@ -482,3 +482,75 @@ def test_null_arguments_are_survivable(lib):
         getattr(lib, name)(*args)
     for h, fn in ((img, lib.Raylib_DestroyImage), (sc, lib.Raylib_DestroyScene), (cam, lib.Raylib_DestroyCamera)):
         assert fn(h) == 1
+
+
+def test_cells_dropped_from_the_job_list_cannot_see_the_box(lib, oracle):
+    """csrc/rl_cull.cc: with a pinhole camera and no sky panorama the renderer leaves out of the megakernel's job list every 8 x 8 cell none of whose camera
+    rays can meet the scene's bounding box, and fills it with the miss shader's constant.  The decision is a rectangle on the image plane with a margin;
+    what must hold is the geometry: NO ray of a dropped cell -- any pixel of it, any jitter in (-1, 1) pixel -- meets the box.  Random cameras and boxes;
+    the rays are the oracle's (reference camera.h:44-53), the box test is exact arithmetic on them in float64."""
+    pass
+    rng = np.random.RandomState(11)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    dropped_cases = ineligible = 0
+    for case in range(60):
+        w, h = int(rng.randint(40, 400)), int(rng.randint(30, 300))
+        lo = rng.uniform(-2, 0, 3); hi = lo + rng.uniform(0.2, 3.0, 3)
+        centre = (lo + hi) / 2
+        dist = float(rng.uniform(0.5, 30.0))
+        direction = rng.normal(size=3); direction /= np.linalg.norm(direction)
+        origin = centre + direction * dist
+        look = centre + rng.normal(size=3) * float(rng.uniform(0.0, 1.5))
+        fov, aspect = float(rng.uniform(15, 90)), w / h
+        cam = lib.Raylib_CreateCamera()
+        lib.Raylib_CameraSetPosition(cam, *[float(x) for x in origin]); lib.Raylib_CameraSetLookAt(cam, *[float(x) for x in look])
+        lib.Raylib_CameraSetPerspective(cam, fov, aspect)
+        bounds = np.concatenate([lo, hi]).astype(np.float32)
+        cx, cy = (w + 7) // 8, (h + 7) // 8
+        empty = np.zeros(cx * cy, np.uint8)
+        const = np.zeros(3, np.float32)
+        n = lib.RaylibAMD_CullCells(cam, fp(bounds), None, None, w, h, empty.ctypes.data_as(C.POINTER(C.c_uint8)), fp(const))
+        lib.Raylib_DestroyCamera(cam)
+        inside = bool(np.all(origin > lo - 1e-3) and np.all(origin < hi + 1e-3))
+        if n < 0:
+            ineligible += 1
+            continue
+        assert not inside
+        assert n == int(empty.sum()) and (const == 0).all()
+        if n == 0:
+            continue
+        dropped_cases += 1
+        ocam = ffi.make_camera(tuple(float(x) for x in origin), tuple(float(x) for x in look), fov, aspect)
+        ys, xs = np.nonzero(empty.reshape(cy, cx))
+        uv = []
+        for (cyy, cxx) in zip(ys, xs):
+            # the cell's four corner pixels and its centre, each at the jitter's extremes and at none
+            for px in (8 * cxx, min(8 * cxx + 7, w - 1), 8 * cxx + 3):
+                for py in (8 * cyy, min(8 * cyy + 7, h - 1), 8 * cyy + 4):
+                    if px >= w or py >= h:
+                        continue
+                    for jx in (-0.999, 0.0, 0.999):
+                        for jy in (-0.999, 0.0, 0.999):
+                            uv.append(((px + jx) / w, (py + jy) / h))
+        uv = np.asarray(uv, np.float32)
+        rays = oracle.camera_rays(ocam, uv, seed=1)[:, :6].astype(np.float64)
+        o, d = rays[:, :3], rays[:, 3:]
+        blo, bhi = bounds[:3].astype(np.float64), bounds[3:].astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t0, t1 = (blo - o) / d, (bhi - o) / d
+        tn = np.nanmax(np.minimum(t0, t1), axis=1); tf = np.nanmin(np.maximum(t0, t1), axis=1)
+        hits = (tf >= np.maximum(tn, 0.0))
+        assert not hits.any(), "case %d: %d rays of dropped cells meet the box" % (case, hits.sum())
+    assert dropped_cases >= 20 and ineligible >= 1, (dropped_cases, ineligible)
+    # with a sun whose ray from the camera misses the box the constant is the sun's illuminance; when it may hit the box nothing is dropped
+    cam = lib.Raylib_CreateCamera()
+    lib.Raylib_CameraSetPosition(cam, 0.0, 1.0, 14.0); lib.Raylib_CameraSetLookAt(cam, 0.0, 1.0, -1.0); lib.Raylib_CameraSetPerspective(cam, 45.0, 200 / 120)
+    bounds = np.asarray([-1, 0, -1, 1, 2, 1], np.float32)
+    empty = np.zeros(25 * 15, np.uint8); const = np.zeros(3, np.float32)
+    sun = np.asarray([9, 8, 7], np.float32)
+    sdir = np.asarray([-1, -1, 0], np.float32) / np.float32(np.sqrt(2))
+    assert lib.RaylibAMD_CullCells(cam, fp(bounds), fp(sun), fp(sdir), 200, 120, empty.ctypes.data_as(C.POINTER(C.c_uint8)), fp(const)) > 100
+    assert (const == sun).all()
+    sdir = np.asarray([0, 0, 1], np.float32)      # the sun behind the box as seen from the camera: its ray runs through the box
+    assert lib.RaylibAMD_CullCells(cam, fp(bounds), fp(sun), fp(sdir), 200, 120, empty.ctypes.data_as(C.POINTER(C.c_uint8)), fp(const)) == -1
+    lib.Raylib_DestroyCamera(cam)
