@@ -671,8 +671,8 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 			const float4 nX = *(const float4*)(rec + oNX), fX = *(const float4*)(rec + oFX);
 			const float4 nY = *(const float4*)(rec + oNY), fY = *(const float4*)(rec + oFY);
 			const float4 nZ = *(const float4*)(rec + oNZ), fZ = *(const float4*)(rec + oFZ);
-			// (Round 3, measured and not kept: the same test in fewer issue cycles by the cost table of tools/valu_calib.hip -- entry = max(tMin, max3), exit = min3 without
-			// the clamp, culled <=> sign of fma(exit, widen, -entry) smeared into the key: 34 cycles per box for 44 on paper, 14.80 ms for 14.31 on the GPU, twice.)
+			// (This form -- 34 issue cycles per box for 46 by the cost table of tools/valu_calib.hip -- ran SLOWER twice in the first half of round 3, 14.80 ms for 14.31, while
+			// the kernel still parked its arguments in VGPR lanes; with those reloads gone (RL_ARGS) it is 13.25 ms for 13.52.)
 			// One box: six fma, max + max3, min3, and the key.  The exit needs no clamp to FLT_MAX (an axis without a constraint gives +inf or NaN, which min3 skips;
 			// "NaN * widen < tn" is false: the box counts as met), and the entry no clamp to 0: this kernel only runs with rayTMin >= 0 (rl_runtime.inl picks the
 			// tree walk otherwise), so tn >= tMin >= 0 is a sortable key as it is.  RL_LL_SMEAR: "culled" as the sign of fma(exit, widen, -entry) smeared over the key.
@@ -701,7 +701,8 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 	}
 	uint32_t from = 0u;   // keys below this one are done (keys are distinct: the slot is part of the key)
 	// (One triangle per turn of ONE loop -- a lane picks its next leaf while its neighbours test their next triangle -- was measured too: 9.8
-	// triangle steps per wave and bounce instead of 12 on 16 leaves, but 19.81 ms against 19.42: the pick costs more per turn than it saves.)
+	// triangle steps per wave and bounce instead of 12 on 16 leaves, but 19.81 ms against 19.42: the pick costs more per turn than it saves.  Again on the
+	// final kernel of round 3: 13.33 ms against 12.50.)
 #ifdef RL_WATCHDOG
 	int guardSel = 0;
 #endif
