@@ -43,12 +43,15 @@ WORKLOADS = {
     "cornell_1080p_64spp": dict(scene="cornell", kw={}, w=1920, h=1080, spp=64, max_path=5, camera="cornell"),
     # configs[2]-sized stress: a memory-bound megakernel (the pool schedule on 298 k triangles)
     "breakfast_300k_1080p_128spp": dict(scene="cornell", kw=dict(tess=91, displace_fraction=0.2), w=1920, h=1080, spp=128, max_path=5, camera="breakfast"),
+    # the same scene from INSIDE (what the named scenes are: interiors): every pixel looks at geometry, no cell can be dropped (round 4)
+    "breakfast_interior_300k_1080p_128spp": dict(scene="cornell", kw=dict(tess=91, displace_fraction=0.2), w=1920, h=1080, spp=128, max_path=5, camera="breakfast_interior"),
 }
 HEADLINE = "cornell_1080p_64spp"
 EXTRA = "breakfast_300k_1080p_128spp"
+EXTRA2 = "breakfast_interior_300k_1080p_128spp"
 
 
-def cpu_baseline(workload, cam, gpu_rays_per_sample):
+def cpu_baseline(workload, cam, ref_rays_per_sample, gpu_frame_s):
     """The reference's own CPU path (Renderer::RenderScene + its ThreadPool, built in place into
     oracle/_ref/libref_native.so) timed on this host's cores on a bounded sample of the same
     workload.  Falls back to the oracle restatement (kind "port") when the prebuilt binary is absent."""
@@ -79,11 +82,19 @@ def cpu_baseline(workload, cam, gpu_rays_per_sample):
         t0 = time.time(); orc.render(scene, camera, st, seed=1, threads=cores); dt = time.time() - t0
         kind = "port"
     samples = w * h * spp
-    return {"value": samples * gpu_rays_per_sample / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
+    cpu_frame_s = dt * workload["spp"] / spp
+    return {"value": samples * ref_rays_per_sample / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
             "seconds": dt, "camera_samples_per_s": samples / dt,
+            # what "x times the CPU" means here: the TIME of the same frame, CPU reference over GPU -- not a ratio of ray rates (the reference traces
+            # every camera sample of the frame, the GPU path leaves the cells outside the scene's silhouette out of its job list)
+            "frame_time_ratio_cpu_over_gpu": cpu_frame_s / gpu_frame_s if gpu_frame_s > 0 else None,
+            "cpu_frame_seconds_scaled_to_full_spp": cpu_frame_s,
             "sample": "%dx%d at %d spp of the same scene/camera (%.1f%% of the step's camera samples), all %d host threads; "
-                      "rays = camera samples x the GPU run's measured rays per camera sample (%.4f), since the reference has no ray counter"
-                      % (w, h, spp, 100.0 * spp / workload["spp"], cores, gpu_rays_per_sample)}
+                      "rays = camera samples x the reference-equivalent queries per camera sample (%.4f): the reference's TraceScene issues one accel->Hit per path "
+                      "segment and one per sun test for EVERY camera sample of the frame (renderer.cc:129,194), which is what the GPU path's counters come to "
+                      "over the whole frame -- executed queries plus the one root-box query (two with a sun) each sample of a dropped cell stands for; the "
+                      "reference itself has no ray counter"
+                      % (w, h, spp, 100.0 * spp / workload["spp"], cores, ref_rays_per_sample)}
 
 
 def golden_windows(workload_name, frame_hw):
@@ -208,12 +219,24 @@ def accumulate(acc, stats, binding):
     acc["kernel_ms"] += stats.kernelMs
     acc["bytes"] += binding.algorithmic_bytes(stats)
     acc["samples"] += stats.cameraSamples
+    acc["culled_rays"] += stats.culledRays; acc["culled_samples"] += stats.culledSamples; acc["culled_cells"] = stats.culledCells; acc["listed_cells"] = stats.listedCells
     acc["paths_per_wave"] = stats.pathsPerWave
     acc["job_heads"] = stats.jobHeads
 
 
 def new_acc():
-    return dict(rays=0, trace_ms=0.0, launches=0, bytes=0, samples=0, kernel_ms=0.0, paths_per_wave=64, job_heads=None)
+    return dict(rays=0, trace_ms=0.0, launches=0, bytes=0, samples=0, kernel_ms=0.0, paths_per_wave=64, job_heads=None,
+                culled_rays=0, culled_samples=0, culled_cells=0, listed_cells=0)
+
+
+def work_block(acc, steps):
+    """What one step consisted of: executed on the device (what `value` is made of) next to what the silhouette cull left out (csrc/rl_cull.cc)."""
+    k = max(1, steps)
+    return {"rays_executed_per_step": acc["rays"] / k, "camera_samples_executed_per_step": acc["samples"] / k,
+            "rays_accounted_not_traced_per_step": acc["culled_rays"] / k, "camera_samples_not_traced_per_step": acc["culled_samples"] / k,
+            "cells_culled": acc["culled_cells"], "cells_listed": acc["listed_cells"],
+            "definition": "a ray = one closest-hit or occlusion query EXECUTED by a kernel (reference renderer.cc:129,194); `value` counts only those. "
+                          "Samples of cells outside the scene's silhouette are neither generated nor traced: k_resolve writes the miss shader's constant for them"}
 
 
 def library_run(lib, binding, scenes, workload_name, steps, warmup, n_gpus, rank_tag="0", want_device_entry=True):
@@ -370,7 +393,8 @@ def main():
         "config": {"workload": args.workload, "mode": "library (Raylib_Render; RAYLIB_NUM_GPUS=%d)" % n, "scene_triangles": r["ntris"],
                    "width": wl["w"], "height": wl["h"], "spp": wl["spp"], "max_path_length": wl["max_path"], "seed": 1,
                    "tiling": "8x8 cells round-robin over %d rank(s)" % ranks, "rays_per_step": acc["rays"] / args.steps,
-                   "camera_samples_per_step": acc["samples"] / args.steps, "frame_check": r["frame_check"], "boundary": r["boundary"],
+                   "camera_samples_per_step": acc["samples"] / args.steps, "work": work_block(acc, args.steps),
+                   "frame_check": r["frame_check"], "boundary": r["boundary"],
                    "build_id": build_id, "timed_region_s": elapsed},
         "roofline": roofline_block(args.workload, acc, ranks, build_id, r["tree_walk"]),
     }
@@ -380,16 +404,18 @@ def main():
                             "gather_ms": s["gatherMs"], "scatter_ms": s["scatterMs"], "rank_kernel_ms": s["rankKernelMs"], "rank_trace_ms": s["rankTraceMs"],
                             "note": "last timed frame; gather_ms = rank 0's stream from the end of its own kernels until every rank's cells are on its device"}
     if ranks == 1 and not args.no_extra and args.workload == HEADLINE:
-        # a second object in the same invocation: the configs[2]-sized scene, whose megakernel (the pool schedule) waits on memory
+        # further objects in the same invocation: the configs[2]-sized scene, whose megakernel (the pool schedule) waits on memory -- seen from outside
+        # (SURVEY 8d's stand-in camera: 89 % of that frame is empty sky and is not traced) and from INSIDE (every pixel is geometry, nothing is dropped)
         k = max(3, min(20, args.steps // 5))
-        e = library_run(lib, binding, scenes, EXTRA, k, 1, 1, rank_tag="x", want_device_entry=False)
-        ea = e["acc"]
-        out["extra"] = {"workload": EXTRA, "value": ea["rays"] / e["elapsed"] / 1e6, "unit": "Mrays/s", "steps": k, "warmup": 1,
+        for key, name in (("extra", EXTRA), ("extra_interior", EXTRA2)):
+            e = library_run(lib, binding, scenes, name, k, 1, 1, rank_tag="x", want_device_entry=False)
+            ea = e["acc"]
+            out[key] = {"workload": name, "value": ea["rays"] / e["elapsed"] / 1e6, "unit": "Mrays/s", "steps": k, "warmup": 1,
                         "ms_per_step": e["elapsed"] / k * 1e3, "ms_per_step_spread": step_times(e["per_step"]), "scene_triangles": e["ntris"],
-                        "spp": e["wl"]["spp"], "frame_check": e["frame_check"], "boundary": e["boundary"],
-                        "roofline": roofline_block(EXTRA, ea, 1, build_id, e["tree_walk"])}
+                        "spp": e["wl"]["spp"], "work": work_block(ea, k), "frame_check": e["frame_check"], "boundary": e["boundary"],
+                        "roofline": roofline_block(name, ea, 1, build_id, e["tree_walk"])}
     if ranks == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl, r["cam"], acc["rays"] / max(1.0, acc["samples"]))
+        out["cpu_baseline"] = cpu_baseline(wl, r["cam"], (acc["rays"] + acc["culled_rays"]) / max(1.0, acc["samples"] + acc["culled_samples"]), elapsed / args.steps)
     print(json.dumps(out))
     sys.stdout.flush()
 
@@ -495,9 +521,10 @@ def process_mode(args, rank, local_rank, world, torch, binding, scenes):
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    tot = torch.tensor([float(acc["rays"]), float(acc["samples"])], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(acc["rays"]), float(acc["samples"]), float(acc["culled_rays"]), float(acc["culled_samples"])], dtype=torch.float64, device=red_dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
+    total_frame_rays, total_frame_samples = total_rays + float(tot[2].item()), total_samples + float(tot[3].item())
     # every rank's megakernel time of the last frame, for attributing a scaling loss
     km = torch.zeros(world, dtype=torch.float64, device=red_dev)
     km[rank] = stats.traceKernelMs
@@ -531,7 +558,11 @@ def process_mode(args, rank, local_rank, world, torch, binding, scenes):
             "config": {"workload": args.workload, "mode": "one process per GPU (RaylibAMD_RenderDevice + one RCCL gather per frame)", "scene_triangles": ntris,
                        "width": w, "height": h, "spp": wl["spp"], "max_path_length": wl["max_path"], "seed": 1,
                        "tiling": "8x8 cells round-robin over %d rank(s)" % world, "rays_per_step": total_rays / args.steps,
-                       "camera_samples_per_step": total_samples / args.steps, "frame_check": frame_check,
+                       "camera_samples_per_step": total_samples / args.steps,
+                       "work": {"rays_executed_per_step": total_rays / args.steps, "camera_samples_executed_per_step": total_samples / args.steps,
+                                "rays_accounted_not_traced_per_step": (total_frame_rays - total_rays) / args.steps,
+                                "camera_samples_not_traced_per_step": (total_frame_samples - total_samples) / args.steps},
+                       "frame_check": frame_check,
                        "boundary": {"timed_entry": "RaylibAMD_RenderDevice + torch.distributed gather", "ms_per_step": elapsed / args.steps * 1e3},
                        "build_id": build_id, "timed_region_s": elapsed},
             "roofline": roofline_block(args.workload, acc, world, build_id),
@@ -539,7 +570,7 @@ def process_mode(args, rank, local_rank, world, torch, binding, scenes):
                           "rank_trace_ms": [float(x) for x in km.tolist()], "note": "rank_trace_ms: every rank's megakernel time in the last timed frame"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, cam, total_rays / max(1.0, total_samples))
+            out["cpu_baseline"] = cpu_baseline(wl, cam, total_frame_rays / max(1.0, total_frame_samples), elapsed / args.steps)
         print(json.dumps(out))
         sys.stdout.flush()
     ses.close()

@@ -30,12 +30,14 @@ extern "C" {
 #endif
 
 typedef struct RaylibAMDStats {
-	uint64_t rays;            /* closest-hit + occlusion queries (reference renderer.cc:129,194,70,79) */
+	/* Every counter below counts work a KERNEL EXECUTED.  Camera samples of cells that were dropped from the job list (culledCells, below) are not in them. */
+	uint64_t rays;            /* closest-hit + occlusion queries executed on the device (reference renderer.cc:129,194,70,79); a camera ray or sun ray that is
+	                             decided by the root node's two boxes alone is one query that fetched one node record */
 	uint64_t nodesVisited;    /* 64-byte BVH node records fetched (a float-box BVH4 node or a leaf-list record of four boxes counts as two) */
 	uint64_t trisTested;      /* 64-byte triangle intersection records fetched */
 	uint64_t shadedHits;      /* 64-byte triangle shading records fetched */
 	uint64_t texFetches;      /* 16-byte texels fetched */
-	uint64_t cameraSamples;   /* (pixel, sample) paths traced */
+	uint64_t cameraSamples;   /* (pixel, sample) paths generated and traced by the megakernel (culledSamples are NOT in here: cameraSamples + culledSamples = pixels x spp) */
 	uint64_t pixels;          /* pixels written (16 bytes each) */
 	double   kernelMs;        /* HIP-event time of all kernels of the last render, on the library's stream */
 	double   traceKernelMs;   /* ... of the path-tracing megakernel launches only */
@@ -44,7 +46,7 @@ typedef struct RaylibAMDStats {
 	uint32_t numNodes;        /* BVH nodes of the scene */
 	uint32_t numTriangles;
 	uint32_t bvhDepth;
-	uint64_t waveTrips;       /* bounce-loop trips summed over waves: rays / (64 * waveTrips) = share of lane slots that traced a ray */
+	uint64_t waveTrips;       /* bounce-loop trips summed over waves (a diagnostic: it depends on which wave drew which batch and differs from run to run) */
 	uint32_t pathsPerWave;    /* schedule of the megakernel: 64 = k_trace (one path per lane), 128/192/256 = k_trace_pool */
 	uint32_t ranks;           /* logical ranks (devices) that rendered the frame: 1, or RAYLIB_NUM_GPUS for a whole-frame render */
 	/* ---- a whole-frame render over several ranks (RAYLIB_NUM_GPUS > 1): where the time went, so that a scaling loss can be attributed ---- */
@@ -57,6 +59,13 @@ typedef struct RaylibAMDStats {
 	double   scatterMs;       /* k_scatter_cells: cell buffers -> row-major frame */
 	double   rankKernelMs[16];/* per rank: HIP-event time of all its kernels (kernelMs is their maximum) */
 	double   rankTraceMs[16]; /* per rank: ... of its megakernel launches (traceKernelMs is their maximum) */
+	/* ---- cells outside the scene's silhouette (csrc/rl_cull.cc): dropped from the job list, filled with the miss shader's constant by k_resolve.
+	 *      Nothing below was executed by any kernel; these are what the dropped samples WOULD have cost (one root-box query each, two with a sun),
+	 *      kept apart so that a rate computed from `rays` is a rate of executed queries. ---- */
+	uint32_t culledCells;     /* 8 x 8 cells left out of the job list (summed over ranks); RaylibAMD_CullCells on the same view returns this number */
+	uint32_t listedCells;     /* cells in the job list (culledCells + listedCells = the frame's cells) */
+	uint64_t culledSamples;   /* camera samples of those cells: pixels of the culled cells x spp */
+	uint64_t culledRays;      /* queries (= root node records) those samples stand for: culledSamples x (2 with a sun, else 1) */
 } RaylibAMDStats;
 
 /* Seed of the per-(pixel, sample) streams of include/raylib_amd_rng.h. */

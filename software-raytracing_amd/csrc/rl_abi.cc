@@ -52,7 +52,7 @@ uint64_t CurrentSeed()
 }
 
 bool RenderInternal(const RendererSettings* settings, Scene* scene, Camera* camera,
-                    uint32_t cellFirst, uint32_t cellStride, void* outDevice, float* outHost)
+                    uint32_t cellFirst, uint32_t cellStride, void* outDevice, float* outHost, bool callerOwnsOut = false)
 {
 	if (!settings || !scene || !camera) { Log("Raylib_Render: null argument"); return false; }
 	if (!scene->finalized) { Log("Raylib_Render: scene was not finalized (Raylib_FinalizeScene)"); return false; }
@@ -73,6 +73,7 @@ bool RenderInternal(const RendererSettings* settings, Scene* scene, Camera* came
 	req.seed = CurrentSeed();
 	req.cellFirst = cellFirst; req.cellStride = cellStride;
 	req.outDevice = outDevice; req.outHostRGBA = outHost;
+	req.callerOwnsOut = callerOwnsOut;
 	RaylibAMDStats stats; memset(&stats, 0, sizeof(stats));
 	bool ok = DeviceRender(*scene, req, stats);
 	{ std::lock_guard<std::mutex> lk(g_stateMu); g_lastStats = stats; }
@@ -345,7 +346,8 @@ int32_t RaylibAMD_RenderDevice(const RendererSettings* settings, SceneHandle sce
                                uint32_t cellFirst, uint32_t cellStride, void* outDevice)
 {
 	if (!settings || settings->viewportWidth == 0 || settings->viewportHeight == 0) return 0;
-	return RenderInternal(settings, (Scene*)scene, (Camera*)camera, cellFirst, cellStride ? cellStride : 1, outDevice, nullptr) ? 1 : 0;
+	// (a buffer of the caller's: nothing of the library's protects it while a frame is in flight, so this entry is synchronous on every path -- rl_runtime.inl RenderMulti)
+	return RenderInternal(settings, (Scene*)scene, (Camera*)camera, cellFirst, cellStride ? cellStride : 1, outDevice, nullptr, outDevice != nullptr) ? 1 : 0;
 }
 
 int32_t RaylibAMD_RenderCellsHost(const RendererSettings* settings, SceneHandle scene, CameraHandle camera,
@@ -454,7 +456,7 @@ int32_t RaylibAMD_CullCells(CameraHandle ch, const float* bounds, const float* s
 	}
 	const uint32_t W = (uint32_t)width, H = (uint32_t)height, cellsX = (W + 7) / 8, cellsY = (H + 7) / 8;
 	CullResult r;
-	if (!CullCells(cs, c->ToDevice(), 1, W, H, cellsX, 0, 1, cellsX * cellsY, r)) {
+	if (!CullCells(cs, c->ToDevice(), 1, 0.0f, W, H, cellsX, 0, 1, cellsX * cellsY, r)) {
 		if (outEmpty) memset(outEmpty, 0, (size_t)cellsX * cellsY);
 		return r.empty.empty() ? -1 : 0;   // not eligible, or eligible with nothing to drop
 	}

@@ -17,11 +17,14 @@ namespace rl {
 // the counters get the camera samples and root-box queries those samples stand for (FinishRender).  The frame cannot change: a listed or a
 // dropped cell's pixels come to the same bits either way (tests/test_gpu_parity.py renders both).  RAYLIB_CULL_CELLS=0: every cell is listed.
 // Returns false when the frame is not eligible.
-bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, uint32_t W, uint32_t H,
+bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, float rayTMin, uint32_t W, uint32_t H,
                uint32_t cellsX, uint32_t cellFirst, uint32_t stride, uint32_t numLocalCells, CullResult& out)
 {
 	if (const char* e = getenv("RAYLIB_CULL_CELLS")) if (atoi(e) == 0) return false;
 	if (DS.prims || !DS.boundsValid || DS.hasSky || cam.lensRadius != 0.0f || maxPathLength <= 0 || numLocalCells == 0) return false;
+	// A negative rayTMin lets a query find hits BEHIND its origin (the tree walk and the tests support it): a camera ray that points away from the box, or a sun
+	// ray from a camera downstream of the box, may then meet the scene after all.  Everything below reasons about t >= 0 only, so such a frame is not culled.
+	if (!(rayTMin >= 0.0f)) return false;
 	auto sub3 = [](const double* a, const double* b, double* r) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; };
 	auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
 	const double O[3] = { cam.origin[0], cam.origin[1], cam.origin[2] }, TL[3] = { cam.top_left[0], cam.top_left[1], cam.top_left[2] };

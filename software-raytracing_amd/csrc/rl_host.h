@@ -194,6 +194,7 @@ struct RenderRequest {
 	bool cellMajor = false; // the rank's cells back to back even when it owns every cell (one rank going through the gather path)
 	int slot = 0;           // frame slot (0 / 1) of the rank's events and counter buffers: a multi-rank frame in flight while the next is enqueued
 	void* outDevice;        // may be null
+	bool callerOwnsOut = false; // outDevice is memory of the CALLER (RaylibAMD_RenderDevice), not an image of the library: the call returns with the frame complete in it
 	float* outHostRGBA;     // may be null; receives what outDevice would (row-major image or the rank's cells)
 };
 bool DeviceAvailable();
@@ -220,7 +221,7 @@ void DeviceFreePixels(void* p);
 // cells outside the scene's silhouette (rl_cull.cc)
 struct CullScene { double boundsMin[3] = { 0, 0, 0 }, boundsMax[3] = { 0, 0, 0 }; bool boundsValid = false, prims = false, hasSky = false, hasSun = false; float sunDirection[3] = { 0, 0, 0 }, sunIlluminance[3] = { 0, 0, 0 }; };
 struct CullResult { std::vector<uint32_t> active; std::vector<unsigned char> empty; uint64_t emptyPixels = 0; float L[3] = { 0, 0, 0 }; uint32_t raysPerSample = 1; };
-bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, uint32_t W, uint32_t H,
+bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, float rayTMin, uint32_t W, uint32_t H,
                uint32_t cellsX, uint32_t cellFirst, uint32_t stride, uint32_t numLocalCells, CullResult& out);
 bool DeviceEvalMath(int fn, const float* x, const float* y, int n, float* out);
 bool DeviceVerifyExactMath(int which, uint64_t* outMismatches, uint64_t* outFirst);   // 0: rtm::rcp1_ vs 1.0f / x, 1: rtm::sqrt_ vs sqrtf, 2: rtm::div_by_ vs a / b, 3: Barycentric short vs divisions; all 2^32 inputs

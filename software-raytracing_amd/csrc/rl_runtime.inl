@@ -17,6 +17,9 @@ namespace rl {
 
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
 	Log("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__, __LINE__, #expr); return false; } } while (0)
+// the same without leaving the function: clears the local `ok` and goes on (code that has work enqueued and must still reach the place that waits for it)
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	Log("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__, __LINE__, #expr); ok = false; } } while (0)
 
 // One physical device's copy of a scene.
 struct DeviceSceneCopy {
@@ -174,6 +177,20 @@ bool EnsureRuntime()
 		R.ranks.push_back(C);
 		Log("raylib(MI355X): rank %d of %d on device %d %s (%s), %d CUs", r, n, C->device, prop.name, prop.gcnArchName, C->numCUs);
 	}
+	if (n > 1) {   // once per process: what a scaling number will have run on
+		std::string matrix;
+		for (size_t a = 0; a < R.devices.size(); ++a) {
+			matrix += a ? " | " : "";
+			for (size_t b2 = 0; b2 < R.devices.size(); ++b2) {
+				int can = a == b2 ? 1 : 0;
+				if (a != b2 && hipDeviceCanAccessPeer(&can, R.devices[a], R.devices[b2]) != hipSuccess) can = -1;
+				matrix += can < 0 ? "?" : (can ? "1" : "0");
+			}
+		}
+		(void)hipGetLastError();
+		Log("raylib(MI355X): %d logical rank(s) on %d distinct device(s) of %d visible; peer access (row: from, column: to) %s; gather %s, pipeline %s",
+		    n, (int)R.devices.size(), count, matrix.c_str(), R.wantRccl ? "rccl (peer copies if it cannot be initialised)" : "peer copies", R.pipeline ? "two frames in flight" : "off");
+	}
 	// peers write their cells straight into rank 0's gather buffer
 	for (size_t s = 1; s < R.devices.size(); ++s) {
 		int can = 0;
@@ -197,13 +214,34 @@ bool EnsureRccl()
 	RcclApi& A = R.rccl;
 	if (A.tried) return A.ok;
 	A.tried = true;
-	// an RCCL the process already holds (a PyTorch process loads its own) is used as it is: two copies of the library in one process would each
-	// keep their own device state
-	A.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-	if (!A.lib) A.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-	if (!A.lib) A.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-	if (!A.lib) A.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-	if (!A.lib) { Log("raylib(MI355X): librccl could not be loaded (%s); the gather uses peer copies", dlerror()); return false; }
+	// An RCCL the process already holds (a PyTorch process maps its own) is ADOPTED, never doubled: two copies of the library in one process would each keep
+	// their own device state.  /proc/self/maps names the file that is mapped; dlopen(that path, RTLD_NOLOAD) returns the handle of exactly that copy, whatever
+	// soname it was loaded under.  Only a process without any librccl loads one -- and when a mapped copy cannot be adopted the gather falls back to peer
+	// copies and says so, instead of loading a second one beside it.
+	std::string mapped;
+	if (FILE* f = fopen("/proc/self/maps", "r")) {
+		char line[1024];
+		while (fgets(line, sizeof(line), f)) {
+			const char* path = strchr(line, '/');
+			if (!path) continue;
+			const char* base = strrchr(path, '/');
+			if (base && strncmp(base + 1, "librccl.so", 10) == 0) { mapped.assign(path); while (!mapped.empty() && (mapped.back() == '\n' || mapped.back() == ' ')) mapped.pop_back(); break; }
+		}
+		fclose(f);
+	}
+	const char* how = "adopted (already mapped by this process)";
+	if (!mapped.empty()) {
+		A.lib = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD);
+		if (!A.lib) A.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+		if (!A.lib) A.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+		if (!A.lib) { Log("raylib(MI355X): %s is mapped by this process but could not be adopted (%s); not loading a second RCCL -- the gather uses peer copies", mapped.c_str(), dlerror()); return false; }
+	} else {
+		how = "loaded by the library (no RCCL was mapped)";
+		A.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+		if (!A.lib) A.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+		if (!A.lib) { Log("raylib(MI355X): librccl could not be loaded (%s); the gather uses peer copies", dlerror()); return false; }
+	}
+	Log("raylib(MI355X): RCCL %s: %s", how, mapped.empty() ? "librccl.so.1" : mapped.c_str());
 	A.CommInitAll = (int (*)(void**, int, const int*))dlsym(A.lib, "ncclCommInitAll");
 	A.CommDestroy = (int (*)(void*))dlsym(A.lib, "ncclCommDestroy");
 	A.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(A.lib, "ncclSend");
@@ -487,7 +525,9 @@ struct PendingRender {
 	float traceMs = 0.0f;
 	uint32_t launches = 0, schedulePaths = 1, jobHeads = 0;
 	uint64_t pixels = 0;
-	uint64_t culledSamples = 0; uint32_t culledRaysPerSample = 0;   // camera samples of cells outside the scene's silhouette: counted, not traced (CullCells)
+	uint64_t culledSamples = 0; uint32_t culledRaysPerSample = 0;   // camera samples of cells outside the scene's silhouette: reported apart, not traced (CullCells)
+	uint32_t culledCells = 0, listedCells = 0;
+	bool enqueuedToEnd = false;                // EnqueueRender reached the ev[slot][7] record (FinishRender waits for it; otherwise for the whole stream)
 	float4* out = nullptr; size_t outBytes = 0;
 	int slot = 0;                              // frame slot: which of the rank's event sets / pinned counter buffers this render uses
 	const unsigned long long* cnt = nullptr;   // -> ctx->cntHost[slot], valid once ev[slot][7] has fired
@@ -589,7 +629,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 			// what the decision depends on: an unchanged view keeps the lists the slot already holds on the device
 			std::vector<unsigned char> key;
 			auto put = [&](const void* ptr, size_t n) { const unsigned char* b = (const unsigned char*)ptr; key.insert(key.end(), b, b + n); };
-			const uint32_t geo[6] = { W, H, req.cellFirst, stride, numLocalCells, (uint32_t)st.maxPathLength };
+			const uint32_t geo[7] = { W, H, req.cellFirst, stride, numLocalCells, (uint32_t)st.maxPathLength, __builtin_bit_cast(uint32_t, st.rayTMin) };
 			const int flags[3] = { traceView.sky ? 1 : 0, traceView.hasSun, getenv("RAYLIB_CULL_CELLS") ? atoi(getenv("RAYLIB_CULL_CELLS")) : 1 };
 			put(&req.camera, sizeof(req.camera)); put(geo, sizeof(geo)); put(flags, sizeof(flags)); put(traceView.sunDirection, sizeof(traceView.sunDirection));
 			put(traceView.sunIlluminance, sizeof(traceView.sunIlluminance)); put(DS->boundsMin, sizeof(DS->boundsMin)); put(DS->boundsMax, sizeof(DS->boundsMax));
@@ -599,7 +639,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				CullScene cs;
 				for (int k = 0; k < 3; ++k) { cs.boundsMin[k] = DS->boundsMin[k]; cs.boundsMax[k] = DS->boundsMax[k]; cs.sunDirection[k] = traceView.sunDirection[k]; cs.sunIlluminance[k] = traceView.sunIlluminance[k]; }
 				cs.boundsValid = DS->boundsValid; cs.prims = PRIMS; cs.hasSky = traceView.sky != nullptr; cs.hasSun = traceView.hasSun != 0;
-				const bool culled = CullCells(cs, req.camera, st.maxPathLength, W, H, cellsX, req.cellFirst, stride, numLocalCells, cr);
+				const bool culled = CullCells(cs, req.camera, st.maxPathLength, st.rayTMin, W, H, cellsX, req.cellFirst, stride, numLocalCells, cr);
 				R.cullKey[q].clear();   // (valid again once the slot's buffers hold this view)
 				R.cullActive[q] = numLocalCells; R.cullEmptyPixels[q] = 0;
 				if (culled) {
@@ -627,6 +667,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				P.emptyL[0] = R.cullL[q][0]; P.emptyL[1] = R.cullL[q][1]; P.emptyL[2] = R.cullL[q][2];
 				pend.culledSamples = R.cullEmptyPixels[q] * (uint64_t)SPP; pend.culledRaysPerSample = R.cullRays[q];
 			}
+			pend.culledCells = numLocalCells - numActive; pend.listedCells = numActive;
 		}
 		int blocksPerCU = 0;
 		{
@@ -654,7 +695,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				// 128 -> 3.62, 256 -> 3.45, 512 -> 3.53, 1024 -> 4.07; on the whole frame 1024 is best (64 -> 33.6 ms: the atomic saturates).
 				const uint64_t waves = (uint64_t)blocks * (RL_BLOCK / 64);
 				uint64_t chunk = ((jobs64 / (waves * 16)) + 32) & ~63ull;
-				if (const char* e = getenv("RAYLIB_JOB_CHUNK")) chunk = (uint64_t)atoi(e);
+				if (const char* e = getenv("RAYLIB_JOB_CHUNK")) chunk = (uint64_t)std::max(0, atoi(e));
 				P.jobChunk = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, chunk));
 				// The pool schedule's jobs differ by two orders of magnitude (a cell that misses the scene's root box against one full of geometry): the launch's
 				// tail is what a wave needs for its LAST chunk, and on the 298 k-triangle frame a chunk of 1024 heavy jobs is 6 ms of a 45 ms launch (wave timeline,
@@ -673,6 +714,9 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 					uint64_t cap = 1024; if (const char* e = getenv("RAYLIB_JOB_CHUNK_MAX")) cap = (uint64_t)std::max(64, atoi(e));
 					P.jobChunk = (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(256, 4 * chunk));
 				}
+				// a chunk is whole batches of 64 jobs (one cell at one sample: DecodeJobBatch decodes base >> 6, TakeJobs packs the head's number into the low
+				// bits of a band's job count) whatever the environment asked for
+				P.jobChunk = std::max(64u, P.jobChunk & ~63u);
 			}
 			if (!Grow(R.pathStack, R.pathStackBytes, (size_t)depthSlots * 8 * P.stackStride * sizeof(float))) return false;
 			{   // the job list in bands of whole cells, one head per XCD (rl_render.hip TakeJobs); heads count from their band's first job: one memset
@@ -714,12 +758,14 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 	HIP_OK(hipEventRecord(R.ev[q][1], R.stream));
 	HIP_OK(hipMemcpyAsync(R.cntHost[q], R.counters, (CNT_COUNT + 24) * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
 	HIP_OK(hipEventRecord(R.ev[q][7], R.stream));
+	pend.enqueuedToEnd = true;
 	uint64_t px = 0;
 	for (uint32_t k = 0; k < numLocalCells; ++k) {
 		const uint32_t cell = req.cellFirst + k * stride, cx = cell % cellsX, cy = cell / cellsX;
 		px += (uint64_t)std::min(8u, W - cx * 8) * std::min(8u, H - cy * 8);
 	}
 	pend.pixels = px;
+	if (!pathTrace) pend.listedCells = numLocalCells;
 	return true;
 }
 
@@ -740,6 +786,11 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 	RankCtx& R = *pend.ctx;
 	const int q = pend.slot;
 	HIP_OK(hipSetDevice(R.device));
+	if (!pend.enqueuedToEnd) {
+		// the enqueue failed half-way: whatever it did queue is waited for (the stream is drained whatever happened), there are no numbers to report
+		(void)hipStreamSynchronize(R.stream);
+		return false;
+	}
 	HIP_OK(hipEventSynchronize(R.ev[q][7]));   // this render's last operation on the rank's stream (a later frame may already be queued behind it)
 	if (pend.lastBatchPending) {
 		float ms = 0.0f;
@@ -751,8 +802,10 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 	const unsigned long long* cnt = pend.cnt;
 	stats.rays += cnt[CNT_RAYS]; stats.nodesVisited += cnt[CNT_NODES]; stats.trisTested += cnt[CNT_TRIS];
 	stats.shadedHits += cnt[CNT_SHADED]; stats.texFetches += cnt[CNT_TEXELS]; stats.cameraSamples += cnt[CNT_SAMPLES];
-	// camera samples of the cells outside the scene's silhouette (CullCells): each stands for one root-box query, two with a sun, as the megakernel counts them
-	stats.cameraSamples += pend.culledSamples; stats.rays += pend.culledSamples * pend.culledRaysPerSample; stats.nodesVisited += pend.culledSamples * pend.culledRaysPerSample;
+	// camera samples of the cells outside the scene's silhouette (CullCells) were never generated or traced: they are reported next to the executed work, not in it
+	// (each would have been one root-box query, two with a sun -- what the megakernel counts for a sample it decides at the root)
+	stats.culledCells += pend.culledCells; stats.listedCells += pend.listedCells;
+	stats.culledSamples += pend.culledSamples; stats.culledRays += pend.culledSamples * pend.culledRaysPerSample;
 	stats.waveTrips += cnt[CNT_TRIPS];
 	stats.pathsPerWave = 64u * pend.schedulePaths;
 	stats.pixels += pend.pixels;
@@ -880,6 +933,8 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats, boo
 	for (int r = 0; r < N; ++r) { remote[(size_t)r] = (R.ranks[(size_t)r]->device != R0.device) || (r == 0 && R.gatherSelf); anyRemote = anyRemote || remote[(size_t)r]; }
 	const bool useRccl = anyRemote && R.wantRccl && EnsureRccl();
 
+	// From here on work is enqueued that only FinishInflight waits for: no early return -- a failing call clears `ok` (HIP_TRY) and the function still
+	// reaches the place that registers the frame and drains every stream.
 	Runtime::Inflight* F = new Runtime::Inflight;
 	F->pend.resize((size_t)N);
 	F->slot = b; F->t0 = std::chrono::steady_clock::now();
@@ -903,7 +958,7 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats, boo
 	for (int r = 1; r < N; ++r) R.ranks[(size_t)r]->worker->Post([&run, r]() { return run(r); });
 	ok = run(0) && ok;
 	for (int r = 1; r < N; ++r) ok = R.ranks[(size_t)r]->worker->Wait() && ok;
-	HIP_OK(hipSetDevice(R0.device));
+	HIP_TRY(hipSetDevice(R0.device));
 	if (ok && useRccl) {
 		// one group: rank 0's GATHER stream receives every remote rank's cells, each remote rank's stream sends them (behind its kernels)
 		RcclApi& A = R.rccl;
@@ -917,9 +972,9 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats, boo
 			RankCtx& C = *R.ranks[(size_t)r];
 			if (!remote[(size_t)r] || !local[(size_t)r] || lead[(size_t)C.devSlot] == r) continue;
 			(void)hipSetDevice(C.device);
-			HIP_OK(hipStreamWaitEvent(sendStream(C), C.ev[b][4], 0));
+			HIP_TRY(hipStreamWaitEvent(sendStream(C), C.ev[b][4], 0));
 		}
-		if (remote[0] && local[0]) { (void)hipSetDevice(R0.device); HIP_OK(hipStreamWaitEvent(R.gatherStream, R0.ev[b][4], 0)); }
+		if (remote[0] && local[0]) { (void)hipSetDevice(R0.device); HIP_TRY(hipStreamWaitEvent(R.gatherStream, R0.ev[b][4], 0)); }
 		int rc = A.GroupStart();
 		for (int r = 0; r < N && rc == 0; ++r) {
 			if (!remote[(size_t)r] || !local[(size_t)r]) continue;
@@ -934,23 +989,23 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats, boo
 			if (lead[sl] < 0 || (int)sl == R0.devSlot) continue;
 			RankCtx& L = *R.ranks[(size_t)lead[sl]];
 			(void)hipSetDevice(L.device);
-			HIP_OK(hipEventRecord(L.ev[b][5], L.stream));   // (slots 5 and 6 belong to rank 0 on ITS device; a lead of another device uses its own 5 for "sends done")
-			for (int r = 0; r < N; ++r) if (r != lead[sl] && remote[(size_t)r] && R.ranks[(size_t)r]->devSlot == (int)sl) HIP_OK(hipStreamWaitEvent(R.ranks[(size_t)r]->stream, L.ev[b][5], 0));
+			HIP_TRY(hipEventRecord(L.ev[b][5], L.stream));   // (slots 5 and 6 belong to rank 0 on ITS device; a lead of another device uses its own 5 for "sends done")
+			for (int r = 0; r < N; ++r) if (r != lead[sl] && remote[(size_t)r] && R.ranks[(size_t)r]->devSlot == (int)sl) HIP_TRY(hipStreamWaitEvent(R.ranks[(size_t)r]->stream, L.ev[b][5], 0));
 		}
 		(void)hipSetDevice(R0.device);
 	}
 	if (ok) {
 		// the gather stream waits for every rank's "my cells are there" (rank 0's own render included), assembles the frame, and rank 0's
 		// render stream is free for the next frame meanwhile
-		for (int r = 0; r < N; ++r) HIP_OK(hipStreamWaitEvent(R.gatherStream, R.ranks[(size_t)r]->ev[b][4], 0));
-		HIP_OK(hipEventRecord(R0.ev[b][5], R.gatherStream));
+		for (int r = 0; r < N; ++r) HIP_TRY(hipStreamWaitEvent(R.gatherStream, R.ranks[(size_t)r]->ev[b][4], 0));
+		HIP_TRY(hipEventRecord(R0.ev[b][5], R.gatherStream));
 		const uint32_t blocks = (uint32_t)(((size_t)W * H + RL_BLOCK - 1) / RL_BLOCK);
 		hipLaunchKernelGGL(k_scatter_cells, dim3(blocks), dim3(RL_BLOCK), 0, R.gatherStream, (const float4*)gather, out, W, H, cellsX, plan);
-		HIP_OK(hipGetLastError());
-		if (req.outHostRGBA) HIP_OK(hipMemcpyAsync(req.outHostRGBA, out, frameBytes, hipMemcpyDeviceToHost, R.gatherStream));
-		HIP_OK(hipEventRecord(R0.ev[b][6], R.gatherStream));
-		if (remote[0] && useRccl) HIP_OK(hipStreamWaitEvent(R0.stream, R0.ev[b][5], 0));   // rank 0's self-send has read its cell buffer before the next render writes it
-		F->timed = true;
+		HIP_TRY(hipGetLastError());
+		if (req.outHostRGBA) HIP_TRY(hipMemcpyAsync(req.outHostRGBA, out, frameBytes, hipMemcpyDeviceToHost, R.gatherStream));
+		HIP_TRY(hipEventRecord(R0.ev[b][6], R.gatherStream));
+		if (remote[0] && useRccl) HIP_TRY(hipStreamWaitEvent(R0.stream, R0.ev[b][5], 0));   // rank 0's self-send has read its cell buffer before the next render writes it
+		F->timed = ok;   // (events 5 and 6 are only read when both were recorded)
 	}
 	F->ok = ok;
 	F->stats.ranks = (uint32_t)N; F->stats.devices = (uint32_t)R.devices.size();
@@ -959,8 +1014,10 @@ bool RenderMulti(Scene& sc, const RenderRequest& req, RaylibAMDStats& stats, boo
 	F->stats.numNodes = (uint32_t)sc.bvh.nodes.size(); F->stats.numTriangles = (uint32_t)sc.triangles.size(); F->stats.bvhDepth = sc.bvh.depth;
 	R.inflight[b] = F;
 	++R.frameNo;
-	if (!ok || !R.pipeline || req.outHostRGBA) {
-		// synchronous after all: a failure (every stream is drained whatever happened), the switch, or pixels wanted in host memory now
+	if (!ok || !R.pipeline || req.outHostRGBA || req.callerOwnsOut) {
+		// synchronous after all: a failure (every stream is drained whatever happened), the switch, pixels wanted in host memory now, or a frame
+		// into device memory of the caller's (RaylibAMD_RenderDevice: "the library's stream has been synchronised when it returns" -- nothing the
+		// library owns would keep a reader or a free of that buffer behind the gather stream's scatter)
 		ok = DrainLocked() && ok;
 		stats = g_deferredStats; g_deferredUnreported = false;
 		return ok;

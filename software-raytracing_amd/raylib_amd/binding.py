@@ -30,7 +30,8 @@ class Stats(C.Structure):
                 ("traceLaunches", C.c_uint32), ("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("bvhDepth", C.c_uint32),
                 ("waveTrips", C.c_uint64), ("pathsPerWave", C.c_uint32), ("ranks", C.c_uint32),
                 ("gatherMode", C.c_uint32), ("rcclCommSize", C.c_uint32), ("devices", C.c_uint32), ("jobHeads", C.c_uint32),
-                ("gatherMs", C.c_double), ("scatterMs", C.c_double), ("rankKernelMs", C.c_double * 16), ("rankTraceMs", C.c_double * 16)]
+                ("gatherMs", C.c_double), ("scatterMs", C.c_double), ("rankKernelMs", C.c_double * 16), ("rankTraceMs", C.c_double * 16),
+                ("culledCells", C.c_uint32), ("listedCells", C.c_uint32), ("culledSamples", C.c_uint64), ("culledRays", C.c_uint64)]
 
     GATHER_MODES = {0: "none", 1: "rccl", 2: "peer"}
 
@@ -39,6 +40,10 @@ class Stats(C.Structure):
         d["rankKernelMs"] = list(self.rankKernelMs)[: max(1, self.ranks)]
         d["rankTraceMs"] = list(self.rankTraceMs)[: max(1, self.ranks)]
         d["gatherMode"] = self.GATHER_MODES.get(self.gatherMode, "?")
+        # the frame's totals, whatever share of it the kernels had to execute: equal with and without the silhouette cull (csrc/rl_cull.cc)
+        d["frameSamples"] = self.cameraSamples + self.culledSamples
+        d["frameRays"] = self.rays + self.culledRays
+        d["frameNodes"] = self.nodesVisited + self.culledRays
         return d
 
 

@@ -248,6 +248,9 @@ def colonnade(path, tess=6, **kw):
 CONFIG_CAMERAS = {
     "cornell":   dict(origin=(0.0, 1.0, 4.0), look_at=(0.0, 1.0, -1.0), fov=45.0, sun=(0.0, 0.0, 0.0), sun_dir=(0.0, -1.0, -0.5)),
     "breakfast": dict(origin=(0.0, 1.0, 5.0), look_at=(0.0, 1.0, -1.0), fov=60.0, sun=(20.0, 20.0, 20.0), sun_dir=(-1.0, -1.0, 0.0)),
+    # the camera INSIDE the tessellated room (what Breakfast Room / Sponza / San Miguel are: interiors, reference Setup.ps1:42-79, scenes.json): the open front is
+    # behind it, every pixel looks at geometry, no cell of the frame can be dropped, paths leave through the holes the displaced triangles left and through the front
+    "breakfast_interior": dict(origin=(0.15, 1.1, 0.9), look_at=(-0.1, 0.9, -1.0), fov=60.0, sun=(20.0, 20.0, 20.0), sun_dir=(-1.0, -1.0, 0.0)),
     "sponza":    dict(origin=(10.0, 2.0, 0.0), look_at=(0.0, 3.0, 0.0), fov=60.0, sun=(20.0, 20.0, 20.0), sun_dir=(0.0, -1.0, -0.5)),
 }
 

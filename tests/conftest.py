@@ -11,6 +11,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _helpers():
+    import helpers
+    return helpers
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import helpers
@@ -42,3 +47,33 @@ def gpu_lib(lib):
 @pytest.fixture(scope="session")
 def workdir(tmp_path_factory):
     return tmp_path_factory.mktemp("scenes")
+
+
+# ---- scenes shared by the GPU test files (session scope: one load, whichever file asks first) ------------------------------------------
+@pytest.fixture(scope="session")
+def sessions(gpu_lib, workdir):
+    s = {name: _helpers().session_for_case(gpu_lib, name, workdir) for name in _helpers().CASES}
+    yield s
+    for v in s.values():
+        v.close()
+
+
+@pytest.fixture(scope="session")
+def full_size(gpu_lib, workdir):
+    from raylib_amd import binding
+    obj, c = _helpers().build_case("cornell", workdir)
+    ses = binding.SceneSession(gpu_lib, obj, c["origin"], c["look_at"], 45.0, 1920 / 1080)
+    img = ses.render(1920, 1080, 64)
+    yield ses, img, ses.stats().as_dict()
+    ses.close()
+
+
+@pytest.fixture(scope="session")
+def mid_scene(gpu_lib, workdir):
+    """Tessellated room with displaced triangles (about 21 k triangles, sun): BVH deeper than 16 -> pool schedule by default."""
+    from raylib_amd import binding
+    d = os.path.join(str(workdir), "mid"); os.makedirs(d, exist_ok=True)
+    obj, n = _helpers().scenes.cornell(os.path.join(d, "mid.obj"), tess=24, displace_fraction=0.2)
+    ses = binding.SceneSession(gpu_lib, obj, (0, 1, 5), (0, 1, -1), 60.0, 96 / 64, sun=(20, 20, 20), sun_dir=(-1.0, -1.0, 0.0))
+    yield ses, obj, n
+    ses.close()

@@ -80,7 +80,10 @@ def main(only=None):
         for wl, gen, kw, camname, w, h, spp, wins in (
                 ("cornell_1080p_64spp", scenes.cornell, {}, "cornell", 1920, 1080, 64, ((952, 536), (700, 300), (1100, 800), (0, 0), (860, 200), (600, 500), (1300, 600), (1000, 900), (800, 750), (1200, 250))),
                 ("breakfast_300k_1080p_128spp", scenes.cornell, dict(tess=91, displace_fraction=0.2), "breakfast", 1920, 1080, 128,
-                 ((952, 536), (760, 340), (1150, 700), (800, 650), (1100, 380), (300, 300), (1000, 560), (900, 420), (1050, 640)))):
+                 ((952, 536), (760, 340), (1150, 700), (800, 650), (1100, 380), (300, 300), (1000, 560), (900, 420), (1050, 640))),
+                # the same scene seen from inside (round 4): every window is geometry
+                ("breakfast_interior_300k_1080p_128spp", scenes.cornell, dict(tess=91, displace_fraction=0.2), "breakfast_interior", 1920, 1080, 128,
+                 ((952, 536), (100, 100), (1800, 60), (40, 1000), (1850, 1040), (600, 300), (1300, 760), (480, 880), (1500, 200)))):
             c = scenes.CONFIG_CAMERAS[camname]
             obj, _ = gen(os.path.join(tmp, wl + ".obj"), **kw)
             flat = objflat.load_obj(obj, orc, sun_illuminance=c["sun"], sun_direction=c["sun_dir"])

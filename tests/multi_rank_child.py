@@ -29,7 +29,35 @@ def render_all(lib, workdir):
         ses.close()
     out["stats"] = np.asarray(stats, np.int64)
     out.update(back_to_back(lib, workdir))
+    out["caller_buffer"] = caller_buffer(lib, workdir)
     return out
+
+
+def caller_buffer(lib, workdir):
+    """RaylibAMD_RenderDevice(whole frame) into device memory of the CALLER's, read back at once with a plain hipMemcpy (the null stream does not
+    wait for the library's non-blocking streams): the entry is documented as synchronous, also when the frame is assembled from several ranks
+    on the gather stream (csrc/rl_runtime.inl RenderMulti, RenderRequest::callerOwnsOut).  Then the buffer is freed straight away."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    w, h = 1920, 1080
+    ses = helpers.session_for_case(lib, "cornell", workdir)
+    st = ses.settings(w, h, 2)
+    frames = []
+    for _ in range(2):                                   # twice: the second call finds the first one's slot
+        dev = C.c_void_p()
+        assert hip.hipMalloc(C.byref(dev), w * h * 16) == 0 and hip.hipMemset(dev, 0xff, w * h * 16) == 0
+        assert lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, 0, 1, dev) == 1
+        host = np.zeros((h, w, 4), np.float32)
+        assert hip.hipMemcpy(host.ctypes.data, dev, w * h * 16, 2) == 0
+        assert hip.hipFree(dev) == 0
+        frames.append(host)
+    s = ses.stats()
+    assert s.cameraSamples + s.culledSamples == w * h * 2 and s.kernelMs > 0      # the call's own numbers, complete when it returned
+    ses.close()
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    return frames[0]
 
 
 def back_to_back(lib, workdir):

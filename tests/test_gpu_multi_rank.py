@@ -63,6 +63,8 @@ def test_raylib_render_over_n_ranks_is_bit_identical(layout, one_rank_frames, wo
     for k in ("p1", "p2", "p3"):
         assert helpers.same(got[k], one_rank_frames[k]).all(), k
     assert np.array_equal(got["pstats"], one_rank_frames["pstats"]) and got["pstats"][3] == 1 and got["pstats"][4] == 1
+    # a frame rendered into a device buffer of the caller's and read back at once with a plain hipMemcpy: complete when RaylibAMD_RenderDevice returned
+    assert helpers.same(got["caller_buffer"], one_rank_frames["caller_buffer"]).all() and helpers.same(got["caller_buffer"], one_rank_frames["f8"]).all()
     # the same camera samples, pixels and rays, however they were dealt; `ranks` says who rendered
     assert np.array_equal(got["stats"][:, 1:4], one_rank_frames["stats"][:, 1:4])
     assert (got["stats"][:, 0] == n).all() and (one_rank_frames["stats"][:, 0] == 1).all()
