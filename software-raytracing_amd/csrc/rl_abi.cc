@@ -179,6 +179,8 @@ void Raylib_DumpImageData(ImageHandle h, float* outDest)
 {
 	Image* img = (Image*)h;
 	if (!img || !outDest) return;
+	// a frame that lives on the device (Raylib_Render / Raylib_PostProcess left it there): packed to RGB there, 25 MB instead of 33 over the bus, through pinned staging
+	if (img->hostStale && img->devValid && DeviceDumpRGB(*img, outDest)) return;
 	img->SyncHost();   // the one read-back of a rendered / post-processed frame
 	const size_t n = (size_t)img->width * img->height;
 	for (size_t k = 0; k < n; ++k) {   // reference render/image.cc:121-135: packed RGB, row-major

@@ -215,6 +215,7 @@ bool DeviceRender(Scene& scene, const RenderRequest& req, RaylibAMDStats& stats)
 bool DeviceDrain(RaylibAMDStats* outLastStats);   // waits for multi-rank frames in flight; true + stats when that completed the last render call's numbers
 bool DeviceClosestHit(Scene& scene, const float* rays, int32_t n, float tMin, void* outHits);
 bool DevicePostProcess(Image& img);          // Image2D::PostProcess on the device; false when no device
+bool DeviceDumpRGB(Image& img, float* outRGB);   // a device-resident frame packed to RGB on the device and copied to caller memory through pinned staging; false: not applicable
 bool DeviceReadback(Image& img);            // device copy -> img.rgba (the caller checked hostStale)
 void* DeviceImagePixels(Image& img);          // (re)allocates img.devPixels for width*height float4; nullptr when no device
 void DeviceFreePixels(void* p);

@@ -2879,6 +2879,21 @@ k_verify_exact_math(int which, unsigned long long* __restrict__ out)
 	if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first); }
 }
 
+// Raylib_DumpImageData's packing (reference render/image.cc:121-135: RGB, 12 bytes per pixel, row-major) on the device: 25 MB cross the bus instead of 33,
+// and the host is left with a plain copy.  One thread packs four pixels: four 16-byte loads, three 16-byte stores.
+__global__ void __launch_bounds__(RL_BLOCK)
+k_pack_rgb(const float4* __restrict__ px, float4* __restrict__ out, float* __restrict__ outTail, size_t n)
+{
+	const size_t q = (size_t)blockIdx.x * RL_BLOCK + threadIdx.x;
+	const size_t i = q * 4;
+	if (i + 4 <= n) {
+		const float4 a = px[i], b = px[i + 1], c = px[i + 2], d = px[i + 3];
+		out[q * 3] = make_float4(a.x, a.y, a.z, b.x); out[q * 3 + 1] = make_float4(b.y, b.z, c.x, c.y); out[q * 3 + 2] = make_float4(c.z, d.x, d.y, d.z);
+	} else {
+		for (size_t k = i; k < n; ++k) { const float4 a = px[k]; outTail[3 * k] = a.x; outTail[3 * k + 1] = a.y; outTail[3 * k + 2] = a.z; }
+	}
+}
+
 // The frame from the ranks' cell buffers (N > 1 behind Raylib_Render): cell c was rendered by rank c % N as its (c / N)-th cell.
 struct ScatterPlan { uint32_t ranks; uint32_t offset[16]; };   // offset[r]: first float4 of rank r's cells in the gather buffer
 __global__ void __launch_bounds__(RL_BLOCK)

@@ -151,6 +151,40 @@ def test_full_size_pool_schedule_bit_identical(full_size, monkeypatch):
     assert np.array_equal(bits(ses.render(1920, 1080, 64)), bits(img))
 
 
+@pytest.mark.parametrize("shape", [(1920, 1080), (1, 1), (17, 1), (333, 127), (1283, 721)])
+def test_dump_image_data_from_a_device_resident_frame(shape, sessions, gpu_lib, monkeypatch):
+    """Raylib_DumpImageData (reference raylib.h:90-93, render/image.cc:121-135: packed RGB float, row 0 on top) of a frame that Raylib_Render left on the
+    device: packed on the device and copied through pinned staging in chunks (csrc/rl_runtime.inl DeviceDumpRGB).  Must equal the RGB of the RGBA read-back
+    and the plain path (RAYLIB_FAST_DUMP=0) bit for bit, for sizes that are not multiples of anything, twice in a row, and after Raylib_PostProcess."""
+    w, h = shape
+    ses = sessions["cornell_glass_sun"]
+    st = ses.settings(w, h, 2)
+    img = gpu_lib.Raylib_CreateImage(w, h)
+    gpu_lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, img)
+    fast = np.full(w * h * 3 + 8, -7.0, np.float32)
+    gpu_lib.Raylib_DumpImageData(img, fast.ctypes.data_as(C.POINTER(C.c_float)))
+    assert (fast[w * h * 3:] == -7.0).all()                      # nothing written past 3 * w * h floats
+    again = np.zeros(w * h * 3, np.float32)
+    gpu_lib.Raylib_DumpImageData(img, again.ctypes.data_as(C.POINTER(C.c_float)))
+    rgba = np.zeros((h, w, 4), np.float32)
+    gpu_lib.RaylibAMD_DumpImageRGBA(img, rgba.ctypes.data_as(C.POINTER(C.c_float)))
+    want = np.ascontiguousarray(rgba[..., :3]).reshape(-1)
+    assert np.array_equal(bits(fast[: w * h * 3]), bits(want)) and np.array_equal(bits(again), bits(want))
+    gpu_lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, img)
+    monkeypatch.setenv("RAYLIB_FAST_DUMP", "0")
+    plain = np.zeros(w * h * 3, np.float32)
+    gpu_lib.Raylib_DumpImageData(img, plain.ctypes.data_as(C.POINTER(C.c_float)))
+    monkeypatch.delenv("RAYLIB_FAST_DUMP")
+    assert np.array_equal(bits(plain), bits(want))
+    gpu_lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, img)
+    gpu_lib.Raylib_PostProcess(img)                              # the post-processed frame lives on the device too
+    pp = np.zeros(w * h * 3, np.float32)
+    gpu_lib.Raylib_DumpImageData(img, pp.ctypes.data_as(C.POINTER(C.c_float)))
+    gpu_lib.RaylibAMD_DumpImageRGBA(img, rgba.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(bits(pp), bits(np.ascontiguousarray(rgba[..., :3]).reshape(-1))) and pp.max() <= 1.0
+    gpu_lib.Raylib_DestroyImage(img)
+
+
 def test_gui_call_sequence(gpu_lib, workdir, oracle):
     """The C# GUI's exact sequence (reference gui-app/gui-app/MainForm.cs:121-256, denoiser absent)."""
     lib = gpu_lib
