@@ -140,11 +140,11 @@ RAYLIB_API int32_t RaylibAMD_EvalTexture(SceneHandle scene, int32_t texture, int
  * part), 11 sqrtf, 12 x / y, 13 fmodf(x, 1).  y may be NULL for one-argument functions. */
 RAYLIB_API int32_t RaylibAMD_EvalDeviceMath(int32_t fn, const float* x, const float* y, int32_t n, float* out);
 
-/* Test hook (host only, no device needed): which 8 x 8 cells of a width x height frame can no ray of the camera -- pinhole, no sky panorama -- meet the box
+/* Test hook (host only, no device needed): which 8 x 8 cells of a width x height frame can no ray of the camera -- pinhole or thin lens, no sky panorama -- meet the box
  * bounds = { min x, y, z, max x, y, z } in?  The renderer leaves those cells out of the megakernel's job list and fills them with the miss shader's
  * constant (csrc/rl_cull.cc).  outEmpty: one byte per cell, row-major, 1 = dropped; outConstant: the constant (the sun's illuminance, or nothing).
  * The sun direction is the normalised one the scene holds.  Returns the number of dropped cells, 0 when none can be dropped, -1 when the frame is not
- * eligible (a lens, a corner of the box beside or behind the camera, a sun ray from the camera that may meet the box). */
+ * eligible (a corner of the box beside or behind the camera, a sun ray from the camera -- from any point of its lens -- that may meet the box). */
 RAYLIB_API int32_t RaylibAMD_CullCells(CameraHandle camera, const float* bounds, const float* sunIlluminance, const float* sunDirection,
                                        int32_t width, int32_t height, uint8_t* outEmpty, float* outConstant);
 

@@ -7,7 +7,7 @@
 
 namespace rl {
 
-// Which of a rank's cells can a camera ray meet the scene in?  With a pinhole camera and no sky panorama every sample of every other cell ends in the
+// Which of a rank's cells can a camera ray meet the scene in?  With no sky panorama (a pinhole camera or a thin lens: round 4) every sample of every other cell ends in the
 // miss shader with the same value (nothing, or the sun's illuminance when the sun is not hidden from the camera either), and the megakernel used to
 // find that out sample by sample: generate the ray, test it against the root's boxes, store the constant -- 63 % of the Cornell frame's camera samples,
 // 89 % of the 298 k-triangle frame's.  Here the scene's bounding box is projected onto the image plane once per frame (double precision, the eight
@@ -21,7 +21,9 @@ bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, f
                uint32_t cellsX, uint32_t cellFirst, uint32_t stride, uint32_t numLocalCells, CullResult& out)
 {
 	if (const char* e = getenv("RAYLIB_CULL_CELLS")) if (atoi(e) == 0) return false;
-	if (DS.prims || !DS.boundsValid || DS.hasSky || cam.lensRadius != 0.0f || maxPathLength <= 0 || numLocalCells == 0) return false;
+	if (DS.prims || !DS.boundsValid || DS.hasSky || maxPathLength <= 0 || numLocalCells == 0) return false;
+	const double lensR = std::fabs((double)cam.lensRadius);   // the console front-end renders with aperture 0.01 (reference src/main.cc:24,421-425)
+	if (!std::isfinite(lensR)) return false;
 	// A negative rayTMin lets a query find hits BEHIND its origin (the tree walk and the tests support it): a camera ray that points away from the box, or a sun
 	// ray from a camera downstream of the box, may then meet the scene after all.  Everything below reasons about t >= 0 only, so such a frame is not culled.
 	if (!(rayTMin >= 0.0f)) return false;
@@ -40,6 +42,11 @@ bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, f
 	if (!(planeDist > 1e-12 * std::sqrt(nn) * std::sqrt(dot3(E, E)))) return false;
 	const double ext = std::max({ DS.boundsMax[0] - DS.boundsMin[0], DS.boundsMax[1] - DS.boundsMin[1], DS.boundsMax[2] - DS.boundsMin[2], 1e-30 });
 	double uLo = 1e300, uHi = -1e300, vLo = 1e300, vHi = -1e300;
+	// A thin lens (reference render/camera.h:44-53: origin + u * rd.x + v * rd.y with |rd| <= lensRadius, aimed at the sample's point F on the focal plane, which is
+	// the plane top_left / horizontal / vertical span): the ray from lens point L through F meets a scene point X of depth z where F = X * (zf / z) + L * (1 - zf / z),
+	// i.e. at the pinhole's projection of X moved by (L - O) * (1 - zf / z) within the focal plane -- at most lensRadius * |1 - zf / z|, largest at the box's nearest
+	// or farthest depth.  The rectangle of the pinhole projection grows by that circle of confusion.
+	double lensFac = 0.0;
 	for (int c = 0; c < 8; ++c) {
 		double X[3], Q[3];
 		for (int k = 0; k < 3; ++k) X[k] = (c >> k & 1) ? DS.boundsMax[k] + 1e-6 * ext : DS.boundsMin[k] - 1e-6 * ext;
@@ -47,6 +54,7 @@ bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, f
 		const double depth = dot3(Q, N);
 		if (!(depth > 1e-9 * std::sqrt(nn) * (std::sqrt(dot3(Q, Q)) + ext))) return false;   // a corner beside or behind the camera: no rectangle bounds the box
 		const double sc = planeDist / depth;
+		lensFac = std::max(lensFac, std::fabs(1.0 - sc));
 		double R3[3]; for (int k = 0; k < 3; ++k) R3[k] = Q[k] * sc - E[k];             // on the image plane, relative to the direction of (u, v) = (0, 0)
 		const double u = dot3(R3, Hh) / hh, v = -dot3(R3, Vv) / vv;
 		if (!std::isfinite(u) || !std::isfinite(v)) return false;
@@ -54,7 +62,9 @@ bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, f
 	}
 	// in pixels: a sample of pixel x has u * W in (x - 1, x + 1)
 	const double margin = 2.0;
-	const double xLo = uLo * W - margin, xHi = uHi * W + margin, yLo = vLo * H - margin, yHi = vHi * H + margin;
+	const double cocU = lensR * lensFac / std::sqrt(hh) * 1.0001, cocV = lensR * lensFac / std::sqrt(vv) * 1.0001;   // the circle of confusion in u and in v
+	if (!std::isfinite(cocU) || !std::isfinite(cocV)) return false;
+	const double xLo = (uLo - cocU) * W - margin, xHi = (uHi + cocU) * W + margin, yLo = (vLo - cocV) * H - margin, yHi = (vHi + cocV) * H + margin;
 	out.raysPerSample = 1;
 	out.L[0] = out.L[1] = out.L[2] = 0.0f;
 	if (DS.hasSun) {
@@ -64,7 +74,7 @@ bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, f
 		double t0 = 0.0, t1 = 1e300;
 		bool miss = false;
 		for (int k = 0; k < 3 && !miss; ++k) {
-			const double lo = DS.boundsMin[k] - 0.01 * ext, hi = DS.boundsMax[k] + 0.01 * ext;
+			const double lo = DS.boundsMin[k] - 0.01 * ext - lensR, hi = DS.boundsMax[k] + 0.01 * ext + lensR;   // (every lens point is within lensR of the camera origin)
 			if (D[k] == 0.0) { if (O[k] < lo || O[k] > hi) miss = true; continue; }
 			double a = (lo - O[k]) / D[k], b = (hi - O[k]) / D[k]; if (a > b) std::swap(a, b);
 			t0 = std::max(t0, a); t1 = std::min(t1, b);

@@ -166,6 +166,24 @@ def test_cells_outside_the_scenes_silhouette_are_not_traced_and_nothing_changes(
                 assert st1["cameraSamples"] == w * h * spp - px * spp
                 dropped_somewhere += int(st1["culledCells"] > 0)
             ses.close()
+    # A thin lens (the console front-end's camera: aperture 0.01, reference src/main.cc:24; here 0.01 and a wide 0.3): the rectangle grows by the circle of
+    # confusion, cells beyond it are dropped, and the frame and the totals are what they are with every cell traced.
+    lens_dropped = 0
+    for aperture, focal in ((0.01, 4.0), (0.3, 2.0), (0.3, 9.0)):
+        for sun, sun_dir in (((0.0, 0.0, 0.0), (0.0, -1.0, -0.5)), ((9.0, 8.0, 7.0), (-1.0, -1.0, 0.0))):
+            ses = binding.SceneSession(gpu_lib, obj, (0.5, 1.2, 9.0), (0.0, 1.0, -1.0), 40.0, 200 / 120, sun=sun, sun_dir=sun_dir, aperture=aperture, focal=focal)
+            img = ses.render(200, 120, 4)
+            st1 = ses.stats().as_dict()
+            monkeypatch.setenv("RAYLIB_CULL_CELLS", "0")
+            ref = ses.render(200, 120, 4)
+            st0 = ses.stats().as_dict()
+            monkeypatch.delenv("RAYLIB_CULL_CELLS")
+            assert np.array_equal(bits(img), bits(ref)), (aperture, focal, sun)
+            for k in ("frameRays", "frameSamples", "frameNodes", "shadedHits", "trisTested", "pixels"):
+                assert st0[k] == st1[k], (k, st0[k], st1[k], aperture, focal, sun)
+            lens_dropped += int(st1["culledCells"] > 0)
+            ses.close()
+    assert lens_dropped == 6, lens_dropped
     # A negative rayTMin lets a query find hits BEHIND its origin: with the light travelling from the box towards a camera that looks at the box from
     # downstream, the sun's occlusion query (origin: the camera, direction: away from the box) then meets the box at t < 0 and every traced sample loses
     # the sun -- a dropped cell filled with the sun's illuminance would be wrong.  Such a frame is not culled at all (csrc/rl_cull.cc).

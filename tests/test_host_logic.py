@@ -492,7 +492,7 @@ def test_cells_dropped_from_the_job_list_cannot_see_the_box(lib, oracle):
     pass
     rng = np.random.RandomState(11)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
-    dropped_cases = ineligible = 0
+    dropped_cases = ineligible = lens_cases = 0
     for case in range(60):
         w, h = int(rng.randint(40, 400)), int(rng.randint(30, 300))
         lo = rng.uniform(-2, 0, 3); hi = lo + rng.uniform(0.2, 3.0, 3)
@@ -502,16 +502,21 @@ def test_cells_dropped_from_the_job_list_cannot_see_the_box(lib, oracle):
         origin = centre + direction * dist
         look = centre + rng.normal(size=3) * float(rng.uniform(0.0, 1.5))
         fov, aspect = float(rng.uniform(15, 90)), w / h
+        # every third camera has a thin lens (the console front-end's aperture is 0.01, reference src/main.cc:24; here up to a fifth of the box's size), focused
+        # in front of, inside or behind the box: the dropped cells must be clear of the circle of confusion too
+        aperture = float(rng.uniform(0.005, 0.4)) if case % 3 == 2 else 0.0
+        focal = float(rng.uniform(0.3, 2.0)) * dist
         cam = lib.Raylib_CreateCamera()
         lib.Raylib_CameraSetPosition(cam, *[float(x) for x in origin]); lib.Raylib_CameraSetLookAt(cam, *[float(x) for x in look])
         lib.Raylib_CameraSetPerspective(cam, fov, aspect)
+        lib.Raylib_CameraSetLens(cam, aperture, focal)
         bounds = np.concatenate([lo, hi]).astype(np.float32)
         cx, cy = (w + 7) // 8, (h + 7) // 8
         empty = np.zeros(cx * cy, np.uint8)
         const = np.zeros(3, np.float32)
         n = lib.RaylibAMD_CullCells(cam, fp(bounds), None, None, w, h, empty.ctypes.data_as(C.POINTER(C.c_uint8)), fp(const))
         lib.Raylib_DestroyCamera(cam)
-        inside = bool(np.all(origin > lo - 1e-3) and np.all(origin < hi + 1e-3))
+        inside = bool(np.all(origin > lo - 1e-3 - aperture) and np.all(origin < hi + 1e-3 + aperture))
         if n < 0:
             ineligible += 1
             continue
@@ -520,7 +525,7 @@ def test_cells_dropped_from_the_job_list_cannot_see_the_box(lib, oracle):
         if n == 0:
             continue
         dropped_cases += 1
-        ocam = ffi.make_camera(tuple(float(x) for x in origin), tuple(float(x) for x in look), fov, aspect)
+        ocam = ffi.make_camera(tuple(float(x) for x in origin), tuple(float(x) for x in look), fov, aspect, aperture, focal)
         ys, xs = np.nonzero(empty.reshape(cy, cx))
         uv = []
         for (cyy, cxx) in zip(ys, xs):
@@ -533,7 +538,26 @@ def test_cells_dropped_from_the_job_list_cannot_see_the_box(lib, oracle):
                         for jy in (-0.999, 0.0, 0.999):
                             uv.append(((px + jx) / w, (py + jy) / h))
         uv = np.asarray(uv, np.float32)
-        rays = oracle.camera_rays(ocam, uv, seed=1)[:, :6].astype(np.float64)
+        if aperture > 0.0:
+            # lens points are drawn per ray: many draws per (u, v), plus the rim of the lens by hand (the reference's r = sqrt(u1) reaches it only in the limit)
+            lens_cases += 1
+            uv = np.tile(uv[:: max(1, len(uv) // 4000)], (12, 1))
+        rays = oracle.camera_rays(ocam, uv, seed=1 + case)[:, :6].astype(np.float64)
+        if aperture > 0.0:
+            cam19 = np.zeros(19, np.float32)
+            c2 = lib.Raylib_CreateCamera()
+            lib.Raylib_CameraSetPosition(c2, *[float(x) for x in origin]); lib.Raylib_CameraSetLookAt(c2, *[float(x) for x in look])
+            lib.Raylib_CameraSetPerspective(c2, fov, aspect); lib.Raylib_CameraSetLens(c2, aperture, focal)
+            lib.RaylibAMD_CameraExport(c2, fp(cam19)); lib.Raylib_DestroyCamera(c2)
+            O, R, TL, Hh, Vv, cu, cv = cam19[0:3].astype(np.float64), float(cam19[3]), cam19[4:7].astype(np.float64), cam19[7:10].astype(np.float64), cam19[10:13].astype(np.float64), cam19[13:16].astype(np.float64), cam19[16:19].astype(np.float64)
+            sub = uv[: len(uv) // 12].astype(np.float64)
+            rim = []
+            for ang in np.linspace(0.0, 2 * np.pi, 8, endpoint=False):
+                L = O + R * (np.cos(ang) * cu + np.sin(ang) * cv)
+                F = TL + sub[:, :1] * Hh + (1.0 - sub[:, 1:2]) * Vv
+                dd = F - L
+                rim.append(np.concatenate([np.broadcast_to(L, dd.shape), dd / np.linalg.norm(dd, axis=1, keepdims=True)], axis=1))
+            rays = np.concatenate([rays] + rim)
         o, d = rays[:, :3], rays[:, 3:]
         blo, bhi = bounds[:3].astype(np.float64), bounds[3:].astype(np.float64)
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -541,7 +565,12 @@ def test_cells_dropped_from_the_job_list_cannot_see_the_box(lib, oracle):
         tn = np.nanmax(np.minimum(t0, t1), axis=1); tf = np.nanmin(np.maximum(t0, t1), axis=1)
         hits = (tf >= np.maximum(tn, 0.0))
         assert not hits.any(), "case %d: %d rays of dropped cells meet the box" % (case, hits.sum())
-    assert dropped_cases >= 20 and ineligible >= 1, (dropped_cases, ineligible)
+    assert dropped_cases >= 20 and lens_cases >= 5, (dropped_cases, ineligible, lens_cases)
+    # a camera inside the box (a corner beside or behind it): no rectangle bounds the box, the frame is not eligible
+    cam = lib.Raylib_CreateCamera()
+    lib.Raylib_CameraSetPosition(cam, 0.0, 1.0, 0.5); lib.Raylib_CameraSetLookAt(cam, 0.0, 1.0, -1.0); lib.Raylib_CameraSetPerspective(cam, 70.0, 200 / 120)
+    assert lib.RaylibAMD_CullCells(cam, fp(np.asarray([-1, 0, -1, 1, 2, 1], np.float32)), None, None, 200, 120, None, None) == -1
+    lib.Raylib_DestroyCamera(cam)
     # with a sun whose ray from the camera misses the box the constant is the sun's illuminance; when it may hit the box nothing is dropped
     cam = lib.Raylib_CreateCamera()
     lib.Raylib_CameraSetPosition(cam, 0.0, 1.0, 14.0); lib.Raylib_CameraSetLookAt(cam, 0.0, 1.0, -1.0); lib.Raylib_CameraSetPerspective(cam, 45.0, 200 / 120)
