@@ -14,10 +14,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
-#include <cmath>
 #include <float.h>
 #include <math.h>
-#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
@@ -296,81 +294,9 @@ static void QuantizeWide(BVH& out)
 	for (std::thread& th : pool) th.join();
 }
 
-// nodes4 -> nodes4c (DNode4C, rl_device.h: 48 bytes, origins on a 16-bit grid over the scene's box).  As in QuantizeWide every decision is made in double,
-// where gridMin + u * gridStep + q * nodeStep is exact for the scenes the format is used for (checked below), so "the grid box contains the float box" holds
-// exactly.  Leaves nodes4c empty when the scene does not fit the format: an extent beyond 2^36 grid steps from the origin of the coordinates (the sums would
-// round in double), a grid step outside 2^-100 .. 2^20 (the device's float products would leave the normal range), more nodes than 3 * index < 2^31 allows.
-static void CompactWide(BVH& out)
-{
-	out.nodes4c.clear();
-	for (int a = 0; a < 3; ++a) { out.gridMin[a] = 0.0f; out.gridStep[a] = 0.0f; }
-	const size_t n = out.nodes4.size();
-	if (n == 0 || n * 3 >= ((size_t)1 << 31)) return;
-	double gmin[3], gstep[3];
-	for (int a = 0; a < 3; ++a) {
-		double lo = 1e300, hi = -1e300;
-		for (int k = 0; k < 4; ++k) if (out.nodes4[0].child[k] != DNODE_EMPTY) { lo = std::min(lo, (double)out.nodes4[0].lo[a][k]); hi = std::max(hi, (double)out.nodes4[0].hi[a][k]); }
-		if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return;
-		const double extent = hi - lo;
-		double step = ldexp(1.0, -100);
-		if (extent > 0.0) { int x; (void)frexp(extent / 65535.0, &x); step = std::max(step, ldexp(1.0, x)); }
-		while (65535.0 * step < extent) step *= 2.0;
-		if (step > ldexp(1.0, 20)) return;
-		if (std::max(std::fabs(lo), std::fabs(hi)) > step * ldexp(1.0, 36)) return;
-		gmin[a] = lo; gstep[a] = step;
-		out.gridMin[a] = (float)lo; out.gridStep[a] = (float)step;   // lo is a float's value, step a power of two: both exact
-	}
-	out.nodes4c.assign(n, DNode4C());
-	std::atomic<bool> ok(true);
-	auto run = [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) {
-		const DNode4& nd = out.nodes4[i];
-		DNode4C c; memset(&c, 0, sizeof(c));
-		uint32_t u[3] = { 0, 0, 0 }, kk[3] = { 0, 0, 0 }, qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
-		for (int a = 0; a < 3; ++a) {
-			double lo = 1e300, hi = -1e300;
-			for (int k = 0; k < 4; ++k) if (nd.child[k] != DNODE_EMPTY) { lo = std::min(lo, (double)nd.lo[a][k]); hi = std::max(hi, (double)nd.hi[a][k]); }
-			if (!(lo <= hi)) { lo = hi = gmin[a]; }
-			double uu = floor((lo - gmin[a]) / gstep[a]);
-			uu = std::max(0.0, std::min(65535.0, uu));
-			while (uu > 0.0 && gmin[a] + uu * gstep[a] > lo) uu -= 1.0;
-			const double origin = gmin[a] + uu * gstep[a];
-			if (origin > lo) { ok.store(false); return; }   // (a child below the scene's box: cannot happen, the root's boxes are the union)
-			const double cover = hi - origin;
-			int k = 0;
-			while (k < 31 && 255.0 * gstep[a] * ldexp(1.0, k - 8) < cover) ++k;
-			const double step = gstep[a] * ldexp(1.0, k - 8);
-			if (255.0 * step < cover) { ok.store(false); return; }
-			u[a] = (uint32_t)uu; kk[a] = (uint32_t)k;
-			for (int ch = 0; ch < 4; ++ch) {
-				if (nd.child[ch] == DNODE_EMPTY) { qlo[a] |= 255u << (8 * ch); continue; }   // inverted: lower 255, upper 0
-				double l = floor(((double)nd.lo[a][ch] - origin) / step), h = ceil(((double)nd.hi[a][ch] - origin) / step);
-				l = std::max(0.0, std::min(255.0, l)); h = std::max(0.0, std::min(255.0, h));
-				while (l > 0.0 && origin + l * step > (double)nd.lo[a][ch]) l -= 1.0;
-				while (h < 255.0 && origin + h * step < (double)nd.hi[a][ch]) h += 1.0;
-				if (origin + l * step > (double)nd.lo[a][ch] || origin + h * step < (double)nd.hi[a][ch]) { ok.store(false); return; }
-				qlo[a] |= (uint32_t)l << (8 * ch);
-				qhi[a] |= (uint32_t)h << (8 * ch);
-			}
-		}
-		c.oxy = u[0] | (u[1] << 16);
-		c.ozk = u[2] | (kk[0] << 16) | (kk[1] << 21) | (kk[2] << 26);
-		c.qloX = qlo[0]; c.qloY = qlo[1]; c.qloZ = qlo[2]; c.qhiX = qhi[0]; c.qhiY = qhi[1]; c.qhiZ = qhi[2];
-		for (int ch = 0; ch < 4; ++ch) c.child[ch] = nd.child[ch] >= 0 ? nd.child[ch] * 3 : nd.child[ch];
-		out.nodes4c[i] = c;
-	} };
-	unsigned threads = n >= (1u << 16) ? std::max(1u, std::min(32u, std::thread::hardware_concurrency())) : 1u;
-	if (const char* e = getenv("RAYLIB_BUILD_THREADS")) { int v = atoi(e); if (v > 0 && n >= (1u << 16)) threads = (unsigned)std::min(v, 32); }
-	std::vector<std::thread> pool;
-	const size_t per = (n + threads - 1) / threads;
-	for (unsigned t = 1; t < threads; ++t) { const size_t a = std::min(n, t * per), b = std::min(n, (t + 1) * per); if (a < b) pool.emplace_back(run, a, b); }
-	run(0, std::min(n, per));
-	for (std::thread& th : pool) th.join();
-	if (!ok.load()) out.nodes4c.clear();
-}
-
 void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 {
-	out.nodes.clear(); out.nodes4.clear(); out.nodes4q.clear(); out.nodes4c.clear(); out.leafList.clear(); out.stackNeed4 = 0; out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
+	out.nodes.clear(); out.nodes4.clear(); out.nodes4q.clear(); out.leafList.clear(); out.stackNeed4 = 0; out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
 	const uint32_t n = (uint32_t)prims.size();
 	Box empty; empty.mn = F3(FLT_MAX, FLT_MAX, FLT_MAX); empty.mx = F3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
 
@@ -546,7 +472,6 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		}
 		out.stackNeed4 = needMax;
 		QuantizeWide(out);
-		CompactWide(out);
 		// ---- the leaf list: a scene that 4 * RL_LEAFLIST_RECORDS leaves of <= 8 triangles can hold is walked without a tree ----
 		// Every ray tests every leaf's box once (4 records of 4 boxes, in lockstep across a wave: no stack, no divergence), then visits the
 		// leaves it touched nearest first.  In a tree this small a wave's rays take different turns at every node, and the wave pays for
@@ -594,7 +519,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 				}
 			}
 		}
-	} else { out.nodes4.clear(); out.nodes4q.clear(); out.nodes4c.clear(); out.leafList.clear(); out.stackNeed4 = 0; }
+	} else { out.nodes4.clear(); out.nodes4q.clear(); out.leafList.clear(); out.stackNeed4 = 0; }
 }
 
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris)
@@ -677,23 +602,6 @@ bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris)
 					const double step = (double)(a == 0 ? q.stepX : (a == 1 ? q.stepY : q.stepZ));
 					{ int e2 = 0; if (!(step > 0.0) || frexp(step, &e2) != 0.5) return false; }   // a power of two
 					const double lo = (double)q.origin[a] + (double)((q.qlo[a] >> (8 * k)) & 255u) * step, hi = (double)q.origin[a] + (double)((q.qhi[a] >> (8 * k)) & 255u) * step;
-					if (!(lo <= (double)n.lo[a][k] && hi >= (double)n.hi[a][k])) return false;
-				}
-			}
-		}
-		if (!bvh.nodes4c.empty()) {   // the 48-byte node: same children (inner references x 3), every grid box around its float box
-			if (bvh.nodes4c.size() != bvh.nodes4.size()) return false;
-			const DNode4C& c = bvh.nodes4c[it.ref];
-			const uint32_t u[3] = { c.oxy & 0xffffu, c.oxy >> 16, c.ozk & 0xffffu }, kk[3] = { (c.ozk >> 16) & 31u, (c.ozk >> 21) & 31u, (c.ozk >> 26) & 31u };
-			const uint32_t ql[3] = { c.qloX, c.qloY, c.qloZ }, qh[3] = { c.qhiX, c.qhiY, c.qhiZ };
-			for (int k = 0; k < 4; ++k) {
-				if (c.child[k] != (n.child[k] >= 0 ? n.child[k] * 3 : n.child[k])) return false;
-				if (n.child[k] == DNODE_EMPTY) continue;
-				for (int a = 0; a < 3; ++a) {
-					const double gs = (double)bvh.gridStep[a];
-					{ int e2 = 0; if (!(gs > 0.0) || frexp(gs, &e2) != 0.5) return false; }   // a power of two
-					const double origin = (double)bvh.gridMin[a] + (double)u[a] * gs, step = gs * ldexp(1.0, (int)kk[a] - 8);
-					const double lo = origin + (double)((ql[a] >> (8 * k)) & 255u) * step, hi = origin + (double)((qh[a] >> (8 * k)) & 255u) * step;
 					if (!(lo <= (double)n.lo[a][k] && hi >= (double)n.hi[a][k])) return false;
 				}
 			}

@@ -50,23 +50,6 @@ struct alignas(64) DNode4Q {
 	int32_t child[4];
 };
 static_assert(sizeof(DNode4Q) == 64, "DNode4Q");
-// The grid node in 48 bytes (round 4) = THREE 16-byte loads per lane and step instead of four.  Why that matters: the pool schedule's lanes each fetch their own
-// node from their own address, and a CU's vector memory path serves such a gather at about one lane-load (16 bytes) per clock whatever the lanes have in common
-// (tools/vmem_gather_bench.hip: 144 G 64-byte records/s chip-wide = 4.3 clocks per record and CU, L1-resident or not; TCP_TOTAL_CACHE_ACCESSES of the
-// 298 k-triangle interior frame: 0.79 per clock and CU, TD busy 99 %).  The kernel is bound by the NUMBER of its load instructions, so the node shrinks:
-//   * the origin is three 16-bit coordinates on a grid over the scene's bounding box (DSceneView::gridMin + u * gridStep, gridStep a power of two, rounded DOWN),
-//   * the per-axis step is gridStep * 2^(k - 8) with a 5-bit k (finer than the origin's grid: a small node keeps small boxes),
-//   * planes and children as in DNode4Q.  A child's grid box still CONTAINS its float box (the host checks it in double), and a box test only has to be
-//     conservative (candidate rule, rl_render.hip OwnBoxPass): the image stays bit-identical.
-// An inner child reference is 3 x the child's index (the record's offset in 16-byte units): the address is base + (ref << 4), no multiply.
-struct alignas(16) DNode4C {
-	uint32_t oxy;        // origin.x on the scene grid in bits 0-15, origin.y in bits 16-31
-	uint32_t ozk;        // origin.z in bits 0-15; kx bits 16-20, ky bits 21-25, kz bits 26-30
-	uint32_t qloX, qloY; // as DNode4Q::qlo / qhi: byte c = child c
-	uint32_t qloZ, qhiX, qhiY, qhiZ;
-	int32_t child[4];    // >= 0: 3 * index of an inner node; < 0: leaf reference as in DNode; DNODE_EMPTY: none
-};
-static_assert(sizeof(DNode4C) == 48, "DNode4C");
 // which of the two the POOL schedule walks (a build-time switch so that both can be timed: make variant EXTRA=-DRL_Q4=0);
 // k_trace has both as instantiations and takes the float boxes whenever the scene carries them
 #ifndef RL_Q4
@@ -148,9 +131,6 @@ struct DSceneView {
 	const DNode* nodes;
 	const DNode4Q* nodes4;     // the wide tree on the 8-bit grid: what the pool schedule walks (nullptr: the scene has none)
 	const DNode4* nodes4f;     // the wide tree with float boxes: uploaded for small, cache-resident scenes (k_trace), where the grid saves nothing
-	const DNode4C* nodes4c;    // the wide tree in 48-byte grid nodes (the pool schedule's default; nullptr: the scene has none or its extent is outside the format's range)
-	float gridMin[3];          // DNode4C: origin of the scene grid (at or below the scene's bounding box)
-	float gridStep[3];         // ... and its step per axis, a power of two: 65535 steps span the scene
 	const DTriIsect* isect;
 	const DTriShade* shade;
 	const DMaterial* materials;

@@ -114,8 +114,6 @@ struct BVH {
 	std::vector<DNode> nodes;
 	std::vector<DNode4> nodes4;       // the same tree collapsed to <= 4 children per node (empty for small scenes / analytic primitives)
 	std::vector<DNode4Q> nodes4q;     // nodes4 on the 8-bit grid (same indices, same children): what the kernels walk by default
-	std::vector<DNode4C> nodes4c;     // the same in 48 bytes (16-bit origins on a scene grid; same indices, inner child references x 3); empty when the scene's extent does not fit the format
-	float gridMin[3] = { 0, 0, 0 }, gridStep[3] = { 0, 0, 0 };
 	uint32_t stackNeed4 = 0;          // worst-case traversal-stack entries of nodes4 (sum of children - 1 along the deepest path)
 	std::vector<DNode4> leafList;     // scenes of <= 4 * RL_LEAFLIST_RECORDS leaves: every leaf's box, four to a record, no inner nodes (k_trace's flat walk; empty otherwise)
 	std::vector<uint32_t> triOrder;   // leaf order -> index into the flat triangle array

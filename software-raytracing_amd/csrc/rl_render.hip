@@ -610,39 +610,6 @@ __device__ __forceinline__ uint4 GLoadU4(const void* p, int i) { const rl_v4u v 
 	tn = fmaxf(tn, __builtin_fmaf((float)((nY_ >> sh) & 0xffu), Ay_, Bny_)); tf = fminf(tf, __builtin_fmaf((float)((fY_ >> sh) & 0xffu), Ay_, Bfy_)); \
 	tn = fmaxf(tn, __builtin_fmaf((float)((nZ_ >> sh) & 0xffu), Az_, Bnz_)); tf = fminf(tf, __builtin_fmaf((float)((fZ_ >> sh) & 0xffu), Az_, Bfz_)); \
 	tk = (tf * widenL_ < tn) ? INFINITY : tn; }
-// The same step on the 48-byte node (DNode4C, rl_device.h): three loads.  Plane q of a node whose origin sits at grid coordinate u has the ray parameter
-//   (gridMin + u * gridStep + q * gridStep * 2^(k - 8) - o) * inv  =  q * A + (u * SI + SB),   SI = gridStep * inv,  SB = (gridMin - o) * inv,  A = SI * 2^(k - 8):
-// SI and SB are the RAY's (RayGrid, set up when the ray is fetched), A is SI with k - 8 added to its exponent (an integer add on the bit pattern: SI is a normal
-// number far from the ends of the range -- CompactWide keeps gridStep within 2^-100 .. 2^20 and inv is a reciprocal of a normal float or the +-1e30 clamp),
-// the node adds two fma per axis.  Rounding: SB carries 2^-23 |SB|, each fma half an ulp of its result, i.e. at most 2^-22 (|SB| + 65536 |SI|) in all (255 |A| <= 2 *
-// 65536 |SI|: a node lies inside the scene's box); the near planes start from SBn = SB - E and the far planes from SBf = SB + E with E = 2^-20 (|SB| + 65536 |SI|),
-// four times that bound -- per ray and axis, nothing per node.  In space that is 1e-6 of the scene's extent (plus the ray origin's distance from it), on every axis
-// whatever its 1 / d.  As with DNode4Q the test only has to be conservative: the candidate rule decides what counts as a hit.
-struct RayGrid { V3 si, sbn, sbf; };
-__device__ __forceinline__ RayGrid MakeRayGrid(const DSceneView& S, V3 o, V3 inv /* clamped: no infinities */)
-{
-	RayGrid g;
-	g.si = v3(S.gridStep[0] * inv.x, S.gridStep[1] * inv.y, S.gridStep[2] * inv.z);
-	const V3 sb = v3((S.gridMin[0] - o.x) * inv.x, (S.gridMin[1] - o.y) * inv.y, (S.gridMin[2] - o.z) * inv.z);
-	const V3 e = v3((fabsf(sb.x) + 65536.0f * fabsf(g.si.x)) * 9.5367431640625e-7f, (fabsf(sb.y) + 65536.0f * fabsf(g.si.y)) * 9.5367431640625e-7f, (fabsf(sb.z) + 65536.0f * fabsf(g.si.z)) * 9.5367431640625e-7f);
-	g.sbn = sb - e; g.sbf = sb + e;
-	return g;
-}
-#define RL_WIDE_STEP_C(S_, cur_, G_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
-	const char* np_ = (const char*)(S_).nodes4c + ((size_t)(uint32_t)(cur_) << 4);   /* an inner reference is the record's offset in 16-byte units */ \
-	const uint4 h_ = GLoadU4(np_, 0); const uint4 p_ = GLoadU4(np_, 1); \
-	const uint4 chu_ = GLoadU4(np_, 2); const int4 ch = make_int4((int)chu_.x, (int)chu_.y, (int)chu_.z, (int)chu_.w); \
-	const float ux_ = (float)(h_.x & 0xffffu), uy_ = (float)(h_.x >> 16), uz_ = (float)(h_.y & 0xffffu); \
-	const float Ax_ = __int_as_float(__float_as_int((G_).si.x) + (int)((((h_.y >> 16) & 31u) << 23) - (8u << 23))); \
-	const float Ay_ = __int_as_float(__float_as_int((G_).si.y) + (int)((((h_.y >> 21) & 31u) << 23) - (8u << 23))); \
-	const float Az_ = __int_as_float(__float_as_int((G_).si.z) + (int)((((h_.y >> 26) & 31u) << 23) - (8u << 23))); \
-	const float Bnx_ = __builtin_fmaf(ux_, (G_).si.x, (G_).sbn.x), Bfx_ = __builtin_fmaf(ux_, (G_).si.x, (G_).sbf.x); \
-	const float Bny_ = __builtin_fmaf(uy_, (G_).si.y, (G_).sbn.y), Bfy_ = __builtin_fmaf(uy_, (G_).si.y, (G_).sbf.y); \
-	const float Bnz_ = __builtin_fmaf(uz_, (G_).si.z, (G_).sbn.z), Bfz_ = __builtin_fmaf(uz_, (G_).si.z, (G_).sbf.z); \
-	const uint32_t nX_ = (nx_) ? p_.y : h_.z, fX_ = (nx_) ? h_.z : p_.y, nY_ = (ny_) ? p_.z : h_.w, fY_ = (ny_) ? h_.w : p_.z, nZ_ = (nz_) ? p_.w : p_.x, fZ_ = (nz_) ? p_.x : p_.w; \
-	const float tMinL_ = (tMin_), tmxL_ = (tmx_), widenL_ = (widen_); \
-	float t0, t1, t2, t3; \
-	RL_QSLAB(0, t0) RL_QSLAB(8, t1) RL_QSLAB(16, t2) RL_QSLAB(24, t3)
 #define RL_WIDE_STEP_F(np_expr, o_, inv_, nx_, ny_, nz_, tMin_, tmx_, widen_, t0, t1, t2, t3, ch) \
 	const float4* np_ = (np_expr); \
 	const float4 lox_ = np_[0], loy_ = np_[1], loz_ = np_[2], hix_ = np_[3], hiy_ = np_[4], hiz_ = np_[5]; \
@@ -1942,23 +1909,7 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #endif
 
 
-struct Trav { V3 o, d, inv; RayGrid g; float rayTime; bool nx, ny, nz, anyhit; HitRec best; int cur, sp, leafI, leaf; };
-// The leaf slot (round 4).  In the vote-driven loop of k_trace_pool a wave executes ONE kind of step per turn -- a node step for the lanes at inner nodes or a
-// primitive step for the lanes at leaves -- and the other party waits: with 7 node steps and 5 to 6 triangle tests per ray about 55 % of the lanes took part in a
-// turn.  A lane now keeps the leaf it has reached in a slot of its own (T.leaf, T.leafI) and goes on with the next node of its stack (T.cur): most lanes can then take
-// part in EITHER kind of turn, and the vote picks the kind that serves more of them.  What it costs: a node popped before the pending leaf has been tested is tested
-// against the old best hit (a few per cent more node records per ray).  What it cannot change: the closest hit is the minimum over all accepted candidates whatever
-// the order they are met in (candidate rule + tie rule), so the bits stay the same -- the schedule tests and the fuzz compare.
-//   T.cur: an inner node (>= 0), TRAV_NONE (nothing left on the stack; the lane lives on through its leaf slot), TRAV_IDLE (no ray), or -- only while the slot
-//          is taken -- a second leaf (< 0) that waits for it;   T.leaf: 0 = free (node 0 is the root, never a leaf), else the leaf reference (< 0).
-// MEASURED, round 4, and not the default: 298 k-triangle frame 36.2 ms against 35.9 without the slot, the same scene from inside 387.1 against 381.3 -- with the
-// vote weighted towards node steps (leaf weight 4: 39.5 / 427 ms) far worse, towards leaf steps (12: 36.0 / 383) approaching the plain walk from above.  The
-// lanes a deferred leaf frees are paid for twice over by the nodes tested against a best hit that the leaf would have shortened: in this tree walk the ORDER
-// (leaf before the next node) is worth more than the occupancy of a turn.  Kept behind the switch because the schedule tests cover it.
-#ifndef RL_POOL_LEAFSLOT
-#define RL_POOL_LEAFSLOT 0
-#endif
-constexpr int TRAV_IDLE = 0x7fffffff, TRAV_NONE = 0x7ffffffe;
+struct Trav { V3 o, d, inv; float rayTime; bool nx, ny, nz, anyhit; HitRec best; int cur, sp, leafI; };
 
 // Single steps on the resumable state, for the vote-driven loop of k_trace_pool: a lane is either at an inner node
 // (cur >= 0), at a leaf (cur < 0, leafI = next primitive of it), or finished (both return true then).
@@ -1994,22 +1945,6 @@ __device__ __forceinline__ bool PopOrFinish(Trav& T, int* stk, int* ovf)
 	T.leafI = 0;
 	return false;
 }
-#if RL_POOL_LEAFSLOT
-template <int LSTACK, int STACK>
-__device__ __forceinline__ void PopNode(Trav& T, int* stk, int* ovf)
-{
-	if (T.sp == 0) { T.cur = TRAV_NONE; return; }
-	--T.sp;
-	T.cur = (LSTACK < STACK && T.sp >= LSTACK) ? ovf[T.sp - LSTACK] : stk[T.sp * RL_BLOCK];
-}
-// after T.cur changed: a leaf moves into the free slot and the next node comes off the stack.  True when the ray has nothing left to do.
-template <int LSTACK, int STACK>
-__device__ __forceinline__ bool Settle(Trav& T, int* stk, int* ovf)
-{
-	if (T.cur < 0 && T.leaf == 0) { T.leaf = T.cur; T.leafI = 0; PopNode<LSTACK, STACK>(T, stk, ovf); }
-	return T.cur == TRAV_NONE && T.leaf == 0;
-}
-#endif
 // min(t, FLT_MAX) for a t that is never NaN (a hit distance, or +inf): one integer minimum on the bit patterns -- floats below FLT_MAX, negative ones
 // included, are below 0x7f7fffff as signed integers too -- where fminf costs the compiler's canonicalising v_max t, t in front of the v_min
 __device__ __forceinline__ float ClampToFltMax(float t) { return __int_as_float(min(__float_as_int(t), 0x7f7fffff)); }
@@ -2027,16 +1962,6 @@ __device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMi
 	bool hr = Slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, tr, RL_POOL_WIDEN);
 	hl = hl && (k.x != DNODE_EMPTY);
 	hr = hr && (k.y != DNODE_EMPTY);
-#if RL_POOL_LEAFSLOT
-	if (hl && hr) {
-		const bool leftFirst = tl <= tr;
-		StackPush<LSTACK, STACK>(T, stk, ovf, leftFirst ? k.y : k.x);
-		T.cur = leftFirst ? k.x : k.y;
-	} else if (hl) T.cur = k.x;
-	else if (hr) T.cur = k.y;
-	else PopNode<LSTACK, STACK>(T, stk, ovf);
-	return Settle<LSTACK, STACK>(T, stk, ovf);
-#else
 	T.leafI = 0;
 	if (hl && hr) {
 		const bool leftFirst = tl <= tr;
@@ -2048,28 +1973,21 @@ __device__ __forceinline__ bool NodeStep(const DSceneView& S, Trav& T, float tMi
 	if (hl) { T.cur = k.x; return false; }
 	if (hr) { T.cur = k.y; return false; }
 	return PopOrFinish<LSTACK, STACK>(T, stk, ovf);
-#endif
 }
 // One step on the BVH4 (DNode4, 128 B): four slab tests, the hit children ordered by entry distance (5-comparator network),
 // the nearest followed, the others pushed far-to-near.  Counts as two 64-byte node records.
-template <int LSTACK, int STACK, int WIDE = 1>
+template <int LSTACK, int STACK>
 __device__ __forceinline__ bool NodeStep4(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c)
 {
 	RL_WSTEP(4);
-	c.nodes += RL_Q4 ? 1 : 2;   // node records fetched (a 48- or 64-byte grid node: one; a float-box node: two)
+	c.nodes += RL_Q4 ? 1 : 2;   // 64-byte records fetched
 	const float tmx = ClampToFltMax(T.best.t);
-	float t0, t1, t2, t3; int r0, r1, r2, r3;
-	if constexpr (WIDE == 2) {
-		RL_WIDE_STEP_C(S, T.cur, T.g, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, a0, a1, a2, a3, ch)
-		t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w;
-	} else {
 #if RL_Q4
-		RL_WIDE_STEP_Q(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, a0, a1, a2, a3, ch)   // T.inv was clamped when the ray was fetched
+	RL_WIDE_STEP_Q(S, T.cur, T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)   // T.inv was clamped when the ray was fetched
 #else
-		RL_WIDE_STEP_F((const float4*)(S.nodes4f + T.cur), T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, a0, a1, a2, a3, ch)
+	RL_WIDE_STEP_F((const float4*)(S.nodes4f + T.cur), T.o, T.inv, T.nx, T.ny, T.nz, tMin, tmx, RL_POOL_WIDEN, t0, t1, t2, t3, ch)
 #endif
-		t0 = a0; t1 = a1; t2 = a2; t3 = a3; r0 = ch.x; r1 = ch.y; r2 = ch.z; r3 = ch.w;
-	}
+	int r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
 	if (r0 == DNODE_EMPTY) t0 = INFINITY;
 	if (r1 == DNODE_EMPTY) t1 = INFINITY;
 	if (r2 == DNODE_EMPTY) t2 = INFINITY;
@@ -2077,16 +1995,6 @@ __device__ __forceinline__ bool NodeStep4(const DSceneView& S, Trav& T, float tM
 	#define RL_CSWAP(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; const int rr = sw ? rb : ra; rb = sw ? ra : rb; ra = rr; }
 	RL_CSWAP(t0, r0, t1, r1) RL_CSWAP(t2, r2, t3, r3) RL_CSWAP(t0, r0, t2, r2) RL_CSWAP(t1, r1, t3, r3) RL_CSWAP(t1, r1, t2, r2)
 	#undef RL_CSWAP
-#if RL_POOL_LEAFSLOT
-	if (!(t0 < INFINITY)) PopNode<LSTACK, STACK>(T, stk, ovf);
-	else {
-		if (t3 < INFINITY) StackPush<LSTACK, STACK>(T, stk, ovf, r3);
-		if (t2 < INFINITY) StackPush<LSTACK, STACK>(T, stk, ovf, r2);
-		if (t1 < INFINITY) StackPush<LSTACK, STACK>(T, stk, ovf, r1);
-		T.cur = r0;
-	}
-	return Settle<LSTACK, STACK>(T, stk, ovf);
-#else
 	T.leafI = 0;
 	if (!(t0 < INFINITY)) return PopOrFinish<LSTACK, STACK>(T, stk, ovf);
 	if (t3 < INFINITY) StackPush<LSTACK, STACK>(T, stk, ovf, r3);
@@ -2094,18 +2002,13 @@ __device__ __forceinline__ bool NodeStep4(const DSceneView& S, Trav& T, float tM
 	if (t1 < INFINITY) StackPush<LSTACK, STACK>(T, stk, ovf, r1);
 	T.cur = r0;
 	return false;
-#endif
 }
 
 template <int LSTACK, int STACK, bool PRIMS>
 __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c)
 {
 	RL_WSTEP(5);
-#if RL_POOL_LEAFSLOT
-	const uint32_t code = (uint32_t)~T.leaf;
-#else
 	const uint32_t code = (uint32_t)~T.cur;
-#endif
 	const int first = (int)(code >> 6);
 	const int count = (int)(code & 7u) + 1;
 	const bool alpha = (code & 8u) != 0;
@@ -2139,12 +2042,7 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 		}
 	}
 	if (++T.leafI < count) return false;
-#if RL_POOL_LEAFSLOT
-	T.leaf = 0;
-	return Settle<LSTACK, STACK>(T, stk, ovf);   // a second leaf that waited in T.cur takes the slot, the next node comes off the stack
-#else
 	return PopOrFinish<LSTACK, STACK>(T, stk, ovf);
-#endif
 }
 
 // sky part of the miss shader (reference render/renderer.cc:155-181)
@@ -2216,8 +2114,8 @@ template <int LSTACK, bool PRIMS, int K> struct PoolOcc {
 };
 
 // STACK: capacity of the traversal stack; LSTACK <= STACK: how much of it lives in LDS (the rest is private overflow)
-// WIDE: 0 the BVH2; 1 the BVH4 in 64-byte grid nodes (S.nodes4; RL_Q4 = 0: float boxes); 2 the BVH4 in 48-byte grid nodes (S.nodes4c: three loads per step)
-template <int STACK, bool PRIMS, int K, int LSTACK = STACK, int WIDE = 0>
+// WIDE: traverse the BVH4 (S.nodes4) instead of the BVH2
+template <int STACK, bool PRIMS, int K, int LSTACK = STACK, bool WIDE = false>
 __global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<LSTACK, PRIMS, K>::kBlocks))
 k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB* __restrict__ samplesK,
              float* __restrict__ pathStackK, unsigned long long* __restrict__ countersK, unsigned int* __restrict__ jobCounterK)
@@ -2267,11 +2165,11 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 	// A lane without a ray has T.cur == IDLE (no node index, not negative like a leaf reference): "busy", "at an inner node", "at a leaf" are then ONE integer
 	// compare each, and a wave vote on a compare is that compare's lane mask.  (A vote on a bool that is not a compare -- `busy && T.cur >= 0` -- makes the
 	// compiler write the bool out as 0 / 1 and compare it with zero again: v_cndmask + v_cmp_ne per vote, four votes per traversal step.)
-	constexpr int IDLE = TRAV_IDLE;
+	constexpr int IDLE = 0x7fffffff;
 	int mySlot = 0;
 	Trav T;
 	T.o = T.d = T.inv = v3s(0.0f); T.rayTime = 0.0f; T.nx = T.ny = T.nz = T.anyhit = false;
-	T.best.t = INFINITY; T.best.a = T.best.b = 0.0f; T.best.tri = -1; T.cur = IDLE; T.sp = 0; T.leafI = 0; T.leaf = 0;
+	T.best.t = INFINITY; T.best.a = T.best.b = 0.0f; T.best.tri = -1; T.cur = IDLE; T.sp = 0; T.leafI = 0;
 #ifdef RL_DIAG_STAMPS
 	unsigned long long stampAcc[4] = { 0, 0, 0, 0 };
 	{ RL_ARGS(); c.diag = counters; }
@@ -2437,15 +2335,11 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 			// the wide nodes' base address in a VGPR pair for the phase: as one of the loop's many uniform values it would be spilled to a VGPR's lanes and
 			// read back (two v_readlane, 4 issue cycles each) at every traversal step
 			DSceneView St = S;
-			if constexpr (WIDE == 2) { const DNode4C* pn = S.nodes4c; asm volatile("" : "+v"(pn)); St.nodes4c = pn; }
-			else { const DNode4Q* pn = S.nodes4; asm volatile("" : "+v"(pn)); St.nodes4 = pn; }
+			{ const DNode4Q* pn = S.nodes4; asm volatile("" : "+v"(pn)); St.nodes4 = pn; }
 #else
 			const DSceneView& St = S;
 #endif
 			WaveLdsSync();
-			// a straggler's grid parameters are made again from its origin and (clamped) reciprocal -- the same values -- so that they are not alive across the
-			// shading code, which needs every register it can get
-			if constexpr (WIDE == 2) T.g = MakeRayGrid(S, T.o, T.inv);   // (every lane: a conditional assignment would keep the old value alive)
 			uint32_t nextSlot = 0;
 			uint32_t finished = 0;      // rays completed in this phase (wave-uniform)
 			for (;;) {
@@ -2461,16 +2355,9 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 							T.rayTime = PRIMS ? pool[F_TIME][slot] : 0.0f;
 							T.inv = v3(FastRcp(T.d.x), FastRcp(T.d.y), FastRcp(T.d.z));
 							if (WIDE && RL_Q4) T.inv = ClampInv(T.inv);   // only the grid nodes' fused plane arithmetic wants finite reciprocals; Slab() relies on +-inf / NaN
-							if constexpr (WIDE == 2) {
-								// the 48-byte node's planes come out of the RAY's grid parameters; a reciprocal beyond 2^60 is held there (its axis stands still at the
-								// scale of the scene either way, and the per-ray error term E covers far more than the difference: RL_WIDE_STEP_C)
-								const float cap = 1.152921504606846976e18f;
-								T.inv = v3(fminf(fmaxf(T.inv.x, -cap), cap), fminf(fmaxf(T.inv.y, -cap), cap), fminf(fmaxf(T.inv.z, -cap), cap));
-								T.g = MakeRayGrid(S, T.o, T.inv);
-							}
 							T.nx = T.inv.x < 0.0f; T.ny = T.inv.y < 0.0f; T.nz = T.inv.z < 0.0f;
 							T.best.t = INFINITY; T.best.tri = -1; T.best.a = 0.0f; T.best.b = 0.0f;
-							T.cur = 0; T.sp = 0; T.leafI = 0; T.leaf = 0;
+							T.cur = 0; T.sp = 0; T.leafI = 0;
 							mySlot = (int)slot;
 							pool[F_TRI][slot] = __int_as_float(T.anyhit ? Q_PENDING_SHADOW : Q_PENDING);
 							c.rays++;
@@ -2489,19 +2376,12 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 				// one step for the larger (cost-weighted) party, lanes at inner nodes or lanes at leaves, until enough lanes
 				// have finished to make a fetch worth it
 				int nb;
-#if RL_POOL_LEAFSLOT
-				int nBusyTurn = nBusy;
-#endif
 				do {
-#if RL_POOL_LEAFSLOT
-					const bool atNode = (uint32_t)T.cur < (uint32_t)TRAV_NONE, atLeaf = T.leaf < 0;   // (both, for most lanes: the vote serves the larger party)
-#else
 					const bool atNode = (uint32_t)T.cur < (uint32_t)IDLE, atLeaf = T.cur < 0;
-#endif
 					const int nN = (int)__popcll(Ballot(atNode)), nL = (int)__popcll(Ballot(atLeaf));
 					bool fin = false;
 					const bool nodeTurn = nN * (WIDE ? RL_POOL_WNODE4 : RL_POOL_WNODE) >= nL * (WIDE ? RL_POOL_WLEAF4 : RL_POOL_WLEAF);
-					if (nodeTurn) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK, WIDE>(St, T, tMinC, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, tMinC, stk, ovf, c); }
+					if (nodeTurn) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(St, T, tMinC, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, tMinC, stk, ovf, c); }
 					else { if (atLeaf) fin = LeafStep<LSTACK, STACK, PRIMS>(S, T, P.rayTMin, stk, ovf, c); }
 					if (fin) {
 						const bool hit = T.best.tri >= 0;
@@ -2510,18 +2390,13 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 						else if (!hit) q = Q_MISS;
 						pool[F_T][mySlot] = T.best.t; pool[F_TRI][mySlot] = __int_as_float(q);
 						pool[F_A][mySlot] = T.best.a; pool[F_B][mySlot] = T.best.b;
-						T.cur = IDLE; T.leaf = 0;
-						}
+						T.cur = IDLE;
+					}
 #ifdef RL_POOL_WATCHDOG
-					if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); T.cur = IDLE; T.leaf = 0; wdAbort = true; }
+					if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); T.cur = IDLE; wdAbort = true; }
 #endif
 					nb = (int)__popcll(Ballot(T.cur != IDLE));
-#if RL_POOL_LEAFSLOT
-					finished += (uint32_t)(nBusyTurn - nb);   // (a lane may count in both parties: the finished are the difference of two busy counts)
-					nBusyTurn = nb;
-#else
 					finished += (uint32_t)(nN + nL - nb);   // whoever was busy and is not any more has finished its ray
-#endif
 				} while (nb > (nextSlot < (uint32_t)PP ? RL_POOL_KEEP : (finished > 0 ? cutAt : 0)));
 			}
 			WaveLdsSync();
@@ -2664,10 +2539,9 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 #endif
 // The instances the runtime selects from (rl_runtime.inl SelectTraceKernel): defined in rl_render_pool.hip's translation unit, referenced from this one.
 #define RL_POOL_INSTANCES(X) \
-	X(16, false, 2, 16, 0) X(16, false, 3, 16, 0) X(16, false, 4, 16, 0) X(32, false, 2, 32, 0) X(32, false, 3, 32, 0) X(32, false, 4, 32, 0) \
-	X(32, false, 2, 4, 0) X(32, false, 2, RL_POOL_SHORT_LSTACK, 0) \
-	X(32, false, 2, 32, 1) X(64, false, 2, 32, 1) X(32, false, 2, RL_POOL_SHORT_LSTACK, 1) X(64, false, 2, RL_POOL_SHORT_LSTACK, 1) \
-	X(32, false, 2, RL_POOL_SHORT_LSTACK, 2) X(64, false, 2, RL_POOL_SHORT_LSTACK, 2)
+	X(16, false, 2, 16, false) X(16, false, 3, 16, false) X(16, false, 4, 16, false) X(32, false, 2, 32, false) X(32, false, 3, 32, false) X(32, false, 4, 32, false) \
+	X(32, false, 2, 4, false) X(32, false, 2, RL_POOL_SHORT_LSTACK, false) \
+	X(32, false, 2, 32, true) X(64, false, 2, 32, true) X(32, false, 2, RL_POOL_SHORT_LSTACK, true) X(64, false, 2, RL_POOL_SHORT_LSTACK, true)
 #ifdef RL_TU_POOL
 #define RL_POOL_X(a, b, c, d, e) template __global__ void k_trace_pool<a, b, c, d, e>(const DRenderParams, const DSceneView, const SkyRot, SampleRGB* __restrict__, float* __restrict__, unsigned long long* __restrict__, unsigned int* __restrict__);
 #else

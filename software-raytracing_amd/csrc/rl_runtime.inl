@@ -24,7 +24,7 @@ namespace rl {
 // One physical device's copy of a scene.
 struct DeviceSceneCopy {
 	int device = 0;
-	DNode4Q* nodes4 = nullptr; DNode4* nodes4f = nullptr; DNode4* leafList = nullptr; DNode4C* nodes4c = nullptr;
+	DNode4Q* nodes4 = nullptr; DNode4* nodes4f = nullptr; DNode4* leafList = nullptr;
 	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
 	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
 	DSphere* spheres = nullptr; DCube* cubes = nullptr;
@@ -37,7 +37,7 @@ struct DeviceScene {
 	std::vector<DeviceSceneCopy*> copy;   // by device slot (Runtime::devices)
 	SkyRot skyRot;
 	uint32_t bvhDepth = 0, stackNeed4 = 0;
-	bool hasNodes4 = false, hasNodes4c = false;
+	bool hasNodes4 = false;
 	double boundsMin[3] = { 0, 0, 0 }, boundsMax[3] = { 0, 0, 0 };   // of all triangle vertices (CullCells)
 	bool boundsValid = false;                                        // triangles only, every coordinate finite
 };
@@ -282,7 +282,7 @@ void FreeCopy(DeviceSceneCopy* C)
 {
 	if (!C) return;
 	(void)hipSetDevice(C->device);
-	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4c) (void)hipFree(C->nodes4c); if (C->nodes4f) (void)hipFree(C->nodes4f); if (C->leafList) (void)hipFree(C->leafList); (void)hipFree(C->isect); (void)hipFree(C->shade);
+	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4f) (void)hipFree(C->nodes4f); if (C->leafList) (void)hipFree(C->leafList); (void)hipFree(C->isect); (void)hipFree(C->shade);
 	(void)hipFree(C->materials); (void)hipFree(C->textures); (void)hipFree(C->texels); (void)hipFree(C->spheres); (void)hipFree(C->cubes);
 	if (C->sky) (void)hipFree(C->sky);
 	delete C;
@@ -403,7 +403,7 @@ bool UploadScene(Scene& sc)
 	}
 
 	DeviceScene* D = new DeviceScene;
-	D->bvhDepth = sc.bvh.depth; D->stackNeed4 = sc.bvh.stackNeed4; D->hasNodes4 = !sc.bvh.nodes4.empty(); D->hasNodes4c = RL_Q4 && !sc.bvh.nodes4c.empty();
+	D->bvhDepth = sc.bvh.depth; D->stackNeed4 = sc.bvh.stackNeed4; D->hasNodes4 = !sc.bvh.nodes4.empty();
 	{   // Rotator(yaw = 90).rotate rows, reference geom/transform.cc:47-65 (host libm, as the reference)
 		const float pi_f = (float)3.1415926535897932385;
 		const float ry = 90.0f * pi_f / 180.0f, rp = 0.0f * pi_f / 180.0f, rr = 0.0f * pi_f / 180.0f;
@@ -438,7 +438,6 @@ bool UploadScene(Scene& sc)
 		// where the grid's extra arithmetic buys nothing (Cornell frame: 22.8 ms on float boxes, 23.8 ms on the grid)
 		const bool wantFull = D->hasNodes4 && (!RL_Q4 || sc.triangles.size() < 4096);
 		if (ok && D->hasNodes4 && RL_Q4) ok = Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size());
-		if (ok && D->hasNodes4 && RL_Q4 && !sc.bvh.nodes4c.empty()) ok = Upload(C->nodes4c, sc.bvh.nodes4c.data(), sc.bvh.nodes4c.size());
 		if (ok && wantFull) ok = Upload(C->nodes4f, sc.bvh.nodes4.data(), sc.bvh.nodes4.size());
 		if (ok && wantFull && !sc.bvh.leafList.empty()) ok = Upload(C->leafList, sc.bvh.leafList.data(), sc.bvh.leafList.size());
 		ok = ok && Upload(C->isect, isect.data(), n) && Upload(C->shade, shade.data(), n);
@@ -446,8 +445,7 @@ bool UploadScene(Scene& sc)
 		ok = ok && Upload(C->spheres, dsph.data(), dsph.size()) && Upload(C->cubes, dcub.data(), dcub.size());
 		if (!ok) { Log("UploadScene: device %d could not take the scene", C->device); FreeScene(D); return false; }   // nothing of a failed upload is left behind
 		DSceneView& V = C->view;
-		V.nodes = C->nodes; V.nodes4 = C->nodes4; V.nodes4f = C->nodes4f; V.nodes4c = C->nodes4c;
-		for (int k = 0; k < 3; ++k) { V.gridMin[k] = sc.bvh.gridMin[k]; V.gridStep[k] = sc.bvh.gridStep[k]; } V.isect = C->isect; V.shade = C->shade; V.materials = C->materials;
+		V.nodes = C->nodes; V.nodes4 = C->nodes4; V.nodes4f = C->nodes4f; V.isect = C->isect; V.shade = C->shade; V.materials = C->materials;
 		V.textures = C->textures; V.texels = C->texels; V.spheres = C->spheres; V.cubes = C->cubes;
 		V.sunIlluminance[0] = sc.sunIlluminance.x; V.sunIlluminance[1] = sc.sunIlluminance.y; V.sunIlluminance[2] = sc.sunIlluminance.z;
 		V.sunDirection[0] = sc.sunDirection.x; V.sunDirection[1] = sc.sunDirection.y; V.sunDirection[2] = sc.sunDirection.z;
@@ -504,12 +502,8 @@ TraceKernel SelectTraceKernel(int& poolK, const DeviceScene* D, bool& shortStack
 		const bool wantWide = haveWide && (w ? atoi(w) != 0 : true);
 		if (poolK == 2 && wantWide) {
 			wide = true; shortStack = true;
-			if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, 1> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, 1>; }
-			// the 48-byte nodes (three loads per step) whenever the scene carries them; RAYLIB_NODE48=0 at render time walks the 64-byte ones
-			const char* c48 = getenv("RAYLIB_NODE48");
-			if (D->hasNodes4c && (c48 ? atoi(c48) != 0 : true))
-				return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, 2> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, 2>;
-			return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, 1> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, 1>;
+			if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, true>; }
+			return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, true>;
 		}
 		if constexpr (STACK == 32) {
 			const bool wantShort = e ? atoi(e) != 0 : D->bvhDepth <= RL_POOL_SHORT_MAXDEPTH;

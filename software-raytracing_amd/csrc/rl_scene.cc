@@ -152,7 +152,6 @@ bool Scene::BuildAccel(float t0, float t1)
 		for (DNode& n : bvh.nodes) { patch(n.left); patch(n.right); }
 		for (DNode4& n : bvh.nodes4) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 		for (DNode4Q& n : bvh.nodes4q) for (int k = 0; k < 4; ++k) patch(n.child[k]);
-		for (DNode4C& n : bvh.nodes4c) for (int k = 0; k < 4; ++k) patch(n.child[k]);   // (an inner reference is >= 0 here too: left alone)
 		for (DNode4& n : bvh.leafList) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 	}
 	Log("Scene finalized: %u triangles, %u BVH nodes, depth %u, SAH cost %.2f (BVH build %.2f s)",
