@@ -7,7 +7,7 @@
 
 namespace rl {
 
-// Which of a rank's cells can a camera ray meet the scene in?  With no sky panorama (a pinhole camera or a thin lens: round 4) every sample of every other cell ends in the
+// Which of a rank's cells can a camera ray meet the scene in?  With no sky panorama (a pinhole camera or a thin lens: round 4; a sky panorama adds each sample's own texel, looked up by k_resolve) every sample of every other cell ends in the
 // miss shader with the same value (nothing, or the sun's illuminance when the sun is not hidden from the camera either), and the megakernel used to
 // find that out sample by sample: generate the ray, test it against the root's boxes, store the constant -- 63 % of the Cornell frame's camera samples,
 // 89 % of the 298 k-triangle frame's.  Here the scene's bounding box is projected onto the image plane once per frame (double precision, the eight
@@ -21,7 +21,8 @@ bool CullCells(const CullScene& DS, const DCamera& cam, int32_t maxPathLength, f
                uint32_t cellsX, uint32_t cellFirst, uint32_t stride, uint32_t numLocalCells, CullResult& out)
 {
 	if (const char* e = getenv("RAYLIB_CULL_CELLS")) if (atoi(e) == 0) return false;
-	if (DS.prims || !DS.boundsValid || DS.hasSky || maxPathLength <= 0 || numLocalCells == 0) return false;
+	// (a sky panorama does not stand in the way: the dropped cells' samples then differ by their sky texel, and k_resolve looks it up per sample -- rl_render.hip)
+	if (DS.prims || !DS.boundsValid || maxPathLength <= 0 || numLocalCells == 0) return false;
 	const double lensR = std::fabs((double)cam.lensRadius);   // the console front-end renders with aperture 0.01 (reference src/main.cc:24,421-425)
 	if (!std::isfinite(lensR)) return false;
 	// A negative rayTMin lets a query find hits BEHIND its origin (the tree walk and the tests support it): a camera ray that points away from the box, or a sun

@@ -179,7 +179,8 @@ struct DRenderParams {
 	const uint32_t* activeCells;
 	const uint8_t*  cellEmpty;
 	uint32_t numActiveCells;
-	float    emptyL[3];
+	float    emptyL[3];        // the sun's part of that constant (0 + illuminance, or 0)
+	uint32_t emptySky;         // 1: the scene has a sky panorama -- a dropped cell's samples differ by their sky texel: k_resolve generates each sample's camera ray and looks it up
 	uint32_t magicSamples;     // floor(2^32 / sampleCount), floor(2^32 / cellsX): division by multiply-high in DecodeJob
 	uint32_t magicCellsX;
 	uint64_t seedMixed;        // raylib_rng_mix64(seed), hoisted out of the per-sample stream set-up

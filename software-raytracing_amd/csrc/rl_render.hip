@@ -2554,8 +2554,9 @@ RL_POOL_INSTANCES(RL_POOL_X)
 // Sequential per-pixel sum of this batch's samples, then (last batch) the mean.
 // reference render/renderer.cc:244-248 + core/vec3.h:214-220 (operator/= multiplies by 1/SPP)
 __global__ void __launch_bounds__(RL_BLOCK)
-k_resolve(const DRenderParams P, const SampleRGB* __restrict__ samples, float4* __restrict__ accum, float4* __restrict__ out, int firstBatch, int lastBatch)
+k_resolve(const DRenderParams P, const DSceneView S, const SkyRot R, const SampleRGB* __restrict__ samples, float4* __restrict__ accum, float4* __restrict__ out, int firstBatch, int lastBatch)
 {
+	RL_MATH_PROLOGUE();
 	const uint32_t numSlots = P.numLocalCells * 64u;
 	const uint32_t slot = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (slot >= numSlots) return;
@@ -2567,7 +2568,23 @@ k_resolve(const DRenderParams P, const SampleRGB* __restrict__ samples, float4* 
 	if (valid) {
 		if (!firstBatch) a = accum[slot];
 		if (P.cellEmpty && P.cellEmpty[cellLocal]) {
-			// a cell outside the scene's silhouette: every sample is the miss shader's constant, added up sample by sample as if it had been stored
+			// a cell outside the scene's silhouette (rl_cull.cc): none of its samples can meet the scene, every one of them is the miss shader's value -- the sun's
+			// illuminance or nothing, the same for all; with a sky panorama the texel its camera ray points at on top (renderer.cc:155-199), so the ray is
+			// generated here exactly as the megakernel generates it (same stream, same draws: jitter, lens, shutter) -- added up sample by sample as if stored
+			if (P.emptySky) {
+				Counters c; c.rays = c.nodes = c.tris = c.shaded = c.texels = c.samples = c.trips = 0; RL_DIAG_BIND(c);
+				for (uint32_t s = 0; s < P.sampleCount; ++s) {
+					const uint32_t sidx = P.sampleBegin + s;
+					Rng g; g.s = raylib_rng_begin_mixed(P.seedMixed, y * P.width + x, sidx);
+					float u, v;
+					PixelUV(P, x, y, sidx, g, u, v);
+					V3 o, d; float rayTime;
+					CameraRay(P.camera, u, v, g, o, d, rayTime);
+					V3 L = MissSky(S, R, d, c);
+					if (S.hasSun) L = L + ld3(S.sunIlluminance);
+					a.x += L.x; a.y += L.y; a.z += L.z;
+				}
+			} else
 			for (uint32_t s = 0; s < P.sampleCount; ++s) { a.x += P.emptyL[0]; a.y += P.emptyL[1]; a.z += P.emptyL[2]; }
 		} else
 		for (uint32_t s = 0; s < P.sampleCount; ++s) {

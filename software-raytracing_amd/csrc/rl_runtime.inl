@@ -665,6 +665,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				numActive = R.cullActive[q];
 				P.activeCells = R.cellList[q]; P.cellEmpty = (const uint8_t*)(R.cellList[q] + R.cellListCells[q]); P.numActiveCells = numActive;
 				P.emptyL[0] = R.cullL[q][0]; P.emptyL[1] = R.cullL[q][1]; P.emptyL[2] = R.cullL[q][2];
+				P.emptySky = traceView.sky ? 1u : 0u;
 				pend.culledSamples = R.cullEmptyPixels[q] * (uint64_t)SPP; pend.culledRaysPerSample = R.cullRays[q];
 			}
 			pend.culledCells = numLocalCells - numActive; pend.listedCells = numActive;
@@ -744,7 +745,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 			HIP_OK(hipEventRecord(R.ev[q][3], R.stream));
 			const uint32_t rblocks = (numSlots + RL_BLOCK - 1) / RL_BLOCK;
 			hipLaunchKernelGGL(k_resolve, dim3(rblocks), dim3(RL_BLOCK), 0, R.stream,
-			                   P, R.samples, R.accum, out, (int)(s0 == 0), (int)(s0 + cnt >= SPP));
+			                   P, traceView, DS->skyRot, R.samples, R.accum, out, (int)(s0 == 0), (int)(s0 + cnt >= SPP));
 			HIP_OK(hipGetLastError());
 			++pend.launches;
 			if (s0 + cnt < SPP) {   // the event pair is reused by the next batch; the last batch's pair is read after the one final sync

@@ -184,6 +184,36 @@ def test_cells_outside_the_scenes_silhouette_are_not_traced_and_nothing_changes(
             lens_dropped += int(st1["culledCells"] > 0)
             ses.close()
     assert lens_dropped == 6, lens_dropped
+    # A sky panorama (the console front-end renders with an HDR panorama and a lens: reference src/main.cc:24,421-425,450): the dropped cells' samples are not a
+    # constant any more -- every one is its own sky texel (plus the sun) -- and k_resolve generates each sample's camera ray to look it up.  Same bits as with every
+    # cell traced, same totals; and the oracle on a window of pure sky and on one across the silhouette.
+    sky = helpers.scenes.sky_panorama()
+    sky_dropped = 0
+    for aperture, sun in ((0.0, (0.0, 0.0, 0.0)), (0.0, (9.0, 8.0, 7.0)), (0.01, (9.0, 8.0, 7.0)), (0.3, (0.0, 0.0, 0.0))):
+        ses = binding.SceneSession(gpu_lib, obj, (0.5, 1.2, 9.0), (0.0, 1.0, -1.0), 40.0, 200 / 120, sun=sun, sun_dir=(-1.0, -1.0, 0.0), aperture=aperture, focal=7.0, sky_image=sky)
+        for spp in (1, 5):
+            img = ses.render(200, 120, spp)
+            st1 = ses.stats().as_dict()
+            monkeypatch.setenv("RAYLIB_CULL_CELLS", "0")
+            ref = ses.render(200, 120, spp)
+            st0 = ses.stats().as_dict()
+            monkeypatch.delenv("RAYLIB_CULL_CELLS")
+            assert np.array_equal(bits(img), bits(ref)), (aperture, sun, spp)
+            for k in ("frameRays", "frameSamples", "frameNodes", "shadedHits", "trisTested", "pixels"):
+                assert st0[k] == st1[k], (k, st0[k], st1[k], aperture, sun)
+            sky_dropped += int(st1["culledCells"] > 0)
+        if aperture == 0.0 and any(sun):
+            flat.sun_illuminance = sun; flat.sun_direction = (-1.0, -1.0, 0.0)
+            flat.textures.append(np.ascontiguousarray(sky, np.float32)); flat.sky_texture = len(flat.textures) - 1
+            scene = oracle.scene_create(flat, 1)
+            cam = ffi.make_camera((0.5, 1.2, 9.0), (0.0, 1.0, -1.0), 40.0, 200 / 120, 0.0, 7.0)   # (the focal distance scales the image plane: same rays only up to rounding)
+            for (x0, y0, size) in ((0, 0, 24), (60, 30, 40)):
+                same, tied, untied, err = window_mismatches_without_a_tie(oracle, scene, cam, ffi.make_settings(200, 120, 5), img, x0, y0, size)
+                assert untied == 0 and same + tied == size * size and tied <= 8, (x0, y0, same, tied, untied, err)
+            oracle.scene_destroy(scene)
+            flat.textures.pop(); flat.sky_texture = -1
+        ses.close()
+    assert sky_dropped == 8, sky_dropped
     # A negative rayTMin lets a query find hits BEHIND its origin: with the light travelling from the box towards a camera that looks at the box from
     # downstream, the sun's occlusion query (origin: the camera, direction: away from the box) then meets the box at t < 0 and every traced sample loses
     # the sun -- a dropped cell filled with the sun's illuminance would be wrong.  Such a frame is not culled at all (csrc/rl_cull.cc).
