@@ -184,6 +184,9 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
                 "achieved_gcyc_per_s": ach, "peak_gcyc_per_s": VALU_PEAK_GCYC, "frac_of_spec_peak": ach / VALU_PEAK_GCYC,
                 # the same cycles against the cycles the launch really had (GRBM_GUI_ACTIVE / 8 of the profiled pass: the clock the chip held)
                 "frac_of_profiled_pass_cycles": rec.get("valu_weighted_busy_fraction"), "unweighted_2cyc_busy_fraction": rec.get("valu_busy_fraction"),
+                "weighted_busy_bounds_of_profiled_pass": rec.get("valu_weighted_busy_bounds"),
+                # hardware's own view (SQ_ACTIVE_INST_VALU: the port's time in 4-clock units, a 2-cycle instruction charged like a 4-cycle one -- an upper bound)
+                "hw_active_inst_valu_x4_over_pass_cycles": rec.get("valu_hw_active_x4_fraction"), "hw_refined_fraction_of_pass_cycles": rec.get("valu_hw_refined_fraction"),
                 "lane_utilisation": rec.get("valu_lane_utilisation"), "wave_wait_fraction": rec.get("wave_wait_fraction"),
                 "waves_per_simd": rec.get("waves_per_simd"), "salu_insts_per_launch": rec.get("salu_insts_per_launch"),
                 "profiled_clock_ghz": rec.get("profiled_clock_ghz")}

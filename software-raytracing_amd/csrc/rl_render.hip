@@ -730,6 +730,17 @@ __device__ __forceinline__ bool TraverseLeafList(const DSceneView& S, V3 o, V3 d
 		const int first = (int)(code >> 6);
 		const int count = (int)(code & 7u) + 1;
 		const bool alpha = (code & 8u) != 0;
+#if defined(RL_DIAG_STAMPS) && RL_DIAG_STAMPS >= 2
+		// diagnostic build: what regrouping the (ray, triangle) pairs of this round across the wave could save at best.  The lanes that visit a leaf in this
+		// round test `count` triangles each; dealt evenly to 64 lanes the round's pairs would take ceil(pairs / 64) wave steps instead of max(count) -- and no
+		// fewer than one, because a ray's next leaf depends on what this one yields (the nearest-first cut).  Summed in slot 7 next to the steps taken (slot 5).
+		{
+			uint32_t pairs = 0;
+			for (int cc = 1; cc <= 8; ++cc) pairs += (uint32_t)cc * (uint32_t)__popcll(Ballot(count == cc));
+			const unsigned long long em_ = Ballot(true);
+			if (c.diag && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)em_) - 1u) atomicAdd(&c.diag[CNT_COUNT + 7], (unsigned long long)((pairs + 63u) / 64u));
+		}
+#endif
 		for (int i = 0; i < count; ++i) {
 			const float4* tr = sm + LdsAt<2>::ISECT + (first + i) * 6;
 			const float4 q0 = tr[0], q1 = tr[1], q2 = tr[2], q3 = tr[3];

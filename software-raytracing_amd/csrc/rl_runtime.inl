@@ -836,6 +836,9 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 	if (getenv("RAYLIB_PRINT_STAMPS")) {
 		const double tot = (double)(cnt[CNT_COUNT] + cnt[CNT_COUNT + 1] + cnt[CNT_COUNT + 2] + cnt[CNT_COUNT + 3]);
 		Log("wave steps: node %llu (lane steps %llu, eff %.3f)  tri %llu (lane %llu, eff %.3f)  leaf rounds %llu  trips %llu", cnt[CNT_COUNT + 4], cnt[CNT_NODES], cnt[CNT_NODES] / (64.0 * cnt[CNT_COUNT + 4] + 1), cnt[CNT_COUNT + 5], cnt[CNT_TRIS], cnt[CNT_TRIS] / (64.0 * cnt[CNT_COUNT + 5] + 1), cnt[CNT_COUNT + 6], cnt[CNT_TRIPS]);
+#if defined(RL_DIAG_STAMPS) && RL_DIAG_STAMPS >= 2
+		if (cnt[CNT_COUNT + 7]) Log("leaf list: %llu triangle wave steps taken; %llu if every round's (ray, triangle) pairs were dealt evenly to the wave's 64 lanes (the bound of any regrouping: a round cannot take less than one step)", cnt[CNT_COUNT + 5], cnt[CNT_COUNT + 7]);
+#endif
 		if (tot > 0) Log("shade split (of all): surface+material %.3f scatter %.3f emit+store %.3f", cnt[CNT_COUNT + 8] / tot, cnt[CNT_COUNT + 9] / tot, cnt[CNT_COUNT + 10] / tot);
 		if (tot > 0) Log("microfacet split (of all): setup %.3f beckmann sample %.3f brdf+pdf %.3f | newton wave iters %llu lane iters %llu (eff %.3f) | microfacet wave calls %llu lanes %llu (eff %.3f)", cnt[CNT_COUNT + 12] / tot, cnt[CNT_COUNT + 13] / tot, cnt[CNT_COUNT + 14] / tot, cnt[CNT_COUNT + 16], cnt[CNT_COUNT + 17], cnt[CNT_COUNT + 17] / (64.0 * cnt[CNT_COUNT + 16] + 1), cnt[CNT_COUNT + 18], cnt[CNT_COUNT + 19], cnt[CNT_COUNT + 19] / (64.0 * cnt[CNT_COUNT + 18] + 1));
 		{

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
 out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 res = json.load(open(out_path)) if os.path.exists(out_path) else {}
-TAG = os.environ.get("ROUND_TAG", "r03")
+TAG = os.environ.get("ROUND_TAG", "r04")
 SIMDS = 256 * 4
 NOMINAL = {"FMA_F32": 2, "MUL_F32": 2, "ADD_F32": 2, "FMA_F64": 4, "MUL_F64": 4, "ADD_F64": 4, "TRANS_F32": 8, "TRANS_F64": 16, "CVT": 4, "INT64": 4}
 
@@ -72,7 +72,17 @@ for arg in sys.argv[1:]:
         "cycles_per_launch": cycles,
         "profiled_clock_ghz": None,
         "valu_weighted_busy_fraction": est / SIMDS / cycles,
-        "valu_weighted_busy_bounds": [lo / SIMDS / cycles, hi / SIMDS / cycles],
+        "valu_weighted_busy_bounds": [lo / SIMDS / cycles, min(1.0, hi / SIMDS / cycles)],   # (the port cannot be busier than always)
+        # The one hardware counter of the VALU port's TIME, and what it can and cannot see (round 4, tools/valu_busy_pmc.sh over the single-opcode streams of
+        # tools/valu_calib: profiles/r04_valu_busy_counters.txt): SQ_ACTIVE_INST_VALU counts max(1, issue cycles / 4) per instruction -- 1 for a 2-cycle AND for a
+        # 4-cycle opcode, 2 for the 8-cycle transcendentals, 4 for the 16-cycle f64 ones -- i.e. the port's time in units of 4 clocks with every 2-cycle instruction
+        # charged 4.  x4 over the launch's SIMD cycles it is an UPPER bound (above 1 where the code is full of 2-cycle opcodes: that excess is itself the
+        # hardware saying they exist); taking 2 clocks back for every instruction the hardware classes as ADD / MUL / FMA F32 and for the 2-cycle share of
+        # INT32 / OTHER (static mix) gives a figure that agrees with the class-weighted one because it leans on the same model for that share.
+        "valu_hw_active_inst_valu": m["SQ_ACTIVE_INST_VALU"],
+        "valu_hw_active_x4_fraction": 4.0 * m["SQ_ACTIVE_INST_VALU"] / SIMDS / cycles,
+        "valu_hw_refined_fraction": (4.0 * m["SQ_ACTIVE_INST_VALU"] - 2.0 * (counts["FMA_F32"] + counts["MUL_F32"] + counts["ADD_F32"])
+                                     - 2.0 * (counts["INT32"] * (4.0 - mix.get("INT32", 3.0)) / 2.0 + other * (4.0 - mix.get("OTHER", 3.5)) / 2.0)) / SIMDS / cycles,
         # round 2's figure, kept for comparison: every VALU instruction charged the 2 cycles of a v_fma_f32
         "valu_busy_fraction": 2.0 * m["SQ_INSTS_VALU"] / SIMDS / cycles,
         "wave_wait_fraction": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
