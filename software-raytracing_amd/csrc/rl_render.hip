@@ -1889,7 +1889,9 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #define Q_MISS     (-7)   /* result of a closest-hit query that hit nothing (distinct from Q_CLOSEST: a straggler may deliver it while the next phase is handing out slots) */
 #define Q_CLEAR    (-8)   /* result of a sun query: nothing in the way */
 #define RL_POOL_WIDEN RL_BOX_WIDEN
+#ifndef RL_POOL_SHORT_LSTACK
 #define RL_POOL_SHORT_LSTACK 18   /* LDS entries of the "short" 32-deep stack: 18 KiB + 20.5 KiB pool + 640 B of libm tables = 4 workgroups per CU */
+#endif
 #define RL_POOL_SHORT_MAXDEPTH 24 /* BVH depth up to which the short variant is used (deeper trees overflow too often: measured) */
 #ifndef RL_POOL_MAXBLOCKS
 #define RL_POOL_MAXBLOCKS 4   /* workgroups per CU the pool kernel is compiled for (register budget 512 / (4 * blocks) per lane) */
