@@ -533,7 +533,17 @@ int32_t RaylibAMD_SceneBVH4Info(SceneHandle sh, uint32_t* nodes4, uint32_t* stac
 	if (!s || !s->finalized || s->bvh.nodes4.empty()) return 0;
 	if (nodes4) *nodes4 = (uint32_t)s->bvh.nodes4.size();
 	if (stackNeed) *stackNeed = s->bvh.stackNeed4;
-	return ValidateBVH4(s->bvh, s->triangles) ? 1 : -1;
+	return (ValidateBVH4(s->bvh, s->triangles) && ValidateBVH8(s->bvh, s->triangles)) ? 1 : -1;   // (the 8-wide tree, where the scene has one, is part of the check)
+}
+int32_t RaylibAMD_SceneBVH8Info(SceneHandle sh, uint32_t* nodes8, uint32_t* levels, float* steps4, float* steps8)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized || s->bvh.nodes8.empty()) return 0;
+	if (nodes8) *nodes8 = (uint32_t)s->bvh.nodes8.size();
+	if (levels) *levels = s->bvh.depth8;
+	if (steps4) *steps4 = s->bvh.sahNodes4;
+	if (steps8) *steps8 = s->bvh.sahNodes8;
+	return ValidateBVH8(s->bvh, s->triangles) ? 1 : -1;
 }
 int32_t RaylibAMD_SceneLeafListInfo(SceneHandle sh, uint32_t* maxPerLeaf)
 {
@@ -555,6 +565,7 @@ uint64_t RaylibAMD_SceneBVHHash(SceneHandle sh)
 	feed(s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(DNode4));
 	feed(s->bvh.nodes4q.data(), s->bvh.nodes4q.size() * sizeof(DNode4Q));
 	feed(s->bvh.leafList.data(), s->bvh.leafList.size() * sizeof(DNode4));
+	feed(s->bvh.nodes8.data(), s->bvh.nodes8.size() * sizeof(DNode8));
 	return h;
 }
 void RaylibAMD_CameraExport(CameraHandle h, float out[19])

@@ -294,9 +294,117 @@ static void QuantizeWide(BVH& out)
 	for (std::thread& th : pool) th.join();
 }
 
+// ---- the 8-wide tree (DNode8, rl_device.h) ---------------------------------------------------------------------------------------------------------
+// Collapse: starting from a node's two children, the inner child with the largest surface area is replaced by its own two children until there are eight (or
+// only leaves) -- the BVH4's rule.  Slots: child c goes to the slot whose three bits (bit 0: +x, bit 1: +y, bit 2: +z) point from the node's centre towards
+// the child's, assigned greedily by the largest dot product of (child centre - node centre) with the slot's (+-1, +-1, +-1): a ray then visits the slots in the
+// order slot XOR (signs of its direction) without sorting anything.  Nodes are numbered breadth first, so the inner children of a node are consecutive; the
+// leaf children of a node, taken in slot order, define the order of the triangle slots (BuildBVH assigns them in W.leafOrder's order).
+struct Wide8Node { int32_t kid[8]; uint32_t firstChild; };   // TmpNode index per slot (-1: none); node index of the first inner child
+struct Wide8 { std::vector<Wide8Node> nodes; std::vector<int32_t> leafOrder; uint32_t depth = 0; double sah = 0.0; };
+
+static void CollapseWide8(const std::vector<TmpNode>& T, int32_t root, Wide8& W)
+{
+	struct Item { int32_t tmp; uint32_t level; };
+	std::vector<Item> queue;
+	queue.push_back({ root, 1u });
+	W.nodes.clear(); W.leafOrder.clear(); W.depth = 0; W.sah = 0.0;
+	const double rootArea = std::max((double)T[root].box.halfArea(), 1e-30);
+	for (size_t at = 0; at < queue.size(); ++at) {
+		const Item it = queue[at];
+		W.depth = std::max(W.depth, it.level);
+		W.sah += (double)T[it.tmp].box.halfArea() / rootArea;
+		int32_t kids[8]; int nk = 0;
+		kids[nk++] = T[it.tmp].left; kids[nk++] = T[it.tmp].right;
+		while (nk < 8) {
+			int best = -1; float bestArea = -1.0f;
+			for (int k = 0; k < nk; ++k) if (T[kids[k]].left >= 0) { const float a = T[kids[k]].box.halfArea(); if (a > bestArea) { bestArea = a; best = k; } }
+			if (best < 0) break;
+			const int32_t open = kids[best];
+			kids[best] = T[open].left; kids[nk++] = T[open].right;
+		}
+		const Box& nb = T[it.tmp].box;
+		const double cx = 0.5 * ((double)nb.mn.x + nb.mx.x), cy = 0.5 * ((double)nb.mn.y + nb.mx.y), cz = 0.5 * ((double)nb.mn.z + nb.mx.z);
+		double cost[8][8];
+		for (int c = 0; c < nk; ++c) {
+			const Box& b = T[kids[c]].box;
+			const double dx = 0.5 * ((double)b.mn.x + b.mx.x) - cx, dy = 0.5 * ((double)b.mn.y + b.mx.y) - cy, dz = 0.5 * ((double)b.mn.z + b.mx.z) - cz;
+			for (int sl = 0; sl < 8; ++sl) cost[c][sl] = ((sl & 1) ? dx : -dx) + ((sl & 2) ? dy : -dy) + ((sl & 4) ? dz : -dz);
+		}
+		Wide8Node nd; for (int sl = 0; sl < 8; ++sl) nd.kid[sl] = -1;
+		bool childDone[8] = { false, false, false, false, false, false, false, false };
+		for (int round = 0; round < nk; ++round) {
+			int bc = -1, bs = -1; double bv = -1e300;
+			for (int c = 0; c < nk; ++c) { if (childDone[c]) continue; for (int sl = 0; sl < 8; ++sl) { if (nd.kid[sl] >= 0) continue; if (cost[c][sl] > bv) { bv = cost[c][sl]; bc = c; bs = sl; } } }
+			nd.kid[bs] = kids[bc]; childDone[bc] = true;
+		}
+		nd.firstChild = (uint32_t)queue.size();
+		for (int sl = 0; sl < 8; ++sl) {
+			const int32_t k = nd.kid[sl];
+			if (k < 0) continue;
+			if (T[k].left >= 0) queue.push_back({ k, it.level + 1u }); else W.leafOrder.push_back(k);
+		}
+		W.nodes.push_back(nd);
+	}
+}
+
+// W + the leaf references (first triangle slot, count) -> out.nodes8.  Grid boxes as in QuantizeWide: every decision in double.
+static void EmitWide8(const std::vector<TmpNode>& T, const Wide8& W, const std::vector<int32_t>& leafCode, BVH& out)
+{
+	out.nodes8.assign(W.nodes.size(), DNode8());
+	out.depth8 = W.depth; out.sahNodes8 = (float)W.sah;
+	auto run = [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) {
+		const Wide8Node& w = W.nodes[i];
+		DNode8 n; memset(&n, 0, sizeof(n));
+		uint32_t imask = 0, leafMask = 0, triBase = 0; bool haveTri = false;
+		for (int c = 0; c < 8; ++c) {
+			const int32_t k = w.kid[c];
+			if (k < 0) continue;
+			if (T[k].left >= 0) { imask |= 1u << c; continue; }
+			const uint32_t code = (uint32_t)~leafCode[k], first = code >> 6, count = (code & 7u) + 1;
+			leafMask |= ((1u << count) - 1u) << (4 * c);
+			if (!haveTri) { triBase = first; haveTri = true; }
+		}
+		uint32_t exps[3] = { 0, 0, 0 };
+		for (int a = 0; a < 3; ++a) {
+			float lo = FLT_MAX, hi = -FLT_MAX;
+			for (int c = 0; c < 8; ++c) if (w.kid[c] >= 0) { lo = std::min(lo, axisOf(T[w.kid[c]].box.mn, a)); hi = std::max(hi, axisOf(T[w.kid[c]].box.mx, a)); }
+			if (!(lo <= hi)) { lo = hi = 0.0f; }
+			n.origin[a] = lo;
+			const double extent = (double)hi - (double)lo;
+			int e = 1;
+			if (extent > 0.0) { int x; (void)frexp(extent / 255.0, &x); e = std::max(1, std::min(254, x + 127)); }
+			double step = ldexp(1.0, e - 127);
+			while (255.0 * step < extent && e < 254) { ++e; step *= 2.0; }
+			exps[a] = (uint32_t)e;
+			for (int c = 0; c < 8; ++c) {
+				if (w.kid[c] < 0) { n.qlo[a][c >> 2] |= 255u << (8 * (c & 3)); continue; }   // inverted: lower 255, upper 0
+				const double blo = axisOf(T[w.kid[c]].box.mn, a), bhi = axisOf(T[w.kid[c]].box.mx, a);
+				double l = floor((blo - (double)lo) / step), h = ceil((bhi - (double)lo) / step);
+				l = std::max(0.0, std::min(255.0, l)); h = std::max(0.0, std::min(255.0, h));
+				while (l > 0.0 && (double)lo + l * step > blo) l -= 1.0;
+				while (h < 255.0 && (double)lo + h * step < bhi) h += 1.0;
+				n.qlo[a][c >> 2] |= (uint32_t)l << (8 * (c & 3));
+				n.qhi[a][c >> 2] |= (uint32_t)h << (8 * (c & 3));
+			}
+		}
+		n.meta = exps[0] | (exps[1] << 8) | (exps[2] << 16) | (imask << 24);
+		n.childBase = w.firstChild; n.triBase = triBase; n.leafMask = leafMask; n.alphaMask = 0;
+		out.nodes8[i] = n;
+	} };
+	const size_t n = W.nodes.size();
+	unsigned threads = n >= (1u << 15) ? std::max(1u, std::min(32u, std::thread::hardware_concurrency())) : 1u;
+	if (const char* e = getenv("RAYLIB_BUILD_THREADS")) { int v = atoi(e); if (v > 0 && n >= (1u << 15)) threads = (unsigned)std::min(v, 32); }
+	std::vector<std::thread> pool;
+	const size_t per = (n + threads - 1) / threads;
+	for (unsigned t = 1; t < threads; ++t) { const size_t a = std::min(n, t * per), b = std::min(n, (t + 1) * per); if (a < b) pool.emplace_back(run, a, b); }
+	run(0, std::min(n, per));
+	for (std::thread& th : pool) th.join();
+}
+
 void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 {
-	out.nodes.clear(); out.nodes4.clear(); out.nodes4q.clear(); out.leafList.clear(); out.stackNeed4 = 0; out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
+	out.nodes.clear(); out.nodes4.clear(); out.nodes4q.clear(); out.nodes8.clear(); out.depth8 = 0; out.leafList.clear(); out.stackNeed4 = 0; out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
 	const uint32_t n = (uint32_t)prims.size();
 	Box empty; empty.mn = F3(FLT_MAX, FLT_MAX, FLT_MAX); empty.mx = F3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
 
@@ -373,9 +481,17 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 	// Leaf references.  Triangle leaves index the triangle arrays in leaf order (out.triOrder lists the
 	// original triangle index of every slot); an analytic primitive's leaf carries its index in its own array.
 	const std::vector<TmpNode>& T = merged;
+	// Triangle-only scenes of at least 8 triangles get the wide trees; the 8-wide one decides the order of the triangle slots (the leaf children of one of its
+	// nodes hold consecutive slots), every other format refers to the same slots through its leaf references.
+	bool trianglesOnly = true;
+	for (uint32_t i = 0; i < n && trianglesOnly; ++i) if (prims[i].kind != PRIM_TRIANGLE) trianglesOnly = false;
+	const bool wideTrees = n >= 8 && trianglesOnly && T[root].left >= 0;
+	// (not for the scenes small enough for the leaf list: its leaves are sub-trees of this tree, whose triangles must stay one range of slots -- the depth-first order)
+	const bool wide8 = wideTrees && n > RL_LEAFLIST_MAXTRIS;
+	Wide8 W8;
+	if (wide8) CollapseWide8(T, root, W8);
 	std::vector<int32_t> leafCode(T.size(), 0);
-	for (size_t t = 0; t < T.size(); ++t) {
-		if (T[t].left >= 0) continue;
+	auto codeLeaf = [&](size_t t) {
 		const uint32_t k = B.kind[B.order[T[t].first]];
 		if (k == PRIM_TRIANGLE) {
 			const uint32_t first = (uint32_t)out.triOrder.size();
@@ -384,7 +500,9 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		} else {
 			leafCode[t] = leafRef(prims[B.order[T[t].first]].index, k, 1);
 		}
-	}
+	};
+	if (wide8) { for (int32_t t : W8.leafOrder) codeLeaf((size_t)t); }
+	else for (size_t t = 0; t < T.size(); ++t) if (T[t].left < 0) codeLeaf(t);
 
 	// Emit two-box nodes in depth-first order.  A tree that is a single leaf still
 	// gets one inner node (left = the leaf, right = empty).
@@ -427,9 +545,8 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 	// ---- the wide tree: collapse to <= 4 children per node ----
 	// Starting from a node's two children, the inner child with the largest surface area is replaced by its own two
 	// children until there are four (or only leaves).  Only for scenes the pool schedule can run (triangles only, not tiny).
-	bool trianglesOnly = true;
-	for (uint32_t i = 0; i < n && trianglesOnly; ++i) if (prims[i].kind != PRIM_TRIANGLE) trianglesOnly = false;
-	if (n >= 8 && trianglesOnly) {
+	if (wideTrees) {
+		if (wide8) EmitWide8(T, W8, leafCode, out);
 		struct Item { int32_t tmp; int32_t slot; uint32_t need; };   // a BVH2 inner node that becomes wide node `slot`
 		std::vector<Item> work;
 		out.nodes4.clear();
@@ -437,8 +554,10 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 		out.nodes4.emplace_back();
 		work.push_back({ root, 0, 0u });
 		uint32_t needMax = 0;
+		double sah4 = 0.0; const double rootArea4 = std::max((double)T[root].box.halfArea(), 1e-30);
 		while (!work.empty()) {
 			const Item it = work.back(); work.pop_back();
+			sah4 += (double)T[it.tmp].box.halfArea() / rootArea4;
 			int32_t kids[4]; int nk = 0;
 			kids[nk++] = T[it.tmp].left; kids[nk++] = T[it.tmp].right;
 			while (nk < 4) {
@@ -470,7 +589,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 			}
 			out.nodes4[it.slot] = nd;
 		}
-		out.stackNeed4 = needMax;
+		out.stackNeed4 = needMax; out.sahNodes4 = (float)sah4;
 		QuantizeWide(out);
 		// ---- the leaf list: a scene that 4 * RL_LEAFLIST_RECORDS leaves of <= 8 triangles can hold is walked without a tree ----
 		// Every ray tests every leaf's box once (4 records of 4 boxes, in lockstep across a wave: no stack, no divergence), then visits the
@@ -519,7 +638,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 				}
 			}
 		}
-	} else { out.nodes4.clear(); out.nodes4q.clear(); out.leafList.clear(); out.stackNeed4 = 0; }
+	} else { out.nodes4.clear(); out.nodes4q.clear(); out.nodes8.clear(); out.depth8 = 0; out.leafList.clear(); out.stackNeed4 = 0; }
 }
 
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris)
@@ -644,6 +763,80 @@ bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris)
 		for (uint8_t v : seen) if (!v) return false;
 	}
 	return true;
+}
+
+// The 8-wide tree must hold every triangle slot exactly once, and every child's grid box must contain every triangle below it.
+bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
+{
+	if (bvh.nodes8.empty()) return true;
+	std::vector<uint8_t> seen(bvh.triOrder.size(), 0);
+	struct Frame { uint32_t node; int child; double lo[3], hi[3]; double clo[3], chi[3]; };   // lo / hi: bounds of what has been seen below this node so far; clo / chi: ... below the child being walked
+	// iterative post-order: for every node, the bounds of the triangles below each child are checked against that child's grid box
+	std::vector<Frame> st;
+	auto gridBox = [&](const DNode8& n, int c, double* lo, double* hi) {
+		for (int a = 0; a < 3; ++a) {
+			const double step = ldexp(1.0, (int)((n.meta >> (8 * a)) & 255u) - 127);
+			lo[a] = (double)n.origin[a] + (double)((n.qlo[a][c >> 2] >> (8 * (c & 3))) & 255u) * step;
+			hi[a] = (double)n.origin[a] + (double)((n.qhi[a][c >> 2] >> (8 * (c & 3))) & 255u) * step;
+		}
+	};
+	Frame f0; f0.node = 0; f0.child = -1; for (int a = 0; a < 3; ++a) { f0.lo[a] = 1e300; f0.hi[a] = -1e300; }
+	st.push_back(f0);
+	uint32_t depth = 0;
+	while (!st.empty()) {
+		Frame& F = st.back();
+		depth = std::max<uint32_t>(depth, (uint32_t)st.size());
+		if (F.node >= bvh.nodes8.size()) return false;
+		const DNode8& n = bvh.nodes8[F.node];
+		const uint32_t imask = n.meta >> 24;
+		if (++F.child >= 8) {
+			// done: hand this node's bounds to the parent's current child
+			const Frame done = F; st.pop_back();
+			if (!st.empty()) {
+				Frame& P = st.back();
+				const DNode8& pn = bvh.nodes8[P.node];
+				double glo[3], ghi[3]; gridBox(pn, P.child, glo, ghi);
+				for (int a = 0; a < 3; ++a) {
+					if (!(glo[a] <= done.lo[a] && ghi[a] >= done.hi[a])) return false;
+					P.lo[a] = std::min(P.lo[a], done.lo[a]); P.hi[a] = std::max(P.hi[a], done.hi[a]);
+				}
+			}
+			continue;
+		}
+		const int c = F.child;
+		const uint32_t nib = (n.leafMask >> (4 * c)) & 15u;
+		if (imask & (1u << c)) {
+			if (nib) return false;
+			Frame ch; ch.node = n.childBase + (uint32_t)__builtin_popcount(imask & ((1u << c) - 1u)); ch.child = -1;
+			for (int a = 0; a < 3; ++a) { ch.lo[a] = 1e300; ch.hi[a] = -1e300; }
+			st.push_back(ch);
+			continue;
+		}
+		if (!nib) {   // unused: the inverted box
+			for (int a = 0; a < 3; ++a) if (((n.qlo[a][c >> 2] >> (8 * (c & 3))) & 255u) != 255u || ((n.qhi[a][c >> 2] >> (8 * (c & 3))) & 255u) != 0u) return false;
+			continue;
+		}
+		if (nib != 1u && nib != 3u && nib != 7u && nib != 15u) return false;
+		const uint32_t first = n.triBase + (uint32_t)__builtin_popcount(n.leafMask & ((1u << (4 * c)) - 1u)), count = (uint32_t)__builtin_popcount(nib);
+		double glo[3], ghi[3]; gridBox(n, c, glo, ghi);
+		for (uint32_t k = 0; k < count; ++k) {
+			if (first + k >= bvh.triOrder.size() || seen[first + k]) return false;
+			seen[first + k] = 1;
+			const uint32_t ti = bvh.triOrder[first + k];
+			if (ti >= tris.size()) return false;
+			const HostTriangle& t = tris[ti];
+			const f3 vs[3] = { t.v0, t.v1, t.v2 };
+			for (const f3& v : vs) {
+				const double p[3] = { v.x, v.y, v.z };
+				for (int a = 0; a < 3; ++a) {
+					if (!(glo[a] <= p[a] && ghi[a] >= p[a])) return false;
+					F.lo[a] = std::min(F.lo[a], p[a]); F.hi[a] = std::max(F.hi[a], p[a]);
+				}
+			}
+		}
+	}
+	for (uint8_t v : seen) if (!v) return false;
+	return depth <= bvh.depth8;
 }
 
 } // namespace rl

@@ -50,6 +50,29 @@ struct alignas(64) DNode4Q {
 	int32_t child[4];
 };
 static_assert(sizeof(DNode4Q) == 64, "DNode4Q");
+// The 8-wide grid node, 80 bytes = five 16-byte loads (round 4).  The tree walk of a large scene is a chain of dependent steps -- fetch a node (about a
+// microsecond under load), ~180 VALU instructions, fetch the next -- of which a SIMD keeps four in flight: fewer loads per step,
+// fuller turns of the vote and cheaper pops did not shorten it; FEWER STEPS do.  Eight children per node: 0.6 x the steps of the 4-wide tree.
+//   * boxes as in DNode4Q: the node's minimum corner as three floats, a power-of-two step per axis (here as biased exponents, one byte each), 8-bit planes
+//     (byte c of qlo[a][c >> 2] / qhi[a][c >> 2] = child c); an unused child has the inverted box lo 255 / hi 0, which no ray enters;
+//   * children are NOT named one by one: the inner children of a node are consecutive nodes (childBase + rank among the inner children, in slot order:
+//     imask bit c = child c is an inner node), the triangles of its leaf children are consecutive triangle slots (triBase + rank among the bits of leafMask,
+//     whose nibble c holds as many low bits as leaf child c has triangles, <= 4) -- so a traversal keeps the hit children of a node as ONE stack entry
+//     (base, hit bits) however many they are, and needs no sort: children sit in the slot whose three bits say on which side of the node they lie
+//     (bit 0: +x, bit 1: +y, bit 2: +z; the builder assigns them greedily), and a ray visits the slots in the order slot XOR (signs of its direction)
+//     (Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", HPG 2017 -- the layout idea; the arithmetic here
+//     is this library's: exact-corner grid boxes, the candidate rule, the tie rule);
+//   * alphaMask bit c = leaf child c holds a triangle whose material is alpha-tested (the cut-out test runs inside traversal, DNode's flag).
+struct alignas(16) DNode8 {
+	float origin[3];
+	uint32_t meta;        // ex | ey << 8 | ez << 16 (biased exponents of the steps) | imask << 24
+	uint32_t childBase;   // node index of the first inner child
+	uint32_t triBase;     // triangle slot of the first triangle of the first leaf child
+	uint32_t leafMask;    // nibble c: (1 << count) - 1 for leaf child c, else 0
+	uint32_t alphaMask;   // bit c (c < 8)
+	uint32_t qlo[3][2], qhi[3][2];
+};
+static_assert(sizeof(DNode8) == 80, "DNode8");
 // which of the two the POOL schedule walks (a build-time switch so that both can be timed: make variant EXTRA=-DRL_Q4=0);
 // k_trace has both as instantiations and takes the float boxes whenever the scene carries them
 #ifndef RL_Q4
@@ -131,6 +154,7 @@ struct DSceneView {
 	const DNode* nodes;
 	const DNode4Q* nodes4;     // the wide tree on the 8-bit grid: what the pool schedule walks (nullptr: the scene has none)
 	const DNode4* nodes4f;     // the wide tree with float boxes: uploaded for small, cache-resident scenes (k_trace), where the grid saves nothing
+	const DNode8* nodes8;      // the 8-wide tree (the pool schedule's default when the scene carries one; nullptr: none)
 	const DTriIsect* isect;
 	const DTriShade* shade;
 	const DMaterial* materials;

@@ -115,6 +115,9 @@ struct BVH {
 	std::vector<DNode4> nodes4;       // the same tree collapsed to <= 4 children per node (empty for small scenes / analytic primitives)
 	std::vector<DNode4Q> nodes4q;     // nodes4 on the 8-bit grid (same indices, same children): what the kernels walk by default
 	uint32_t stackNeed4 = 0;          // worst-case traversal-stack entries of nodes4 (sum of children - 1 along the deepest path)
+	std::vector<DNode8> nodes8;       // the 8-wide tree (DNode8, rl_device.h); its leaves are the BVH2's leaves, and the order of the triangle slots is ITS order (a node's leaf children hold consecutive slots)
+	uint32_t depth8 = 0;              // levels of nodes8: a traversal's stack holds at most one entry (the rest of a node's hit children) per level
+	float sahNodes4 = 0.0f, sahNodes8 = 0.0f;   // sum over the wide tree's nodes of (node's surface area / root's): the expected node steps of a random ray through either tree
 	std::vector<DNode4> leafList;     // scenes of <= 4 * RL_LEAFLIST_RECORDS leaves: every leaf's box, four to a record, no inner nodes (k_trace's flat walk; empty otherwise)
 	std::vector<uint32_t> triOrder;   // leaf order -> index into the flat triangle array
 	uint32_t depth = 0;
@@ -127,6 +130,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out);
 bool BVHCapacityOk(size_t numPrimitives);   // a leaf reference addresses 2^25 primitive slots
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris);
 bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris);
+bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris);   // true also when the scene has no 8-wide tree
 
 // Scene elements created through include/raylib_amd.h (the reference's procedural scenes `new` C++ objects in the
 // application instead: src/main.cc:913-984).  A material is owned by the library and shared by reference.

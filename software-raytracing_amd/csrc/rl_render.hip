@@ -1911,6 +1911,10 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #ifndef RL_POOL_WNODE4
 #define RL_POOL_WNODE4 4  /* the same for a BVH4 step */
 #endif
+#ifndef RL_POOL_WNODE8
+#define RL_POOL_WNODE8 4  /* ... and for a step on the 8-wide tree */
+#define RL_POOL_WLEAF8 12   /* 298 k-triangle room from inside: 6 -> 365.7 ms, 9 -> 358.9, 12 -> 357.8, 16 -> 360.9 (the 4-wide tree: 381.4) */
+#endif
 #ifndef RL_POOL_WLEAF4
 // Re-tuned at the end of round 3 (the leaf step is a third cheaper than it was -- two divisions gone, the own-box rule on v_max / v_min -- but above all the lanes at
 // leaves are the ones about to FINISH: serving them first frees lanes for the next fetch).  298 k frame / colonnade / 2.36 M triangles at 4K, ms: 5 -> 36.85 / 373.7 /
@@ -1922,7 +1926,13 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #endif
 
 
-struct Trav { V3 o, d, inv; float rayTime; bool nx, ny, nz, anyhit; HitRec best; int cur, sp, leafI; };
+struct Trav {
+	V3 o, d, inv; float rayTime; bool nx, ny, nz, anyhit; HitRec best; int cur, sp, leafI;
+	// the 8-wide tree's walk (NodeStep8 / LeafStep8): the hit inner children of a node still to be visited, as ONE group -- gx the node's childBase, gy = their bits
+	// in VISITING order (bit 24 + (slot XOR oct), highest first) | the node's alphaMask << 8 | its imask --; the triangles of its hit leaf children still to be tested:
+	// tx the node's triBase, tz its leafMask, ty the bits of tz that are left; oct: bit 0 / 1 / 2 set when the ray travels towards +x / +y / +z
+	uint32_t gx, gy, tx, ty, tz, oct;
+};
 
 // Single steps on the resumable state, for the vote-driven loop of k_trace_pool: a lane is either at an inner node
 // (cur >= 0), at a leaf (cur < 0, leafI = next primitive of it), or finished (both return true then).
@@ -2058,6 +2068,103 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 	return PopOrFinish<LSTACK, STACK>(T, stk, ovf);
 }
 
+// ---- the 8-wide tree (DNode8, rl_device.h) in the vote-driven loop --------------------------------------------------------------------------------
+// A lane's state is (T.gx, T.gy): the group of hit inner children it is working through, (T.tx, T.ty, T.tz): the triangles of hit leaf children it still has
+// to test, and a stack of groups (two words each: the LDS stack's entries pairwise, then the private overflow).  T.cur only says which party of the vote the
+// lane belongs to: 0 at a node (a group with a child left), -1 at a leaf (a triangle left), TRAV-idle without a ray.  One node step = take the group's next
+// child in visiting order, push the rest of the group (ONE entry however many children it holds), fetch the child (five 16-byte loads), test its eight boxes,
+// and turn the hits into the next group and the next triangles -- no sort, no per-child pushes.  The triangles of a node's leaf children are tested before any
+// of its inner children is entered (they are the geometry nearest to hand); the order of two candidates never decides a hit (candidate rule, tie rule).
+__device__ __forceinline__ void Push8(Trav& T, int* stk, int* ovf, const int G, const int GMAX)
+{
+	if (T.sp < G) { stk[(2 * T.sp) * RL_BLOCK] = (int)T.gx; stk[(2 * T.sp + 1) * RL_BLOCK] = (int)T.gy; ++T.sp; }
+	else if (T.sp < GMAX) { ovf[2 * (T.sp - G)] = (int)T.gx; ovf[2 * (T.sp - G) + 1] = (int)T.gy; ++T.sp; }   // (the host picks this walk only for trees of at most GMAX levels)
+}
+// what comes next for a lane whose triangles are done: the rest of its group, else the stack's top group, else nothing (true: the ray is finished)
+__device__ __forceinline__ bool Next8(Trav& T, int* stk, int* ovf, const int G)
+{
+	if (T.ty != 0u) { T.cur = -1; return false; }
+	if ((T.gy >> 24) != 0u) { T.cur = 0; return false; }
+	if (T.sp == 0) return true;
+	--T.sp;
+	if (T.sp < G) { T.gx = (uint32_t)stk[(2 * T.sp) * RL_BLOCK]; T.gy = (uint32_t)stk[(2 * T.sp + 1) * RL_BLOCK]; }
+	else { T.gx = (uint32_t)ovf[2 * (T.sp - G)]; T.gy = (uint32_t)ovf[2 * (T.sp - G) + 1]; }
+	T.cur = 0;
+	return false;
+}
+// One child: six planes, entry = max, exit = min, and "culled" (exit * widen < entry) as the SIGN of fma(exit, widen, -entry), shifted into a mask with one
+// v_alignbit (mask = mask << 1 | sign): a multiply, a compare, a select and an or less per child than `if (...) mask |= bit` costs.  (The fused form is culled exactly
+// when exit * widen < entry in real arithmetic; the rounded product of RL_WIDE_STEP_Q can only let MORE boxes through: both are conservative.)
+#define RL_QSLAB8(wn, wf, sh) { \
+	float tn = tMinL_, tf = tmxL_; \
+	tn = fmaxf(tn, __builtin_fmaf((float)((nX##wn >> sh) & 0xffu), Ax_, Bnx_)); tf = fminf(tf, __builtin_fmaf((float)((fX##wf >> sh) & 0xffu), Ax_, Bfx_)); \
+	tn = fmaxf(tn, __builtin_fmaf((float)((nY##wn >> sh) & 0xffu), Ay_, Bny_)); tf = fminf(tf, __builtin_fmaf((float)((fY##wf >> sh) & 0xffu), Ay_, Bfy_)); \
+	tn = fmaxf(tn, __builtin_fmaf((float)((nZ##wn >> sh) & 0xffu), Az_, Bnz_)); tf = fminf(tf, __builtin_fmaf((float)((fZ##wf >> sh) & 0xffu), Az_, Bfz_)); \
+	culled = __builtin_amdgcn_alignbit(culled, __float_as_uint(__builtin_fmaf(tf, RL_POOL_WIDEN, -tn)), 31u); }
+__device__ __forceinline__ bool NodeStep8(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c, const unsigned char* perm, const int G, const int GMAX)
+{
+	RL_WSTEP(4);
+	c.nodes++;   // one 80-byte record
+	// the group's next child in visiting order; the rest of the group, if any, is one stack entry
+	const uint32_t pos = 31u - (uint32_t)__clz((int)T.gy);
+	T.gy &= ~(1u << pos);
+	const uint32_t slot = (pos - 24u) ^ T.oct;
+	const uint32_t node = T.gx + (uint32_t)__popc(T.gy & 0xffu & ((1u << slot) - 1u));
+	if ((T.gy >> 24) != 0u) Push8(T, stk, ovf, G, GMAX);
+	const char* np_ = (const char*)S.nodes8 + (size_t)node * 80u;
+	const uint4 h_ = GLoadU4(np_, 0), k_ = GLoadU4(np_, 1), p0_ = GLoadU4(np_, 2), p1_ = GLoadU4(np_, 3), p2_ = GLoadU4(np_, 4);
+	const float Ax_ = __uint_as_float((h_.w & 0xffu) << 23) * T.inv.x, Ay_ = __uint_as_float(((h_.w >> 8) & 0xffu) << 23) * T.inv.y, Az_ = __uint_as_float(((h_.w >> 16) & 0xffu) << 23) * T.inv.z;
+	const float Bx_ = (__uint_as_float(h_.x) - T.o.x) * T.inv.x, By_ = (__uint_as_float(h_.y) - T.o.y) * T.inv.y, Bz_ = (__uint_as_float(h_.z) - T.o.z) * T.inv.z;
+	// (|B| + 255 |A|) * 2^-21, as in RL_WIDE_STEP_Q: four times the rounding of q * A + B against the reference's (bound - o) * inv
+	const float Ex_ = fabsf(Ax_ * 1.21593475e-4f) + fabsf(Bx_ * 4.76837158e-7f), Ey_ = fabsf(Ay_ * 1.21593475e-4f) + fabsf(By_ * 4.76837158e-7f), Ez_ = fabsf(Az_ * 1.21593475e-4f) + fabsf(Bz_ * 4.76837158e-7f);
+	const float Bnx_ = Bx_ - Ex_, Bfx_ = Bx_ + Ex_, Bny_ = By_ - Ey_, Bfy_ = By_ + Ey_, Bnz_ = Bz_ - Ez_, Bfz_ = Bz_ + Ez_;
+	// planes: p0 = qlo x (children 0-3, 4-7), qlo y (0-3, 4-7); p1 = qlo z (0-3, 4-7), qhi x (0-3, 4-7); p2 = qhi y (0-3, 4-7), qhi z (0-3, 4-7)
+	const uint32_t nX0 = T.nx ? p1_.z : p0_.x, fX0 = T.nx ? p0_.x : p1_.z, nX1 = T.nx ? p1_.w : p0_.y, fX1 = T.nx ? p0_.y : p1_.w;
+	const uint32_t nY0 = T.ny ? p2_.x : p0_.z, fY0 = T.ny ? p0_.z : p2_.x, nY1 = T.ny ? p2_.y : p0_.w, fY1 = T.ny ? p0_.w : p2_.y;
+	const uint32_t nZ0 = T.nz ? p2_.z : p1_.x, fZ0 = T.nz ? p1_.x : p2_.z, nZ1 = T.nz ? p2_.w : p1_.y, fZ1 = T.nz ? p1_.y : p2_.w;
+	const float tMinL_ = tMin, tmxL_ = ClampToFltMax(T.best.t);
+	uint32_t culled = 0u;   // child 7 first: child c ends up in bit c
+	RL_QSLAB8(1, 1, 24) RL_QSLAB8(1, 1, 16) RL_QSLAB8(1, 1, 8) RL_QSLAB8(1, 1, 0)
+	RL_QSLAB8(0, 0, 24) RL_QSLAB8(0, 0, 16) RL_QSLAB8(0, 0, 8) RL_QSLAB8(0, 0, 0)
+	const uint32_t hitSlot = ~culled & 0xffu;
+	// hits -> the next group (inner children, bits moved to visiting order by the workgroup's 8 x 256 table) and the next triangles (leaf children)
+	const uint32_t imask = h_.w >> 24;
+	const uint32_t innerP = (uint32_t)perm[T.oct * 256u + (hitSlot & imask)];
+	T.gx = k_.x; T.gy = (innerP << 24) | ((k_.w & 0xffu) << 8) | imask;
+	uint32_t e = hitSlot & ~imask;
+	e = (e | (e << 12)) & 0x000f000fu; e = (e | (e << 6)) & 0x03030303u; e = (e | (e << 3)) & 0x11111111u;
+	e = (e << 4) - e;   // every bit a nibble
+	T.tx = k_.y; T.tz = k_.z; T.ty = k_.z & e;
+	return Next8(T, stk, ovf, G);
+}
+template <bool PRIMS>
+__device__ __forceinline__ bool LeafStep8(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c, const int G)
+{
+	RL_WSTEP(5);
+	const uint32_t b = (uint32_t)__ffs((int)T.ty) - 1u;
+	T.ty &= T.ty - 1u;
+	const int i = (int)(T.tx + (uint32_t)__popc(T.tz & ((1u << b) - 1u)));
+	const bool alpha = ((T.gy >> (8u + (b >> 2))) & 1u) != 0u;
+	const V3 o = T.o, d = T.d;
+	c.tris++;
+	const Tri TT = LoadTri(S, i);
+	// reference geom/triangle.cc:22-27
+	const float t = dot((TT.v0 - o), TT.n) / dot(d, TT.n);
+	if (t >= tMin && t <= FLT_MAX && (t < T.best.t || (t == T.best.t && i < T.best.tri))) {   // ties: the lower slot, as in Traverse()
+		const V3 pp = o + t * d;
+		const V3 w = pp - TT.v0;
+		const float wv = dot(w, TT.v), wu = dot(w, TT.u);
+		float pa, pb;
+		if (Barycentric(S.fastBary != 0, TT.uv * wv - TT.vv * wu, TT.uv * wu - TT.uu * wv, TT.denom, TT.rden, pa, pb) && OwnBoxPass(TT.v0, TT.v1, TT.v2, o, v3(rtm::rcp1_(d.x), rtm::rcp1_(d.y), rtm::rcp1_(d.z)), tMin, t)) {
+			if (!alpha || AlphaTestCandidate(S, i, pa, pb, c)) {
+				T.best.t = t; T.best.a = pa; T.best.b = pb; T.best.tri = i;
+				if (T.anyhit) return true;
+			}
+		}
+	}
+	return Next8(T, stk, ovf, G);
+}
+
 // sky part of the miss shader (reference render/renderer.cc:155-181)
 __device__ __forceinline__ V3 MissSky(const DSceneView& S, const SkyRot& R, V3 d, Counters& c)
 {
@@ -2127,8 +2234,8 @@ template <int LSTACK, bool PRIMS, int K> struct PoolOcc {
 };
 
 // STACK: capacity of the traversal stack; LSTACK <= STACK: how much of it lives in LDS (the rest is private overflow)
-// WIDE: traverse the BVH4 (S.nodes4) instead of the BVH2
-template <int STACK, bool PRIMS, int K, int LSTACK = STACK, bool WIDE = false>
+// WIDE: 0 the BVH2; 1 the BVH4 (S.nodes4: 64-byte grid nodes; RL_Q4 = 0: float boxes); 3 the 8-wide tree (S.nodes8; STACK / LSTACK then count words: two per group)
+template <int STACK, bool PRIMS, int K, int LSTACK = STACK, int WIDE = 0>
 __global__ void __launch_bounds__(RL_BLOCK, (PoolOcc<LSTACK, PRIMS, K>::kBlocks))
 k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB* __restrict__ samplesK,
              float* __restrict__ pathStackK, unsigned long long* __restrict__ countersK, unsigned int* __restrict__ jobCounterK)
@@ -2145,6 +2252,18 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 	int* ovf = ovfStore;
 	__shared__ float s_pool[RL_BLOCK / 64][PoolOcc<LSTACK, PRIMS, K>::kFields][PP];
 	__shared__ unsigned char s_free[RL_BLOCK / 64][PP];
+	// the 8-wide walk: s_perm[oct * 256 + y] = the byte y with every bit b moved to bit b XOR oct (slot order -> visiting order of a ray of octant oct)
+	__shared__ unsigned char s_perm[WIDE == 3 ? 8 * 256 : 1];
+	if constexpr (WIDE == 3) {
+		for (uint32_t i = threadIdx.x; i < 8u * 256u; i += RL_BLOCK) {
+			const uint32_t m = i >> 8, y = i & 255u;
+			uint32_t r = 0;
+			for (uint32_t bb = 0; bb < 8u; ++bb) if ((y >> bb) & 1u) r |= 1u << (bb ^ m);
+			s_perm[i] = (unsigned char)r;
+		}
+		__syncthreads();
+	}
+	constexpr int G8 = LSTACK / 2, GMAX8 = STACK / 2;   // groups in the LDS part of the stack, groups in all
 
 	int* stk = s_stack + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -2183,6 +2302,7 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 	Trav T;
 	T.o = T.d = T.inv = v3s(0.0f); T.rayTime = 0.0f; T.nx = T.ny = T.nz = T.anyhit = false;
 	T.best.t = INFINITY; T.best.a = T.best.b = 0.0f; T.best.tri = -1; T.cur = IDLE; T.sp = 0; T.leafI = 0;
+	T.gx = T.gy = T.tx = T.ty = T.tz = T.oct = 0u;
 #ifdef RL_DIAG_STAMPS
 	unsigned long long stampAcc[4] = { 0, 0, 0, 0 };
 	{ RL_ARGS(); c.diag = counters; }
@@ -2348,7 +2468,8 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 			// the wide nodes' base address in a VGPR pair for the phase: as one of the loop's many uniform values it would be spilled to a VGPR's lanes and
 			// read back (two v_readlane, 4 issue cycles each) at every traversal step
 			DSceneView St = S;
-			{ const DNode4Q* pn = S.nodes4; asm volatile("" : "+v"(pn)); St.nodes4 = pn; }
+			if constexpr (WIDE == 3) { const DNode8* pn = S.nodes8; asm volatile("" : "+v"(pn)); St.nodes8 = pn; }
+			else { const DNode4Q* pn = S.nodes4; asm volatile("" : "+v"(pn)); St.nodes4 = pn; }
 #else
 			const DSceneView& St = S;
 #endif
@@ -2367,10 +2488,15 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 							T.d = T.anyhit ? -ld3(S.sunDirection) : v3(pool[F_DX][slot], pool[F_DY][slot], pool[F_DZ][slot]);
 							T.rayTime = PRIMS ? pool[F_TIME][slot] : 0.0f;
 							T.inv = v3(FastRcp(T.d.x), FastRcp(T.d.y), FastRcp(T.d.z));
-							if (WIDE && RL_Q4) T.inv = ClampInv(T.inv);   // only the grid nodes' fused plane arithmetic wants finite reciprocals; Slab() relies on +-inf / NaN
+							if ((WIDE && RL_Q4) || WIDE == 3) T.inv = ClampInv(T.inv);   // only the grid nodes' fused plane arithmetic wants finite reciprocals; Slab() relies on +-inf / NaN
 							T.nx = T.inv.x < 0.0f; T.ny = T.inv.y < 0.0f; T.nz = T.inv.z < 0.0f;
 							T.best.t = INFINITY; T.best.tri = -1; T.best.a = 0.0f; T.best.b = 0.0f;
 							T.cur = 0; T.sp = 0; T.leafI = 0;
+							if constexpr (WIDE == 3) {
+								// the root as a group of one: base 0, imask 1, its bit at the visiting position of slot 0
+								T.oct = (T.nx ? 0u : 1u) | (T.ny ? 0u : 2u) | (T.nz ? 0u : 4u);
+								T.gx = 0u; T.gy = (1u << (24u + T.oct)) | 1u; T.tx = T.ty = T.tz = 0u;
+							}
 							mySlot = (int)slot;
 							pool[F_TRI][slot] = __int_as_float(T.anyhit ? Q_PENDING_SHADOW : Q_PENDING);
 							c.rays++;
@@ -2393,9 +2519,14 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 					const bool atNode = (uint32_t)T.cur < (uint32_t)IDLE, atLeaf = T.cur < 0;
 					const int nN = (int)__popcll(Ballot(atNode)), nL = (int)__popcll(Ballot(atLeaf));
 					bool fin = false;
-					const bool nodeTurn = nN * (WIDE ? RL_POOL_WNODE4 : RL_POOL_WNODE) >= nL * (WIDE ? RL_POOL_WLEAF4 : RL_POOL_WLEAF);
-					if (nodeTurn) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(St, T, tMinC, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, tMinC, stk, ovf, c); }
-					else { if (atLeaf) fin = LeafStep<LSTACK, STACK, PRIMS>(S, T, P.rayTMin, stk, ovf, c); }
+					const bool nodeTurn = nN * (WIDE == 3 ? RL_POOL_WNODE8 : WIDE ? RL_POOL_WNODE4 : RL_POOL_WNODE) >= nL * (WIDE == 3 ? RL_POOL_WLEAF8 : WIDE ? RL_POOL_WLEAF4 : RL_POOL_WLEAF);
+					if constexpr (WIDE == 3) {
+						if (nodeTurn) { if (atNode) fin = NodeStep8(St, T, tMinC, stk, ovf, c, s_perm, G8, GMAX8); }
+						else { if (atLeaf) fin = LeafStep8<PRIMS>(S, T, P.rayTMin, stk, ovf, c, G8); }
+					} else {
+						if (nodeTurn) { if (atNode) fin = WIDE ? NodeStep4<LSTACK, STACK>(St, T, tMinC, stk, ovf, c) : NodeStep<LSTACK, STACK>(S, T, tMinC, stk, ovf, c); }
+						else { if (atLeaf) fin = LeafStep<LSTACK, STACK, PRIMS>(S, T, P.rayTMin, stk, ovf, c); }
+					}
 					if (fin) {
 						const bool hit = T.best.tri >= 0;
 						int q = T.best.tri;
@@ -2552,9 +2683,10 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 #endif
 // The instances the runtime selects from (rl_runtime.inl SelectTraceKernel): defined in rl_render_pool.hip's translation unit, referenced from this one.
 #define RL_POOL_INSTANCES(X) \
-	X(16, false, 2, 16, false) X(16, false, 3, 16, false) X(16, false, 4, 16, false) X(32, false, 2, 32, false) X(32, false, 3, 32, false) X(32, false, 4, 32, false) \
-	X(32, false, 2, 4, false) X(32, false, 2, RL_POOL_SHORT_LSTACK, false) \
-	X(32, false, 2, 32, true) X(64, false, 2, 32, true) X(32, false, 2, RL_POOL_SHORT_LSTACK, true) X(64, false, 2, RL_POOL_SHORT_LSTACK, true)
+	X(16, false, 2, 16, 0) X(16, false, 3, 16, 0) X(16, false, 4, 16, 0) X(32, false, 2, 32, 0) X(32, false, 3, 32, 0) X(32, false, 4, 32, 0) \
+	X(32, false, 2, 4, 0) X(32, false, 2, RL_POOL_SHORT_LSTACK, 0) \
+	X(32, false, 2, 32, 1) X(64, false, 2, 32, 1) X(32, false, 2, RL_POOL_SHORT_LSTACK, 1) X(64, false, 2, RL_POOL_SHORT_LSTACK, 1) \
+	X(32, false, 2, 16, 3)
 #ifdef RL_TU_POOL
 #define RL_POOL_X(a, b, c, d, e) template __global__ void k_trace_pool<a, b, c, d, e>(const DRenderParams, const DSceneView, const SkyRot, SampleRGB* __restrict__, float* __restrict__, unsigned long long* __restrict__, unsigned int* __restrict__);
 #else

@@ -24,7 +24,7 @@ namespace rl {
 // One physical device's copy of a scene.
 struct DeviceSceneCopy {
 	int device = 0;
-	DNode4Q* nodes4 = nullptr; DNode4* nodes4f = nullptr; DNode4* leafList = nullptr;
+	DNode4Q* nodes4 = nullptr; DNode4* nodes4f = nullptr; DNode4* leafList = nullptr; DNode8* nodes8 = nullptr;
 	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
 	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
 	DSphere* spheres = nullptr; DCube* cubes = nullptr;
@@ -37,7 +37,7 @@ struct DeviceScene {
 	std::vector<DeviceSceneCopy*> copy;   // by device slot (Runtime::devices)
 	SkyRot skyRot;
 	uint32_t bvhDepth = 0, stackNeed4 = 0;
-	bool hasNodes4 = false;
+	bool hasNodes4 = false, hasNodes8 = false; uint32_t depth8 = 0; float sahNodes4 = 0.0f;
 	double boundsMin[3] = { 0, 0, 0 }, boundsMax[3] = { 0, 0, 0 };   // of all triangle vertices (CullCells)
 	bool boundsValid = false;                                        // triangles only, every coordinate finite
 };
@@ -282,7 +282,7 @@ void FreeCopy(DeviceSceneCopy* C)
 {
 	if (!C) return;
 	(void)hipSetDevice(C->device);
-	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4f) (void)hipFree(C->nodes4f); if (C->leafList) (void)hipFree(C->leafList); (void)hipFree(C->isect); (void)hipFree(C->shade);
+	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4f) (void)hipFree(C->nodes4f); if (C->nodes8) (void)hipFree(C->nodes8); if (C->leafList) (void)hipFree(C->leafList); (void)hipFree(C->isect); (void)hipFree(C->shade);
 	(void)hipFree(C->materials); (void)hipFree(C->textures); (void)hipFree(C->texels); (void)hipFree(C->spheres); (void)hipFree(C->cubes);
 	if (C->sky) (void)hipFree(C->sky);
 	delete C;
@@ -403,7 +403,7 @@ bool UploadScene(Scene& sc)
 	}
 
 	DeviceScene* D = new DeviceScene;
-	D->bvhDepth = sc.bvh.depth; D->stackNeed4 = sc.bvh.stackNeed4; D->hasNodes4 = !sc.bvh.nodes4.empty();
+	D->bvhDepth = sc.bvh.depth; D->stackNeed4 = sc.bvh.stackNeed4; D->hasNodes4 = !sc.bvh.nodes4.empty(); D->hasNodes8 = !sc.bvh.nodes8.empty(); D->depth8 = sc.bvh.depth8; D->sahNodes4 = sc.bvh.sahNodes4;
 	{   // Rotator(yaw = 90).rotate rows, reference geom/transform.cc:47-65 (host libm, as the reference)
 		const float pi_f = (float)3.1415926535897932385;
 		const float ry = 90.0f * pi_f / 180.0f, rp = 0.0f * pi_f / 180.0f, rr = 0.0f * pi_f / 180.0f;
@@ -438,6 +438,7 @@ bool UploadScene(Scene& sc)
 		// where the grid's extra arithmetic buys nothing (Cornell frame: 22.8 ms on float boxes, 23.8 ms on the grid)
 		const bool wantFull = D->hasNodes4 && (!RL_Q4 || sc.triangles.size() < 4096);
 		if (ok && D->hasNodes4 && RL_Q4) ok = Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size());
+		if (ok && D->hasNodes8) ok = Upload(C->nodes8, sc.bvh.nodes8.data(), sc.bvh.nodes8.size());
 		if (ok && wantFull) ok = Upload(C->nodes4f, sc.bvh.nodes4.data(), sc.bvh.nodes4.size());
 		if (ok && wantFull && !sc.bvh.leafList.empty()) ok = Upload(C->leafList, sc.bvh.leafList.data(), sc.bvh.leafList.size());
 		ok = ok && Upload(C->isect, isect.data(), n) && Upload(C->shade, shade.data(), n);
@@ -445,7 +446,7 @@ bool UploadScene(Scene& sc)
 		ok = ok && Upload(C->spheres, dsph.data(), dsph.size()) && Upload(C->cubes, dcub.data(), dcub.size());
 		if (!ok) { Log("UploadScene: device %d could not take the scene", C->device); FreeScene(D); return false; }   // nothing of a failed upload is left behind
 		DSceneView& V = C->view;
-		V.nodes = C->nodes; V.nodes4 = C->nodes4; V.nodes4f = C->nodes4f; V.isect = C->isect; V.shade = C->shade; V.materials = C->materials;
+		V.nodes = C->nodes; V.nodes4 = C->nodes4; V.nodes4f = C->nodes4f; V.nodes8 = C->nodes8; V.isect = C->isect; V.shade = C->shade; V.materials = C->materials;
 		V.textures = C->textures; V.texels = C->texels; V.spheres = C->spheres; V.cubes = C->cubes;
 		V.sunIlluminance[0] = sc.sunIlluminance.x; V.sunIlluminance[1] = sc.sunIlluminance.y; V.sunIlluminance[2] = sc.sunIlluminance.z;
 		V.sunDirection[0] = sc.sunDirection.x; V.sunDirection[1] = sc.sunDirection.y; V.sunDirection[2] = sc.sunDirection.z;
@@ -487,13 +488,14 @@ bool SyncSky(Scene& sc)
 	return true;
 }
 
+#define RL_BVH8_MIN_STEPS 48.0f
 typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot, SampleRGB*, float*, unsigned long long*, unsigned int*);
 
 // poolK = 0: k_trace (one path per lane); poolK = K: k_trace_pool with 64*K paths per wave
 template <int STACK, bool PRIMS>
-TraceKernel SelectTraceKernel(int& poolK, const DeviceScene* D, bool& shortStack, bool& wide)
+TraceKernel SelectTraceKernel(int& poolK, const DeviceScene* D, bool& shortStack, int& width)
 {
-	shortStack = false; wide = false;
+	shortStack = false; width = 2;
 	if constexpr (STACK <= 32 && !PRIMS) {
 		const char* e = getenv("RAYLIB_POOL_SHORT_STACK");
 		// the wide tree: default whenever the scene carries one whose worst-case stack fits; RAYLIB_BVH4=0|1 overrides
@@ -501,9 +503,15 @@ TraceKernel SelectTraceKernel(int& poolK, const DeviceScene* D, bool& shortStack
 		const bool haveWide = D && D->hasNodes4 && D->stackNeed4 <= 64;   // (the pool's node format is a build-time choice: RL_Q4)
 		const bool wantWide = haveWide && (w ? atoi(w) != 0 : true);
 		if (poolK == 2 && wantWide) {
-			wide = true; shortStack = true;
-			if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, true>; }
-			return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, true> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, true>;
+			width = 4; shortStack = true;
+			if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, 1> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, 1>; }
+			// the 8-wide tree (0.68 x the steps of the 4-wide one, each 1.4 x as long) when the scene carries one of at most 16 levels -- a group of hit children per
+			// level is all its stack ever holds -- and its rays are expected to take many steps: measured over rooms and colonnades of 1 k ... 10 M triangles
+			// (tools/gpu_bvh8_sweep.py) the 8-wide walk loses 3 - 10 % below ~40 expected steps of the 4-wide tree (the builder's sum of node areas over the root's),
+			// breaks even there and wins 3 - 9 % from 59 up.  RAYLIB_BVH8=0|1 overrides the choice.
+			const char* w8 = getenv("RAYLIB_BVH8");
+			if (D->hasNodes8 && D->depth8 <= 16 && (w8 ? atoi(w8) != 0 : D->sahNodes4 >= RL_BVH8_MIN_STEPS)) { width = 8; return (TraceKernel)k_trace_pool<32, PRIMS, 2, 16, 3>; }
+			return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, 1> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, 1>;
 		}
 		if constexpr (STACK == 32) {
 			const bool wantShort = e ? atoi(e) != 0 : D->bvhDepth <= RL_POOL_SHORT_MAXDEPTH;
@@ -523,9 +531,9 @@ struct PendingRender {
 	RankCtx* ctx = nullptr;
 	bool pathTrace = false, lastBatchPending = false;
 	float traceMs = 0.0f;
-	uint32_t launches = 0, schedulePaths = 1, jobHeads = 0;
+	uint32_t launches = 0, schedulePaths = 1, jobHeads = 0, treeWidth = 2;
 	uint64_t pixels = 0;
-	uint64_t culledSamples = 0; uint32_t culledRaysPerSample = 0;   // camera samples of cells outside the scene's silhouette: reported apart, not traced (CullCells)
+	uint64_t culledSamples = 0; uint32_t culledRaysPerSample = 0, culledSkyTexels = 0;   // camera samples of cells outside the scene's silhouette: reported apart, not traced (CullCells)
 	uint32_t culledCells = 0, listedCells = 0;
 	bool enqueuedToEnd = false;                // EnqueueRender reached the ev[slot][7] record (FinishRender waits for it; otherwise for the whole stream)
 	float4* out = nullptr; size_t outBytes = 0;
@@ -592,8 +600,8 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 		uint32_t minTris = 256; if (const char* e = getenv("RAYLIB_POOL_MIN_TRIS")) minTris = (uint32_t)atoi(e);
 		int poolK = (STACK <= 32 && !PRIMS && sc.triangles.size() >= minTris) ? 2 : 0;
 		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
-		bool shortStack = false, wide = false;
-		TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, DS, shortStack, wide);
+		bool shortStack = false; int width = 2;
+		TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, DS, shortStack, width);
 		// k_trace walks the 4-wide tree too when the scene has one whose worst-case stack fits this instantiation's LDS stack:
 		// on float boxes if the scene carries them (small scenes), else on the grid nodes
 		DSceneView traceView = D->view;
@@ -604,7 +612,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 			const char* w = getenv("RAYLIB_BVH4");
 			const bool baseWide = !PRIMS && DS->hasNodes4 && DS->stackNeed4 <= (uint32_t)STACK && (w ? atoi(w) != 0 : true);
 			if (!baseWide) { traceView.nodes4 = nullptr; traceView.nodes4f = nullptr; }
-			wide = baseWide;
+			width = baseWide ? 4 : 2;
 			const bool full = traceView.nodes4f != nullptr;
 			if (full) traceView.nodes4 = nullptr;
 			// the whole scene in LDS when it fits the fixed layout (rl_render.hip RL_LDS_*); RAYLIB_LDS_SCENE=0 keeps it in global memory
@@ -616,13 +624,13 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				const char* f = getenv("RAYLIB_LEAF_LIST");
 				const bool flat = lds && traceView.leafList != nullptr && traceView.numLeafRecords <= RL_LEAFLIST_RECORDS && sc.triangles.size() <= RL_LEAFLIST_MAXTRIS && (f ? atoi(f) != 0 : true)
 				                  && st.rayTMin >= 0.0f;   // its sortable keys are entry distances, never negative (rl_render.hip TraverseLeafList)
-				if (flat) traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, 2>;
+				if (flat) { traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, 2>; width = 0; }
 				else if (lds) traceKernel = (TraceKernel)k_trace<STACK, PRIMS, true, 1>;
 			}
 			if (!lds) traceKernel = full ? (TraceKernel)k_trace<STACK, PRIMS, true> : (TraceKernel)k_trace<STACK, PRIMS, false>;
 		}
 		const uint32_t pathsPerThread = poolK > 0 ? (uint32_t)poolK : 1u;
-		pend.schedulePaths = pathsPerThread;
+		pend.schedulePaths = pathsPerThread; pend.treeWidth = (uint32_t)width;
 		// ---- cells that cannot see the scene leave the job list (CullCells) ----
 		uint32_t numActive = numLocalCells;
 		{
@@ -666,7 +674,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 				P.activeCells = R.cellList[q]; P.cellEmpty = (const uint8_t*)(R.cellList[q] + R.cellListCells[q]); P.numActiveCells = numActive;
 				P.emptyL[0] = R.cullL[q][0]; P.emptyL[1] = R.cullL[q][1]; P.emptyL[2] = R.cullL[q][2];
 				P.emptySky = traceView.sky ? 1u : 0u;
-				pend.culledSamples = R.cullEmptyPixels[q] * (uint64_t)SPP; pend.culledRaysPerSample = R.cullRays[q];
+				pend.culledSamples = R.cullEmptyPixels[q] * (uint64_t)SPP; pend.culledRaysPerSample = R.cullRays[q]; pend.culledSkyTexels = traceView.sky ? 1u : 0u;
 			}
 			pend.culledCells = numLocalCells - numActive; pend.listedCells = numActive;
 		}
@@ -807,8 +815,10 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 	// (each would have been one root-box query, two with a sun -- what the megakernel counts for a sample it decides at the root)
 	stats.culledCells += pend.culledCells; stats.listedCells += pend.listedCells;
 	stats.culledSamples += pend.culledSamples; stats.culledRays += pend.culledSamples * pend.culledRaysPerSample;
+	stats.texFetches += pend.culledSamples * pend.culledSkyTexels;   // (k_resolve DOES look up the sky texel of every sample of a dropped cell: executed, counted)
 	stats.waveTrips += cnt[CNT_TRIPS];
 	stats.pathsPerWave = 64u * pend.schedulePaths;
+	stats.treeWidth = pend.treeWidth; stats.nodeBytes = pend.treeWidth == 8 ? (uint32_t)sizeof(DNode8) : 64u;
 	stats.pixels += pend.pixels;
 	stats.kernelMs = std::max(stats.kernelMs, (double)totalMs);
 	stats.traceKernelMs = std::max(stats.traceKernelMs, (double)(pend.pathTrace ? pend.traceMs : totalMs));

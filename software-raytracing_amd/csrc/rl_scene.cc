@@ -153,10 +153,20 @@ bool Scene::BuildAccel(float t0, float t1)
 		for (DNode4& n : bvh.nodes4) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 		for (DNode4Q& n : bvh.nodes4q) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 		for (DNode4& n : bvh.leafList) for (int k = 0; k < 4; ++k) patch(n.child[k]);
+		for (DNode8& n : bvh.nodes8) {   // the 8-wide node names its leaf children's triangles through triBase + leafMask; the flag is a bit per child
+			n.alphaMask = 0;
+			for (int c = 0; c < 8; ++c) {
+				const uint32_t nib = (n.leafMask >> (4 * c)) & 15u;
+				if (!nib) continue;
+				const uint32_t first = n.triBase + (uint32_t)__builtin_popcount(n.leafMask & ((1u << (4 * c)) - 1u)), count = (uint32_t)__builtin_popcount(nib);
+				for (uint32_t k = 0; k < count; ++k) if (alpha[bvh.triOrder[first + k]]) { n.alphaMask |= 1u << c; break; }
+			}
+		}
 	}
 	Log("Scene finalized: %u triangles, %u BVH nodes, depth %u, SAH cost %.2f (BVH build %.2f s)",
 	    (unsigned)triangles.size(), (unsigned)bvh.nodes.size(), bvh.depth, bvh.sahCost, buildSec);
 	if (!bvh.nodes4.empty()) Log("\twide tree: %u BVH4 nodes, worst-case traversal stack %u entries", (unsigned)bvh.nodes4.size(), bvh.stackNeed4);
+	if (!bvh.nodes8.empty()) Log("\t8-wide tree: %u nodes, %u levels; expected node steps of a random ray %.1f (4-wide tree: %.1f)", (unsigned)bvh.nodes8.size(), bvh.depth8, bvh.sahNodes8, bvh.sahNodes4);
 	if (!bvh.leafList.empty()) {
 		unsigned leaves = 0;
 		for (const DNode4& nd : bvh.leafList) for (int k = 0; k < 4; ++k) if (nd.child[k] != DNODE_EMPTY) ++leaves;

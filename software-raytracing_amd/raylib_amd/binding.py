@@ -31,7 +31,8 @@ class Stats(C.Structure):
                 ("waveTrips", C.c_uint64), ("pathsPerWave", C.c_uint32), ("ranks", C.c_uint32),
                 ("gatherMode", C.c_uint32), ("rcclCommSize", C.c_uint32), ("devices", C.c_uint32), ("jobHeads", C.c_uint32),
                 ("gatherMs", C.c_double), ("scatterMs", C.c_double), ("rankKernelMs", C.c_double * 16), ("rankTraceMs", C.c_double * 16),
-                ("culledCells", C.c_uint32), ("listedCells", C.c_uint32), ("culledSamples", C.c_uint64), ("culledRays", C.c_uint64)]
+                ("culledCells", C.c_uint32), ("listedCells", C.c_uint32), ("culledSamples", C.c_uint64), ("culledRays", C.c_uint64),
+                ("treeWidth", C.c_uint32), ("nodeBytes", C.c_uint32)]
 
     GATHER_MODES = {0: "none", 1: "rccl", 2: "peer"}
 
@@ -52,8 +53,8 @@ NODE_B, TRI_B, SHADE_B, TEXEL_B, PIXEL_B = 64, 64, 64, 16, 16
 
 
 def algorithmic_bytes(stats):
-    """nodes*NODE_B + tris*TRI_B + shaded*SHADE_B + texels*TEXEL_B + pixels*16."""
-    return (stats.nodesVisited * NODE_B + stats.trisTested * TRI_B + stats.shadedHits * SHADE_B +
+    """nodes*NODE_B + tris*TRI_B + shaded*SHADE_B + texels*TEXEL_B + pixels*16 (NODE_B = 80 when the 8-wide tree was walked)."""
+    return (stats.nodesVisited * (getattr(stats, "nodeBytes", 0) or NODE_B) + stats.trisTested * TRI_B + stats.shadedHits * SHADE_B +
             stats.texFetches * TEXEL_B + stats.pixels * PIXEL_B)
 
 
@@ -127,6 +128,7 @@ _EXPORTS = {
     "RaylibAMD_ParseFloat": (C.c_float, [C.c_char_p]),
     "RaylibAMD_ImageSize": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "RaylibAMD_SceneBVH4Info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "RaylibAMD_SceneBVH8Info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "RaylibAMD_SceneLeafListInfo": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "RaylibAMD_SceneBVHHash": (C.c_uint64, [C.c_void_p]),
     "RaylibAMD_CameraExport": (None, [C.c_void_p, C.POINTER(C.c_float)]),

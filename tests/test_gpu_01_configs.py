@@ -87,7 +87,8 @@ def test_config2_300k_triangles_1080p_128spp(gpu_lib, oracle, workdir, monkeypat
     # every schedule of the megakernel gives the same bits and the same ray / shading counts (2 spp keeps this part short)
     base = ses.render(1920, 1080, 2)
     sb = ses.stats().as_dict()
-    for env in (dict(RAYLIB_POOL="0"), dict(RAYLIB_POOL_SHORT_STACK="0"), dict(RAYLIB_BVH4="0")):
+    assert sb["treeWidth"] == 8 and sb["nodeBytes"] == 80     # a scene this deep walks the 8-wide tree by default (RaylibAMD_SceneBVH8Info: 59 expected steps on the 4-wide one)
+    for env in (dict(RAYLIB_POOL="0"), dict(RAYLIB_POOL_SHORT_STACK="0"), dict(RAYLIB_BVH4="0"), dict(RAYLIB_BVH8="0")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other = ses.render(1920, 1080, 2)
@@ -96,6 +97,8 @@ def test_config2_300k_triangles_1080p_128spp(gpu_lib, oracle, workdir, monkeypat
             monkeypatch.delenv(k)
         assert np.array_equal(bits(other), bits(base)), env
         assert so["rays"] == sb["rays"] and so["shadedHits"] == sb["shadedHits"] and so["cameraSamples"] == sb["cameraSamples"], env
+        if "RAYLIB_POOL" not in env:     # (k_trace's LDS stack is too short for this scene's 4-wide tree: it walks the binary one)
+            assert so["treeWidth"] == (2 if "RAYLIB_BVH4" in env else 4), env
     ses.close()
 
 

@@ -20,7 +20,7 @@ def _l2(a, b):
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13, 21, 22])
-def test_random_scenes_against_oracle(seed, gpu_lib, oracle, workdir):
+def test_random_scenes_against_oracle(seed, gpu_lib, oracle, workdir, monkeypatch):
     from raylib_amd import binding
     rng = np.random.RandomState(seed)
     d = os.path.join(str(workdir), "fuzz%d" % seed); os.makedirs(d, exist_ok=True)
@@ -53,6 +53,13 @@ def test_random_scenes_against_oracle(seed, gpu_lib, oracle, workdir):
                                    sky_image=scenes.sky_panorama() if sky else None)
         gpu_lib.RaylibAMD_SetSeed(seed_val)
         img = ses.render(w, h, spp, max_path=max_path)
+        if n > 108:
+            # these scenes are too shallow for the 8-wide tree to be the default (RaylibAMD_SceneBVH8Info): force it, same bits required
+            monkeypatch.setenv("RAYLIB_BVH8", "1"); monkeypatch.setenv("RAYLIB_POOL", "2")
+            img8 = ses.render(w, h, spp, max_path=max_path)
+            assert ses.stats().treeWidth == 8 and ses.stats().nodeBytes == 80
+            monkeypatch.delenv("RAYLIB_BVH8"); monkeypatch.delenv("RAYLIB_POOL")
+            assert ((bits(img8) == bits(img)) | (np.isnan(img8) & np.isnan(img))).all(), "case %d: the 8-wide walk differs from the default schedule" % case
         gpu_lib.RaylibAMD_SetSeed(1)
         ses.close()
         flat = objflat.load_obj(obj, oracle, texture_loader=helpers.texture_loader, sun_illuminance=sun, sun_direction=sun_dir)

@@ -289,10 +289,15 @@ def test_pool_schedule_is_default_on_deep_bvh_and_bit_identical(mid_scene, gpu_l
         assert np.array_equal(bits(ses.render(96, 64, 8, max_path=6)), bits(base)), mode
     monkeypatch.delenv("RAYLIB_POOL_SHORT_STACK")
     # sample batches (the sample buffer is summed in sample order whatever the batch size) and the BVH2 under the pool schedule
-    for env in (dict(RAYLIB_SAMPLE_BATCH="3"), dict(RAYLIB_BVH4="0"), dict(RAYLIB_BVH4="0", RAYLIB_SAMPLE_BATCH="1")):
+    # ... and the 8-wide tree, which this scene is too shallow to get by default
+    assert st["treeWidth"] == 4 and st["nodeBytes"] == 64
+    for env in (dict(RAYLIB_SAMPLE_BATCH="3"), dict(RAYLIB_BVH4="0"), dict(RAYLIB_BVH4="0", RAYLIB_SAMPLE_BATCH="1"), dict(RAYLIB_BVH8="1"), dict(RAYLIB_BVH8="1", RAYLIB_JOB_HEADS="1")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert np.array_equal(bits(ses.render(96, 64, 8, max_path=6)), bits(base)), env
+        se = ses.stats().as_dict()
+        assert se["treeWidth"] == (8 if "RAYLIB_BVH8" in env else 2 if "RAYLIB_BVH4" in env else 4), env
+        assert se["rays"] == st0["rays"] and se["shadedHits"] == st0["shadedHits"], env
         for k in env:
             monkeypatch.delenv(k)
     # windows recomputed by the CPU oracle with the same pixel keys

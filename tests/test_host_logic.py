@@ -157,8 +157,27 @@ def test_small_scenes_carry_a_valid_leaf_list(lib, workdir):
             assert lib.RaylibAMD_SceneBVH4Info(ses.scene, None, None) == 1, (make.__name__, kw)
         if expect:
             assert 1 <= leaves <= 24 and 1 <= most.value <= 8 and n <= 108, (make.__name__, kw, n, leaves, most.value)
+            assert lib.RaylibAMD_SceneBVH8Info(ses.scene, None, None, None, None) == 0    # (the 8-wide tree orders triangle slots its own way: not for leaf-list scenes)
         else:
             assert leaves == 0 and n > 108, (make.__name__, kw, n, leaves)
+        ses.close()
+
+
+def test_larger_scenes_carry_a_valid_eight_wide_tree(lib, workdir):
+    """Above 108 triangles the builder also emits the 8-wide collapse (rl_bvh.cc CollapseWide8 / EmitWide8): structurally valid on rooms, soups (long thin
+    triangles, coincident vertices) and cut-out scenes, fewer nodes and fewer expected steps than the 4-wide tree, levels within what the kernel's group
+    stack holds (16)."""
+    from raylib_amd import binding
+    cases = [(scenes.soup, dict(n_tris=109)), (scenes.soup, dict(n_tris=5000, seed=3)), (scenes.cornell, dict(tess=9, displace_fraction=0.2)),
+             (scenes.cornell, dict(tess=40)), (scenes.cutout, dict(tess=12)), (scenes.colonnade, dict(tess=2))]
+    for k, (make, kw) in enumerate(cases):
+        obj, n = make(os.path.join(str(workdir), "w8_%d.obj" % k), **kw)[:2]
+        ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+        n4, need, n8, lev, s4, s8 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_float(), C.c_float()
+        assert lib.RaylibAMD_SceneBVH4Info(ses.scene, C.byref(n4), C.byref(need)) == 1, (make.__name__, kw)
+        assert lib.RaylibAMD_SceneBVH8Info(ses.scene, C.byref(n8), C.byref(lev), C.byref(s4), C.byref(s8)) == 1, (make.__name__, kw)
+        assert n / 8 / 4 <= n8.value < n4.value and 1 <= lev.value <= 16, (make.__name__, kw, n, n4.value, n8.value, lev.value)
+        assert 1.0 <= s8.value < s4.value, (make.__name__, kw, s4.value, s8.value)
         ses.close()
 
 

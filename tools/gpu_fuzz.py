@@ -12,7 +12,8 @@ MODES = [dict(RAYLIB_POOL="0"), dict(), dict(RAYLIB_BVH4="0"), dict(RAYLIB_POOL_
          dict(RAYLIB_POOL="3", RAYLIB_BVH4="0"), dict(RAYLIB_POOL="2", RAYLIB_SAMPLE_BATCH="1"),
          dict(RAYLIB_POOL="0", RAYLIB_LEAF_LIST="0"), dict(RAYLIB_POOL="0", RAYLIB_LDS_SCENE="0"),
          dict(RAYLIB_JOB_HEADS="1"), dict(RAYLIB_POOL="0", RAYLIB_JOB_HEADS="3", RAYLIB_JOB_CHUNK="64"),
-         dict(RAYLIB_CULL_CELLS="0")]   # round 3: one head; three heads with the smallest chunks (every wave steals)
+         dict(RAYLIB_CULL_CELLS="0"),   # round 3: one head; three heads with the smallest chunks (every wave steals)
+         dict(RAYLIB_POOL="2", RAYLIB_BVH8="1")]   # round 4: the 8-wide tree (scenes above 108 triangles carry one; these are too shallow to get it by default)
 if os.environ.get("FUZZ_MODES_JSON"): import json; MODES = json.loads(os.environ["FUZZ_MODES_JSON"])   # debugging: the schedules to run, e.g. '[{"RAYLIB_POOL": "0"}]'
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 bad = 0
@@ -59,7 +60,7 @@ for case in range(cases):
         for k in env: del os.environ[k]
         # cut-out scenes run the alpha test on traversal candidates, whose number depends on the order candidates are met in:
         # their shading / texel counts are schedule-dependent, rays and samples are not
-        key = (st["rays"], st["cameraSamples"]) if kind in (2, 4) else (st["rays"], st["shadedHits"], st["cameraSamples"], st["texFetches"])
+        key = (st["frameRays"], st["frameSamples"]) if kind in (2, 4) else (st["frameRays"], st["shadedHits"], st["frameSamples"], st["texFetches"])   # (frame totals: executed + culled)
         if ref is None: ref = (img, key)
         elif not (np.array_equal(bits(img), bits(ref[0])) and key == ref[1]):
             bad += 1
