@@ -303,8 +303,65 @@ static void QuantizeWide(BVH& out)
 struct Wide8Node { int32_t kid[8]; uint32_t firstChild; };   // TmpNode index per slot (-1: none); node index of the first inner child
 struct Wide8 { std::vector<Wide8Node> nodes; std::vector<int32_t> leafOrder; uint32_t depth = 0; double sah = 0.0; };
 
+// Which binary nodes become 8-wide nodes is decided for the whole tree at once (the dynamic programme of Ylitie, Karras, Laine, "Efficient incoherent ray
+// traversal on GPUs through compressed wide BVHs", HPG 2017, section 3.1, without its leaf merging: the binary tree's leaves stay what they are), minimising the
+// sum of the 8-wide nodes' surface areas -- the node steps a random ray is expected to take.  c[n][i - 1]: the least cost of the sub-tree under n when it may
+// occupy i slots of its parent 8-wide node (i = 1: n is itself an 8-wide node, or a leaf).  Opening the largest child first (what the 4-wide tree does; here
+// RAYLIB_WIDE_GREEDY=1) leaves 4.1 of the 8 slots used on the 298 k-triangle room -- 63 655 nodes, an expected 39.5 steps; the plan: 45 455 nodes, 5.4 slots used,
+// 38.5 steps, and frames 0.3 ... 4.7 % shorter (tools/gpu_w8_plan_ab.py).  For the 4-wide tree the same plan buys 0.7 ... 2 % of expected steps and a deeper
+// worst-case stack (colonnade 29 -> 33 entries: the next kernel instance): not used there.
+template <int W> struct WidePlan {
+	float c[W - 1];
+	uint32_t bits;   // k (slots of the left sub-tree) when n's children share j = 2 ... W slots: 3 bits each from bit 0; bit 21 + i: c[i - 1] is c[i - 2] (i = 2 ... W - 1)
+	int kAt(int j) const { return (int)((bits >> (3 * (j - 2))) & 7u); }
+	bool sameAsFewer(int i) const { return ((bits >> (21 + i)) & 1u) != 0u; }
+};
+template <int W>
+static void PlanWide(const std::vector<TmpNode>& T, int32_t root, std::vector<WidePlan<W>>& plan)
+{
+	plan.assign(T.size(), WidePlan<W>());
+	const double rootArea = std::max((double)T[root].box.halfArea(), 1e-30);
+	for (size_t t = T.size(); t-- > 0;) {   // children follow their parent in T: a reverse sweep sees them first
+		WidePlan<W>& P = plan[t];
+		if (T[t].left < 0) { for (int i = 0; i < W - 1; ++i) P.c[i] = 0.0f; P.bits = 0; continue; }
+		const WidePlan<W>& L = plan[T[t].left]; const WidePlan<W>& R = plan[T[t].right];
+		float d[W + 1]; uint32_t bits = 0;   // d[j]: n's two children share j slots
+		for (int j = 2; j <= W; ++j) {
+			float best = FLT_MAX; int bestK = 1;
+			for (int k = 1; k < j; ++k) { if (k > W - 1 || j - k > W - 1) continue; const float v = L.c[k - 1] + R.c[j - k - 1]; if (v < best) { best = v; bestK = k; } }
+			d[j] = best; bits |= (uint32_t)bestK << (3 * (j - 2));
+		}
+		P.c[0] = (float)((double)T[t].box.halfArea() / rootArea) + d[W];
+		for (int i = 2; i <= W - 1; ++i) {
+			if (d[i] < P.c[i - 2]) P.c[i - 1] = d[i];
+			else { P.c[i - 1] = P.c[i - 2]; bits |= 1u << (21 + i); }
+		}
+		P.bits = bits;
+	}
+}
+// the planned children of the W-wide node rooted at t: its two sub-trees share W slots as the plan says; a sub-tree given i slots is either opened (its own two
+// children share them) or, with one slot, a child of this node.  Returns their number.
+template <int W>
+static int PlannedChildren(const std::vector<TmpNode>& T, const std::vector<WidePlan<W>>& plan, int32_t t, int32_t* kids)
+{
+	struct Share { int32_t t; int slots; } todo[2 * W]; int top = 0, nk = 0;
+	{ const int k = plan[t].kAt(W); todo[top++] = { T[t].right, W - k }; todo[top++] = { T[t].left, k }; }
+	while (top > 0) {
+		const Share sh = todo[--top];
+		if (T[sh.t].left < 0) { kids[nk++] = sh.t; continue; }
+		int i = sh.slots;
+		while (i > 1 && plan[sh.t].sameAsFewer(i)) --i;
+		if (i == 1) { kids[nk++] = sh.t; continue; }
+		const int k = plan[sh.t].kAt(i);
+		todo[top++] = { T[sh.t].right, i - k }; todo[top++] = { T[sh.t].left, k };
+	}
+	return nk;
+}
+
 static void CollapseWide8(const std::vector<TmpNode>& T, int32_t root, Wide8& W)
 {
+	std::vector<WidePlan<8>> plan;
+	{ const char* e = getenv("RAYLIB_WIDE_GREEDY"); if (!(e && atoi(e) != 0)) PlanWide<8>(T, root, plan); }
 	struct Item { int32_t tmp; uint32_t level; };
 	std::vector<Item> queue;
 	queue.push_back({ root, 1u });
@@ -315,6 +372,8 @@ static void CollapseWide8(const std::vector<TmpNode>& T, int32_t root, Wide8& W)
 		W.depth = std::max(W.depth, it.level);
 		W.sah += (double)T[it.tmp].box.halfArea() / rootArea;
 		int32_t kids[8]; int nk = 0;
+		if (!plan.empty()) nk = PlannedChildren<8>(T, plan, it.tmp, kids);
+		else {
 		kids[nk++] = T[it.tmp].left; kids[nk++] = T[it.tmp].right;
 		while (nk < 8) {
 			int best = -1; float bestArea = -1.0f;
@@ -322,6 +381,7 @@ static void CollapseWide8(const std::vector<TmpNode>& T, int32_t root, Wide8& W)
 			if (best < 0) break;
 			const int32_t open = kids[best];
 			kids[best] = T[open].left; kids[nk++] = T[open].right;
+		}
 		}
 		const Box& nb = T[it.tmp].box;
 		const double cx = 0.5 * ((double)nb.mn.x + nb.mx.x), cy = 0.5 * ((double)nb.mn.y + nb.mx.y), cz = 0.5 * ((double)nb.mn.z + nb.mx.z);
