@@ -137,8 +137,9 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
     avg_launch_ms = acc["trace_ms"] / launches
     sec = avg_launch_ms * 1e-3
     samples_per_launch = acc["samples"] / launches
-    # ---- algorithmic bytes, SURVEY 8(d): a property of the WORKLOAD -- the records a tree walk of this scene fetches: 64 B per BVH4
-    # grid-node step (a float-box BVH4 step = 2 records), 64 B per triangle test, 64 B per shading record, 16 B per texel and per pixel.
+    # ---- algorithmic bytes, SURVEY 8(d): a property of the WORKLOAD -- the records a tree walk of this scene fetches: 64 B per 4-wide
+    # grid-node step (a float-box step = 2 records) or 80 B per 8-wide one (the scenes deep enough to get that tree, RaylibAMDStats.treeWidth /
+    # nodeBytes say which), 64 B per triangle test, 64 B per shading record, 16 B per texel and per pixel.
     # Where the kernel that ran walks something else (the Cornell class: the leaf list, every box of it per ray, from LDS), the tree-walk
     # counts come from one untimed frame with RAYLIB_LEAF_LIST=0 and the kernel's own LDS-served bytes are reported next to them.
     ran_bytes = acc["bytes"] / launches
@@ -151,7 +152,8 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
     alg_gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
     algorithmic = {"bytes_per_launch": alg_bytes, "bytes_per_camera_sample": alg_bytes / max(1.0, samples_per_launch), "gbs": alg_gbs,
                    "frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
-                   "definition": "64 B x (BVH4-walk node records + triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran",
+                   "definition": "node bytes x node records of the tree walk (64 B on the 4-wide tree, 80 B on the 8-wide one) + 64 B x (triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran",
+                   "tree_width": acc.get("tree_width"), "node_bytes": acc.get("node_bytes"),
                    "served_elsewhere": served}
     out = {"kernel": "k_trace" if acc["paths_per_wave"] <= 64 else "k_trace_pool", "paths_per_wave": int(acc["paths_per_wave"]),
            "avg_launch_ms": avg_launch_ms, "launches": acc["launches"], "job_heads": acc.get("job_heads"), "algorithmic": algorithmic}
@@ -225,6 +227,7 @@ def accumulate(acc, stats, binding):
     acc["culled_rays"] += stats.culledRays; acc["culled_samples"] += stats.culledSamples; acc["culled_cells"] = stats.culledCells; acc["listed_cells"] = stats.listedCells
     acc["paths_per_wave"] = stats.pathsPerWave
     acc["job_heads"] = stats.jobHeads
+    acc["tree_width"] = int(stats.treeWidth); acc["node_bytes"] = int(stats.nodeBytes)
 
 
 def new_acc():

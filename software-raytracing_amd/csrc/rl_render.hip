@@ -111,7 +111,7 @@ __device__ __forceinline__ bool isZero(V3 a) { return a.x == 0.0f && a.y == 0.0f
 // job queue empty and when they end (s_memrealtime, 100 MHz), three arrays of 8192 slots behind the counters
 #ifdef RL_DIAG_TIMELINE
 #define RL_TIMELINE_SLOTS (4 * 8192)   /* start | job list seen empty | end | XCC id */
-#define RL_TIMELINE(which) { if (lane == 0 && (gtid >> 6) < 8192u) { counters[CNT_COUNT + 24 + (which) * 8192 + (gtid >> 6)] = __builtin_amdgcn_s_memrealtime(); if ((which) == 0) counters[CNT_COUNT + 24 + 3 * 8192 + (gtid >> 6)] = XccId(); } }
+#define RL_TIMELINE(which) { if (lane == 0 && (gtid >> 6) < 8192u) { countersK[CNT_COUNT + 24 + (which) * 8192 + (gtid >> 6)] = __builtin_amdgcn_s_memrealtime(); if ((which) == 0) countersK[CNT_COUNT + 24 + 3 * 8192 + (gtid >> 6)] = XccId(); } }
 #else
 #define RL_TIMELINE_SLOTS 0
 #define RL_TIMELINE(which)
