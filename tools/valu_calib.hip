@@ -96,6 +96,17 @@ KERNEL(bfe_u32, unsigned, unsigned, STREAM8("v_bfe_u32 %0, %0, 4, 8", "v"(a)))
 KERNEL(bfi_b32, unsigned, unsigned, STREAM8("v_bfi_b32 %0, %1, %0, %2", "v"(a) COMMA "v"(b)))
 KERNEL(perm_b32, unsigned, unsigned, STREAM8("v_perm_b32 %0, %0, %1, %2", "v"(a) COMMA "v"(b)))
 KERNEL(alignbit_b32, unsigned, unsigned, STREAM8("v_alignbit_b32 %0, %0, %1, 7", "v"(a)))
+KERNEL(pk_fma_f16, unsigned, unsigned, STREAM8("v_pk_fma_f16 %0, %0, %1, %2", "v"(a) COMMA "v"(b)))
+KERNEL(pk_max_f16, unsigned, unsigned, STREAM8("v_pk_max_f16 %0, %0, %1", "v"(a)))
+KERNEL(pk_min_f16, unsigned, unsigned, STREAM8("v_pk_min_f16 %0, %0, %1", "v"(a)))
+KERNEL(pk_maximum3_f16, unsigned, unsigned, STREAM8("v_pk_maximum3_f16 %0, %0, %1, %2", "v"(a) COMMA "v"(b)))
+KERNEL(pk_add_f16, unsigned, unsigned, STREAM8("v_pk_add_f16 %0, %0, %1", "v"(a)))
+KERNEL(pk_mul_f16, unsigned, unsigned, STREAM8("v_pk_mul_f16 %0, %0, %1", "v"(a)))
+KERNEL(pk_max_i16, unsigned, unsigned, STREAM8("v_pk_max_i16 %0, %0, %1", "v"(a)))
+KERNEL(pk_mad_i16, unsigned, unsigned, STREAM8("v_pk_mad_i16 %0, %0, %1, %2", "v"(a) COMMA "v"(b)))
+KERNEL(add_f32_sdwa, float, float, STREAM8("v_add_f32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v"(a)))
+KERNEL(cvt_f32_u32_sdwa, unsigned, unsigned, STREAM8("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2", "v"(a)))
+KERNEL(cvt_pk_f32_fp8, double, unsigned, STREAM8("v_cvt_pk_f32_fp8 %0, %1", "v"(a)))
 KERNEL(mul_u32_u24, unsigned, unsigned, STREAM8("v_mul_u32_u24 %0, %0, %1", "v"(a)))
 KERNEL(mad_u32_u24, unsigned, unsigned, STREAM8("v_mad_u32_u24 %0, %0, %1, %2", "v"(a) COMMA "v"(b)))
 KERNEL(add_co_u32, unsigned, unsigned, STREAM8_VCC("v_add_co_u32 %0, vcc, %0, %1", "v"(a)))
@@ -239,6 +250,17 @@ int main(int argc, char** argv)
 	CASE(bfi_b32, "INT32", 1, unsigned, unsigned, 3u, 5u)
 	CASE(perm_b32, "", 1, unsigned, unsigned, 3u, 0x03020100u)
 	CASE(alignbit_b32, "", 1, unsigned, unsigned, 3u, 0)
+	CASE(pk_fma_f16, "", 1, unsigned, unsigned, 0x3c003c00u, 0x38003800u)
+	CASE(pk_max_f16, "", 1, unsigned, unsigned, 0x3c003c00u, 0)
+	CASE(pk_min_f16, "", 1, unsigned, unsigned, 0x3c003c00u, 0)
+	CASE(pk_maximum3_f16, "", 1, unsigned, unsigned, 0x3c003c00u, 0x38003800u)
+	CASE(pk_add_f16, "", 1, unsigned, unsigned, 0x3c003c00u, 0)
+	CASE(pk_mul_f16, "", 1, unsigned, unsigned, 0x3c003c00u, 0)
+	CASE(pk_max_i16, "", 1, unsigned, unsigned, 0x3c003c00u, 0)
+	CASE(pk_mad_i16, "", 1, unsigned, unsigned, 0x00030003u, 0x00050005u)
+	CASE(add_f32_sdwa, "", 1, float, float, 0.5f, 0)
+	CASE(cvt_f32_u32_sdwa, "", 1, unsigned, unsigned, 0x11223344u, 0)
+	CASE(cvt_pk_f32_fp8, "", 1, double, unsigned, 0x38383838u, 0)
 	CASE(mul_u32_u24, "INT32", 1, unsigned, unsigned, 3u, 0)
 	CASE(mad_u32_u24, "INT32", 1, unsigned, unsigned, 3u, 5u)
 	CASE(add_co_u32, "INT32", 1, unsigned, unsigned, 3u, 0)
