@@ -602,3 +602,16 @@ def test_cells_dropped_from_the_job_list_cannot_see_the_box(lib, oracle):
     sdir = np.asarray([0, 0, 1], np.float32)      # the sun behind the box as seen from the camera: its ray runs through the box
     assert lib.RaylibAMD_CullCells(cam, fp(bounds), fp(sun), fp(sdir), 200, 120, empty.ctypes.data_as(C.POINTER(C.c_uint8)), fp(const)) == -1
     lib.Raylib_DestroyCamera(cam)
+
+
+def test_sanitizer_stub_covers_the_device_interface():
+    """tools/nodevice_stub.cc stands in for the HIP translation units in the ASan / UBSan build of the host side (tools/asan_host_check.sh): every Device*
+    function rl_host.h declares needs a definition there, or that build stops linking the day an entry point is added (it did, twice)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    decl = open(os.path.join(root, "software-raytracing_amd", "csrc", "rl_host.h")).read()
+    stub = open(os.path.join(root, "tools", "nodevice_stub.cc")).read()
+    declared = set(re.findall(r"^\s*(?:bool|void|void\*|int|int32_t)\s+(Device[A-Za-z0-9_]+)\s*\(", decl, re.M))
+    defined = set(re.findall(r"\b(Device[A-Za-z0-9_]+)\s*\(", stub))
+    assert len(declared) >= 10, declared
+    assert declared <= defined, sorted(declared - defined)

@@ -5,7 +5,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/libraylib_asan.so
 SRC="$ROOT/software-raytracing_amd/csrc"
 g++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -DRAYLIB_EXPORTS=1 \
-    -I"$ROOT/include" -I"$SRC" "$SRC"/rl_abi.cc "$SRC"/rl_scene.cc "$SRC"/rl_bvh.cc "$SRC"/rl_obj_loader.cc "$SRC"/rl_image_io.cc "$SRC"/rl_jpeg.cc "$SRC"/rl_log.cc \
+    -I"$ROOT/include" -I"$SRC" "$SRC"/rl_abi.cc "$SRC"/rl_scene.cc "$SRC"/rl_bvh.cc "$SRC"/rl_cull.cc "$SRC"/rl_obj_loader.cc "$SRC"/rl_image_io.cc "$SRC"/rl_jpeg.cc "$SRC"/rl_log.cc \
     "$ROOT/tools/nodevice_stub.cc" -o "$OUT" -lz -lpthread
 cd "$ROOT"
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \

@@ -9,9 +9,12 @@ bool DeviceClosestHit(Scene&, const float*, int32_t, float, void*) { return fals
 bool DevicePostProcess(Image&) { return false; }
 void* DeviceImagePixels(Image&) { return nullptr; }
 bool DeviceReadback(Image&) { return false; }
+bool DeviceDumpRGB(Image&, float*) { return false; }
 void DeviceFreePixels(void*) {}
 bool DeviceEvalMath(int, const float*, const float*, int, float*) { return false; }
 bool DeviceEvalHook(int, Scene*, const DCamera*, int, int, const float*, int, uint64_t, float*) { return false; }
 void DeviceReleaseScene(DeviceScene*) {}
 void DeviceShutdown() {}
+bool DeviceDrain(RaylibAMDStats*) { return false; }
+bool DeviceVerifyExactMath(int, uint64_t*, uint64_t*) { return false; }
 }
