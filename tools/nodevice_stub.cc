@@ -15,6 +15,7 @@ bool DeviceEvalMath(int, const float*, const float*, int, float*) { return false
 bool DeviceEvalHook(int, Scene*, const DCamera*, int, int, const float*, int, uint64_t, float*) { return false; }
 void DeviceReleaseScene(DeviceScene*) {}
 void DeviceShutdown() {}
+int DeviceNumRanks() { return 0; }
 bool DeviceDrain(RaylibAMDStats*) { return false; }
 bool DeviceVerifyExactMath(int, uint64_t*, uint64_t*) { return false; }
 }
