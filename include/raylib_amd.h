@@ -181,7 +181,7 @@ RAYLIB_API int32_t RaylibAMD_SceneBVH4Info(SceneHandle scene, uint32_t* outNodes
 /* The 8-wide collapse (80-byte grid nodes, children in octant order; scenes of more than 108 triangles): 0 = none, 1 = present and valid (every triangle slot
  * reached once, every node's 8-bit grid boxes contain the triangles below them, no path longer than *outLevels), -1 = invalid.  outSteps4 / outSteps8: the sum
  * over the 4-wide / 8-wide tree's nodes of (node area / root area) -- the node steps a random ray is expected to take; the megakernel walks the 8-wide
- * tree when outSteps4 >= 48 (RAYLIB_BVH8=0|1 overrides; RaylibAMDStats.treeWidth says which tree a frame walked). */
+ * tree when outSteps4 >= 40 (RAYLIB_BVH8=0|1 overrides; RaylibAMDStats.treeWidth says which tree a frame walked). */
 RAYLIB_API int32_t RaylibAMD_SceneBVH8Info(SceneHandle scene, uint32_t* outNodes8, uint32_t* outLevels, float* outSteps4, float* outSteps8);
 /* The leaf list of a small scene (at most 24 leaves, 108 triangles): what k_trace walks instead of the tree when the scene is LDS-resident.
  * Returns the number of leaves (0 = the scene has none); the list's validity is part of RaylibAMD_SceneBVH4Info's check. */

@@ -488,7 +488,7 @@ bool SyncSky(Scene& sc)
 	return true;
 }
 
-#define RL_BVH8_MIN_STEPS 48.0f
+#define RL_BVH8_MIN_STEPS 40.0f
 typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot, SampleRGB*, float*, unsigned long long*, unsigned int*);
 
 // poolK = 0: k_trace (one path per lane); poolK = K: k_trace_pool with 64*K paths per wave
@@ -505,10 +505,10 @@ TraceKernel SelectTraceKernel(int& poolK, const DeviceScene* D, bool& shortStack
 		if (poolK == 2 && wantWide) {
 			width = 4; shortStack = true;
 			if (e && atoi(e) == 0) { shortStack = false; return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, 32, 1> : (TraceKernel)k_trace_pool<64, PRIMS, 2, 32, 1>; }
-			// the 8-wide tree (0.68 x the steps of the 4-wide one, each 1.4 x as long) when the scene carries one of at most 16 levels -- a group of hit children per
+			// the 8-wide tree (0.67 x the steps of the 4-wide one, each 1.4 x as long) when the scene carries one of at most 16 levels -- a group of hit children per
 			// level is all its stack ever holds -- and its rays are expected to take many steps: measured over rooms and colonnades of 1 k ... 10 M triangles
-			// (tools/gpu_bvh8_sweep.py) the 8-wide walk loses 3 - 10 % below ~40 expected steps of the 4-wide tree (the builder's sum of node areas over the root's),
-			// breaks even there and wins 3 - 9 % from 59 up.  RAYLIB_BVH8=0|1 overrides the choice.
+			// (tools/gpu_bvh8_sweep.py, profiles/r04_bvh8_sweep.log) the 8-wide walk loses 2 - 8 % below ~30 expected steps of the 4-wide tree (the builder's sum of
+			// node areas over the root's), breaks even between 30 and 42 and wins 3 - 9 % from 59 up.  RAYLIB_BVH8=0|1 overrides the choice.
 			const char* w8 = getenv("RAYLIB_BVH8");
 			if (D->hasNodes8 && D->depth8 <= 16 && (w8 ? atoi(w8) != 0 : D->sahNodes4 >= RL_BVH8_MIN_STEPS)) { width = 8; return (TraceKernel)k_trace_pool<32, PRIMS, 2, 16, 3>; }
 			return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, 1> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, 1>;
