@@ -163,7 +163,7 @@ def test_small_scenes_carry_a_valid_leaf_list(lib, workdir):
         ses.close()
 
 
-def test_larger_scenes_carry_a_valid_eight_wide_tree(lib, workdir):
+def test_larger_scenes_carry_a_valid_eight_wide_tree(lib, workdir, monkeypatch):
     """Above 108 triangles the builder also emits the 8-wide collapse (rl_bvh.cc CollapseWide8 / EmitWide8): structurally valid on rooms, soups (long thin
     triangles, coincident vertices) and cut-out scenes, fewer nodes and fewer expected steps than the 4-wide tree, levels within what the kernel's group
     stack holds (16)."""
@@ -179,6 +179,14 @@ def test_larger_scenes_carry_a_valid_eight_wide_tree(lib, workdir):
         assert n / 8 / 4 <= n8.value < n4.value and 1 <= lev.value <= 16, (make.__name__, kw, n, n4.value, n8.value, lev.value)
         assert 1.0 <= s8.value < s4.value, (make.__name__, kw, s4.value, s8.value)
         ses.close()
+        # the planned collapse (least summed node area) is never worse than opening the largest child first, the A/B switch's tree is valid too
+        monkeypatch.setenv("RAYLIB_WIDE_GREEDY", "1")
+        ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+        g8, gs8 = C.c_uint32(), C.c_float()
+        assert lib.RaylibAMD_SceneBVH8Info(ses.scene, C.byref(g8), None, None, C.byref(gs8)) == 1, (make.__name__, kw)
+        assert s8.value <= gs8.value * (1 + 1e-5), (make.__name__, kw, s8.value, gs8.value)
+        ses.close()
+        monkeypatch.delenv("RAYLIB_WIDE_GREEDY")
 
 
 def test_bvh_build_is_the_same_tree_for_any_thread_count(lib, workdir, monkeypatch):
