@@ -99,6 +99,18 @@ def test_config2_300k_triangles_1080p_128spp(gpu_lib, oracle, workdir, monkeypat
         assert so["rays"] == sb["rays"] and so["shadedHits"] == sb["shadedHits"] and so["cameraSamples"] == sb["cameraSamples"], env
         if "RAYLIB_POOL" not in env:     # (k_trace's LDS stack is too short for this scene's 4-wide tree: it walks the binary one)
             assert so["treeWidth"] == (2 if "RAYLIB_BVH4" in env else 4), env
+    # the 8-wide walk behind Raylib_Render over three ranks (each rank its share of the cells, gathered on rank 0): the one-rank frame, bit for bit
+    out = os.path.join(d, "three_ranks.npz")
+    env = dict(os.environ, RAYLIB_NUM_GPUS="3", RAYLIB_GPU_MAP="0,0,0")
+    for k in ("RAYLIB_POOL", "RAYLIB_LIB", "RAYLIB_BVH8"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "multi_rank_child.py"), str(workdir), out, "obj", obj, "breakfast", "1920", "1080", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    three = np.load(out)
+    assert np.array_equal(bits(three["img"]), bits(base)), "Raylib_Render over three ranks differs from the one-rank frame"
+    assert three["stats"][0] == 3 and three["stats"][1] == sb["cameraSamples"] and three["stats"][3] == sb["rays"], three["stats"]
+    os.remove(out)
     ses.close()
 
 
