@@ -124,7 +124,7 @@ def step_times(ts):
     return {"min": min(ts) * 1e3, "median": statistics.median(ts) * 1e3, "max": max(ts) * 1e3, "n": len(ts)}
 
 
-def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
+def roofline_block(workload_name, acc, world, build_id, tree_walk=None, gpus_in_acc=1, frame_samples_per_launch=None):
     """The roofline object of the line.
 
     Measured in THIS run: launches, average megakernel launch duration (HIP events on the library's stream), the launch's record
@@ -132,7 +132,12 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
     counts by class are REPLAYED from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_traffic.json, written by
     tools/profile_round.sh -> tools/pmc_traffic.py); they sit in `replayed_pmc` with the build id of the library they were taken from,
     and when that is not the loaded library's (`RaylibAMD_BuildId`) the line says STALE and takes its headline figure from what this run
-    measured alone.  Peaks are constants."""
+    measured alone.  Peaks are constants.
+
+    N > 1: `acc` holds either the sum over the N ranks of one process (library mode: gpus_in_acc = N, the launch time is
+    the slowest rank's) or this rank's own launches (process mode: gpus_in_acc = 1); `frame_samples_per_launch` = the camera samples ALL ranks
+    executed per launch.  The N = 1 counter passes are then replayed SCALED by the share of the frame's executed camera samples `acc` covers
+    and priced against gpus_in_acc GPUs' peaks -- labelled as such; bytes a kernel was served from LDS are never put over the HBM peak."""
     launches = max(1, acc["launches"])
     avg_launch_ms = acc["trace_ms"] / launches
     sec = avg_launch_ms * 1e-3
@@ -143,24 +148,35 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
     # Where the kernel that ran walks something else (the Cornell class: the leaf list, every box of it per ray, from LDS), the tree-walk
     # counts come from one untimed frame with RAYLIB_LEAF_LIST=0 and the kernel's own LDS-served bytes are reported next to them.
     ran_bytes = acc["bytes"] / launches
-    if tree_walk is not None:
-        alg_bytes = tree_walk["bytes_per_launch"]
+    leaf_list_ran = acc.get("tree_width") == 0        # k_trace<.., LDS = 2>: no tree is walked, every ray reads every leaf box from LDS
+    hbm_peak = HBM_PEAK_GBS * gpus_in_acc             # the peak of the GPUs whose launches `acc` adds up
+    valu_peak = VALU_PEAK_GCYC * gpus_in_acc
+    served = None
+    if leaf_list_ran:
         served = {"schedule": "leaf list (k_trace<.., LDS = 2>): every traced ray reads all leaf-box records, from LDS",
                   "lds_served_bytes_per_launch": ran_bytes, "lds_served_bytes_per_camera_sample": ran_bytes / max(1.0, samples_per_launch)}
+    if tree_walk is not None:
+        alg_bytes = tree_walk["bytes_per_launch"]
+    elif leaf_list_ran:
+        alg_bytes = None                              # (no tree-walk frame was rendered: the LDS-served bytes are NOT the workload's HBM demand)
     else:
-        alg_bytes, served = ran_bytes, None
-    alg_gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
-    algorithmic = {"bytes_per_launch": alg_bytes, "bytes_per_camera_sample": alg_bytes / max(1.0, samples_per_launch), "gbs": alg_gbs,
-                   "frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
-                   "definition": "node bytes x node records of the tree walk (64 B on the 4-wide tree, 80 B on the 8-wide one) + 64 B x (triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran",
+        alg_bytes = ran_bytes
+    alg_gbs = alg_bytes / sec / 1e9 if (sec > 0 and alg_bytes is not None) else None
+    algorithmic = {"bytes_per_launch": alg_bytes, "bytes_per_camera_sample": None if alg_bytes is None else alg_bytes / max(1.0, samples_per_launch), "gbs": alg_gbs,
+                   "frac_of_hbm_peak": None if alg_gbs is None else alg_gbs / hbm_peak, "hbm_peak_gbs": hbm_peak, "gpus": gpus_in_acc,
+                   "definition": "node bytes x node records of the tree walk (64 B on the 4-wide tree, 80 B on the 8-wide one) + 64 B x (triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran"
+                                 + ("; summed over the %d ranks of this process, against %d GPUs' peak" % (gpus_in_acc, gpus_in_acc) if gpus_in_acc > 1 else ""),
                    "tree_width": acc.get("tree_width"), "node_bytes": acc.get("node_bytes"),
                    "served_elsewhere": served}
     out = {"kernel": "k_trace" if acc["paths_per_wave"] <= 64 else "k_trace_pool", "paths_per_wave": int(acc["paths_per_wave"]),
            "avg_launch_ms": avg_launch_ms, "launches": acc["launches"], "job_heads": acc.get("job_heads"), "algorithmic": algorithmic}
-    # ---- replayed hardware counters
+    # ---- replayed hardware counters (of the N = 1 run of this workload; N > 1: scaled by the share of the frame's executed samples `acc` covers)
     rec, stale, source = None, None, None
+    share = 1.0
+    if world > 1:
+        share = (samples_per_launch / frame_samples_per_launch) if frame_samples_per_launch else None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if world == 1 and os.path.exists(pmc):
+    if share is not None and os.path.exists(pmc):
         try:
             rec = json.load(open(pmc)).get(workload_name)
         except (OSError, ValueError) as e:
@@ -168,22 +184,25 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
     if rec:
         stale = rec.get("build_id") != build_id
         source = ("STALE: " if stale else "") + "replayed from profiles/pmc_traffic.json (%s, build %s; loaded library is build %s)" % (rec.get("round"), rec.get("build_id"), build_id)
-    traffic = rec["hbm_bytes_per_launch"] if rec else None
+        if world > 1:
+            source += "; N = 1 counters SCALED by %.4f = the share of the frame's executed camera samples these launches cover, against %d GPU(s)' peak" % (share, gpus_in_acc)
+    traffic = rec["hbm_bytes_per_launch"] * share if rec else None
     hbm = None
     if rec and stale and rec.get("cycles_per_launch"):
         # counters of another build: priced against THAT build's launch (its cycles at the spec clock), not against this run's time -- old counts over a
         # new time are a fraction of nothing; the line says STALE and the headline falls back to this run's algorithmic bytes
-        sec = rec["cycles_per_launch"] / 2.4e9
+        sec = rec["cycles_per_launch"] / 2.4e9 * share / gpus_in_acc
     if rec and sec > 0:
         gbs = traffic / sec / 1e9
-        hbm = {"measured_bytes_per_launch": traffic, "gbs": gbs, "frac": gbs / HBM_PEAK_GBS, "tcc_hit_rate": rec.get("tcc_hit_rate")}
+        hbm = {"measured_bytes_per_launch": traffic, "gbs": gbs, "frac": gbs / hbm_peak, "tcc_hit_rate": rec.get("tcc_hit_rate"), "scaled_from_n1": world > 1}
     valu = None
     if rec and sec > 0 and rec.get("valu_weighted_cycles_per_launch"):
-        wc = rec["valu_weighted_cycles_per_launch"]
+        wc = rec["valu_weighted_cycles_per_launch"] * share
         ach = wc / sec / 1e9
-        valu = {"weighted_issue_cycles_per_launch": wc, "insts_per_launch": rec.get("valu_insts_per_launch"),
-                "mean_cost_cycles_per_inst": wc / rec["valu_insts_per_launch"], "class_counts": rec.get("valu_class_counts"),
-                "achieved_gcyc_per_s": ach, "peak_gcyc_per_s": VALU_PEAK_GCYC, "frac_of_spec_peak": ach / VALU_PEAK_GCYC,
+        valu = {"weighted_issue_cycles_per_launch": wc, "insts_per_launch": rec.get("valu_insts_per_launch") * share if rec.get("valu_insts_per_launch") else None,
+                "scaled_from_n1": world > 1,
+                "mean_cost_cycles_per_inst": rec["valu_weighted_cycles_per_launch"] / rec["valu_insts_per_launch"], "class_counts": rec.get("valu_class_counts"),
+                "achieved_gcyc_per_s": ach, "peak_gcyc_per_s": valu_peak, "frac_of_spec_peak": ach / valu_peak,
                 # the same cycles against the cycles the launch really had (GRBM_GUI_ACTIVE / 8 of the profiled pass: the clock the chip held)
                 "frac_of_profiled_pass_cycles": rec.get("valu_weighted_busy_fraction"), "unweighted_2cyc_busy_fraction": rec.get("valu_busy_fraction"),
                 "weighted_busy_bounds_of_profiled_pass": rec.get("valu_weighted_busy_bounds"),
@@ -193,13 +212,17 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None):
                 "waves_per_simd": rec.get("waves_per_simd"), "salu_insts_per_launch": rec.get("salu_insts_per_launch"),
                 "profiled_clock_ghz": rec.get("profiled_clock_ghz")}
     # ---- headline: the resource nearest its roof among those measured with fresh counters; else this run's algorithmic bytes
+    scaled = " -- replayed from the N = 1 passes, scaled by executed camera samples" if world > 1 else ""
     if valu and not stale and (not hbm or valu["frac_of_spec_peak"] >= hbm["frac"]):
-        head = {"achieved": valu["achieved_gcyc_per_s"], "peak": VALU_PEAK_GCYC, "unit": "G SIMD-issue-cycles/s", "frac": valu["frac_of_spec_peak"], "resource": "VALU issue (class-weighted)"}
+        head = {"achieved": valu["achieved_gcyc_per_s"], "peak": valu_peak, "unit": "G SIMD-issue-cycles/s", "frac": valu["frac_of_spec_peak"], "resource": "VALU issue (class-weighted)" + scaled}
     elif hbm and not stale:
-        head = {"achieved": hbm["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "resource": "HBM (measured bytes)"}
+        head = {"achieved": hbm["gbs"], "peak": hbm_peak, "unit": "GB/s", "frac": hbm["frac"], "resource": "HBM (measured bytes)" + scaled}
+    elif alg_gbs is not None:
+        head = {"achieved": alg_gbs, "peak": hbm_peak, "unit": "GB/s", "frac": alg_gbs / hbm_peak, "resource": "HBM (algorithmic bytes of the tree walk; no fresh counters)"}
     else:
-        head = {"achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "resource": "HBM (algorithmic bytes; no fresh counters)"}
-    vf = valu["frac_of_profiled_pass_cycles"] if valu and valu["frac_of_profiled_pass_cycles"] else (valu["frac_of_spec_peak"] if valu else 0.0)
+        head = {"achieved": None, "peak": hbm_peak, "unit": "GB/s", "frac": None,
+                "resource": "none: no fresh counter passes for this build, and the kernel that ran reads its scene from LDS (its bytes are not an HBM figure)"}
+    vf = valu["frac_of_profiled_pass_cycles"] if valu and valu["frac_of_profiled_pass_cycles"] and world == 1 else (valu["frac_of_spec_peak"] if valu else 0.0)
     hf = hbm["frac"] if hbm else 0.0
     if hbm and hf >= 0.6 and hf >= vf:
         bound = "hbm"
@@ -316,9 +339,11 @@ def library_run(lib, binding, scenes, workload_name, steps, warmup, n_gpus, rank
         torch.cuda.synchronize()
         boundary["render_device_ms_per_step"] = (time.perf_counter() - t2) / k2 * 1e3
     tree_walk = None
-    if acc["paths_per_wave"] <= 64 and n_gpus == 1:
-        # the workload's algorithmic bytes: the same frame on the BVH4 walk (the leaf-list kernel reads every leaf box per ray, from LDS)
+    if acc.get("tree_width") == 0:
+        # the workload's algorithmic bytes: the same frame on the BVH4 walk (the leaf-list kernel reads every leaf box per ray, from LDS); with several ranks
+        # behind the call the counters are the ranks' sum and the launch count one rank's, as in the timed frames
         keep = os.environ.get("RAYLIB_LEAF_LIST")
+        lib.RaylibAMD_GetLastStats(C.byref(stats))     # (nothing of the frames above is still in flight when the switch changes)
         os.environ["RAYLIB_LEAF_LIST"] = "0"
         lib.Raylib_Render(C.byref(st), ses.scene, ses.camera, image)
         lib.RaylibAMD_GetLastStats(C.byref(stats))
@@ -402,8 +427,16 @@ def main():
                    "camera_samples_per_step": acc["samples"] / args.steps, "work": work_block(acc, args.steps),
                    "frame_check": r["frame_check"], "boundary": r["boundary"],
                    "build_id": build_id, "timed_region_s": elapsed},
-        "roofline": roofline_block(args.workload, acc, ranks, build_id, r["tree_walk"]),
+        "roofline": roofline_block(args.workload, acc, ranks, build_id, r["tree_walk"], gpus_in_acc=ranks,
+                                   frame_samples_per_launch=acc["samples"] / max(1, acc["launches"])),
     }
+    # the two N = 1 figures a scaling curve can start from: this mode's (Raylib_Render, what `python bench.py --gpus 1` -- the driver's
+    # N = 1 run -- times) and process mode's (RaylibAMD_RenderDevice into a caller's device buffer + one gather, what torch.distributed.run launches for N > 1)
+    out["config"]["n1_reference"] = {
+        "library_mode_ms_per_step": out["ms_per_step"] if ranks == 1 else None,
+        "process_mode_entry_ms_per_step": r["boundary"].get("render_device_ms_per_step"),
+        "note": "the driver's N = 1 line is library mode (Raylib_Render); its N > 1 lines are process mode (RaylibAMD_RenderDevice per rank + one RCCL gather per frame): "
+                "a SCALE curve compares those two, so process mode's own one-rank entry time stands here next to it"}
     if ranks > 1 or gpu_map:
         s = r["last_stats"]
         out["multi_gpu"] = {"ranks": ranks, "devices": s["devices"], "gpu_map": gpu_map, "gather": s["gatherMode"], "rccl_comm_size": s["rcclCommSize"],
@@ -536,6 +569,20 @@ def process_mode(args, rank, local_rank, world, torch, binding, scenes):
     km[rank] = stats.traceKernelMs
     dist.all_reduce(km, op=dist.ReduceOp.SUM)
 
+    # outside the timed region: this rank's share once more on the tree walk, where the kernel that ran read its scene from LDS (the leaf list) -- the workload's
+    # algorithmic bytes are the tree walk's, whatever schedule ran
+    tree_walk = None
+    if acc.get("tree_width") == 0:
+        keep = os.environ.get("RAYLIB_LEAF_LIST")
+        os.environ["RAYLIB_LEAF_LIST"] = "0"
+        torch.cuda.synchronize()
+        if lib.RaylibAMD_RenderDevice(C.byref(st), ses.scene, ses.camera, rank, world, C.c_void_p(mines[0].data_ptr())) == 1:
+            lib.RaylibAMD_GetLastStats(C.byref(stats))
+            tree_walk = {"bytes_per_launch": binding.algorithmic_bytes(stats) / max(1, stats.traceLaunches), "launch_ms": stats.traceKernelMs / max(1, stats.traceLaunches)}
+        if keep is None:
+            del os.environ["RAYLIB_LEAF_LIST"]
+        else:
+            os.environ["RAYLIB_LEAF_LIST"] = keep
     frame_check = None
     if rank == 0:
         # outside the timed region: the frame assembled from the ranks' cells against this rank's own render of the whole frame
@@ -570,8 +617,13 @@ def process_mode(args, rank, local_rank, world, torch, binding, scenes):
                                 "camera_samples_not_traced_per_step": (total_frame_samples - total_samples) / args.steps},
                        "frame_check": frame_check,
                        "boundary": {"timed_entry": "RaylibAMD_RenderDevice + torch.distributed gather", "ms_per_step": elapsed / args.steps * 1e3},
+                       "n1_reference": {"note": "the driver's N = 1 line is library mode (`python bench.py --gpus 1`: Raylib_Render); this line is process mode "
+                                                "(RaylibAMD_RenderDevice per rank + one gather per frame), whose own one-rank time is `boundary.render_device_ms_per_step` of the N = 1 line "
+                                                "(or this line at WORLD_SIZE = 1)"},
                        "build_id": build_id, "timed_region_s": elapsed},
-            "roofline": roofline_block(args.workload, acc, world, build_id),
+            # rank 0's own launches (the other ranks run the same kernel on their share of the cells: rank_trace_ms below)
+            "roofline": roofline_block(args.workload, acc, world, build_id, tree_walk, gpus_in_acc=1,
+                                       frame_samples_per_launch=total_samples / max(1, acc["launches"])),
             "multi_gpu": {"ranks": world, "devices": min(world, visible), "gather": "gloo via host (BENCH_SHARE_GPU)" if share else "rccl (torch.distributed gather)",
                           "rank_trace_ms": [float(x) for x in km.tolist()], "note": "rank_trace_ms: every rank's megakernel time in the last timed frame"},
         }

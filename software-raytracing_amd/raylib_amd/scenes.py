@@ -448,6 +448,44 @@ def pbr_maps(path, tess=1, ext=None, mtl=None):
     return obj, n
 
 
+# ---------------------------------------------------------------------------------
+# Hall of mirrors: the Cornell room closed by a front wall, every wall and both boxes `illum 3` (Mirror, reference
+# loader/obj_loader.cc:365-367: albedo = min(0.95, Kd)) -- a Mirror always scatters with pdf 1 (render/material.h:149-163), so from a
+# camera inside nearly every path lives until the maxPathLength cut (renderer.cc:120-123) and its vertices all carry weight
+# (0.95^200 = 3.5e-5 of a 17-unit light is far above a float's resolution): the test scene for long paths.
+
+MIRROR_HALL_MTL = """newmtl white
+Kd 0.95 0.95 0.95
+illum 3
+
+newmtl red
+Kd 0.95 0.9 0.88
+illum 3
+
+newmtl green
+Kd 0.9 0.95 0.89
+illum 3
+
+newmtl mirror
+Kd 0.93 0.93 0.95
+illum 3
+
+newmtl light
+Ns 10
+Kd 0.78 0.78 0.78
+Ks 0 0 0
+Ke 17 12 4
+illum 2
+"""
+MIRROR_HALL_CAMERA = dict(origin=(0.15, 1.1, 0.9), look_at=(-0.1, 0.9, -1.0), fov=60.0, sun=(0.0, 0.0, 0.0), sun_dir=(0.0, -1.0, -0.5))
+
+
+def mirror_hall(path, tess=1):
+    objs = cornell_objects()
+    objs.append(("frontwall", WHITE, [_quad((1, 0, 1), (-1, 0, 1), (-1, 2, 1), (1, 2, 1))]))
+    return write_obj(path, objs, MIRROR_HALL_MTL, tess=tess)
+
+
 def soup(path, n_tris=10000, seed=3, extent=4.0, size=0.35):
     """Random triangle soup (no normals, no UVs) for closest-hit / BVH-vs-brute-force tests."""
     rng = np.random.RandomState(seed)

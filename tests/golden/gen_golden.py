@@ -129,6 +129,35 @@ def main(only=None):
             print("native_stats", name, helpers.z_statistics(seeded, out[name + "_mean"], out[name + "_std"], RUNS))
         np.savez_compressed(os.path.join(HERE, "native_stats.npz"), **out)
 
+    # ---- long paths (round 5): maxPathLength 32 and 200 -- the GUI allows up to 1024 (gui-app/gui-app/MainForm.Designer.cs:140), the cut is
+    # renderer.cc:120-123.  A closed-ish Cornell box keeps every path alive to the cut (MicrofacetMaterial::Scatter always returns true, material.cc:339), the
+    # glass / mirror variant adds Dielectric and Mirror vertices, the procedural scene Metal / DiffuseLight / spheres / a moving cube.  64 x 64 x 4 spp each.
+    if want("long_paths"):
+        out = {}
+        for name in ("cornell", "cornell_glass_sun", "pbr_maps"):
+            obj, c, flat = helpers.flat_for_case(name, tmp, orc)
+            scene = ref.scene_create(flat, BUILD_SEED)
+            cam = helpers.camera_for_case(c)
+            for depth in (32, 200):
+                out["%s_len%d" % (name, depth)] = ref.render(scene, cam, ffi.make_settings(64, 64, 4, max_path=depth), seed=SEED)
+                print("long_paths", name, depth, float(np.nanmean(out["%s_len%d" % (name, depth)][..., :3])))
+        flat, c = helpers.procedural_flat()
+        scene = ref.scene_create(flat, BUILD_SEED)
+        cam = ffi.make_camera(c["origin"], c["look_at"], c["fov"], c["aspect"], c["aperture"], c["focal"], *c["shutter"])
+        for depth in (32, 200):
+            out["procedural_len%d" % depth] = ref.render(scene, cam, ffi.make_settings(96, 64, 4, max_path=depth), seed=SEED)
+            print("long_paths procedural", depth, float(np.nanmean(out["procedural_len%d" % depth][..., :3])))
+        # the hall of mirrors (scenes.mirror_hall): nearly every path reaches the cut -- also at the GUI's maximum, 1024
+        obj, _ = scenes.mirror_hall(os.path.join(tmp, "mirror_hall.obj"))
+        c = scenes.MIRROR_HALL_CAMERA
+        flat = objflat.load_obj(obj, orc, sun_illuminance=c["sun"], sun_direction=c["sun_dir"])
+        scene = ref.scene_create(flat, BUILD_SEED)
+        cam = ffi.make_camera(c["origin"], c["look_at"], c["fov"], 1.0)
+        for depth in (5, 32, 200, 1024):
+            out["mirror_hall_len%d" % depth] = ref.render(scene, cam, ffi.make_settings(64, 64, 4, max_path=depth), seed=SEED)
+            print("long_paths mirror_hall", depth, float(np.nanmean(out["mirror_hall_len%d" % depth][..., :3])))
+        np.savez_compressed(os.path.join(HERE, "long_paths.npz"), **out)
+
     if only is not None and not (want("procedural") or want("kat") or want("soup")):
         return
     # ---- procedural scene: spheres, a moving cube, Metal / DiffuseLight / Dielectric / Mirror -----------------------

@@ -306,6 +306,69 @@ def test_ragged_viewport_and_deeper_paths(name, gpu_lib, workdir, oracle):
     ses.close()
 
 
+LONG_SCHEDULES = (dict(), dict(RAYLIB_POOL="2"), dict(RAYLIB_LEAF_LIST="0"), dict(RAYLIB_POOL="2", RAYLIB_BVH4="0"))
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_glass_sun", "pbr_maps"])
+def test_long_paths_vs_reference_goldens(name, sessions, oracle, workdir, monkeypatch):
+    """maxPathLength 32 and 200 (the GUI allows up to 1024, reference gui-app/gui-app/MainForm.Designer.cs:140; the cut is
+    renderer.cc:120-123): 64 x 64 x 4 spp against the REAL reference's renders (tests/golden/long_paths.npz), on both megakernels -- the path stack in HBM and the
+    back-to-front fold are the code that grows with depth."""
+    g = golden("long_paths")
+    ses = sessions[name]
+    obj, c, flat = helpers.flat_for_case(name, workdir, oracle)
+    ties = tie_mask(oracle, flat, ffi.make_camera(c["origin"], c["look_at"], c["fov"], c["aspect"]), 64, 64)
+    for depth in (32, 200):
+        want = g["%s_len%d" % (name, depth)]
+        for env in LONG_SCHEDULES:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            img = ses.render(64, 64, 4, max_path=depth)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert np.array_equal(np.isfinite(img), np.isfinite(want)), (name, depth, env)
+            assert_same_outside_ties(img, want, ties, "%s maxPathLength %d %s" % (name, depth, env))
+
+
+def test_long_paths_hall_of_mirrors_and_procedural(gpu_lib, oracle, workdir, monkeypatch):
+    """A closed room of mirrors (scenes.mirror_hall: every wall `illum 3`, the camera inside): nearly every path lives until the maxPathLength cut and every one
+    of its vertices carries weight -- 5, 32, 200 and the GUI's maximum 1024 against the real reference's renders, every schedule; the frames of different depths
+    differ in most pixels (so a fold that stopped early, or a path stack that wrapped, cannot pass).  Then the procedural scene (spheres, a moving cube, Metal,
+    DiffuseLight, Dielectric) at 32 and 200."""
+    from raylib_amd import binding
+    g = golden("long_paths")
+    d = os.path.join(str(workdir), "mirror_hall"); os.makedirs(d, exist_ok=True)
+    obj, n = helpers.scenes.mirror_hall(os.path.join(d, "mirror_hall.obj"))
+    c = helpers.scenes.MIRROR_HALL_CAMERA
+    flat = helpers.objflat.load_obj(obj, oracle, sun_illuminance=c["sun"], sun_direction=c["sun_dir"])
+    ties = tie_mask(oracle, flat, ffi.make_camera(c["origin"], c["look_at"], c["fov"], 1.0), 64, 64)
+    ses = binding.SceneSession(gpu_lib, obj, c["origin"], c["look_at"], c["fov"], 1.0, sun=c["sun"], sun_dir=c["sun_dir"])
+    frames = {}
+    for depth in (5, 32, 200, 1024):
+        want = g["mirror_hall_len%d" % depth]
+        for env in LONG_SCHEDULES:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            img = ses.render(64, 64, 4, max_path=depth)
+            st = ses.stats().as_dict()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert_same_outside_ties(img, want, ties, "mirror hall maxPathLength %d %s" % (depth, env))
+            assert st["pathsPerWave"] == (128 if "RAYLIB_POOL" in env else 64)
+        frames[depth] = img
+        # the path really is that long: more queries per camera sample than the previous depth allows
+        assert st["rays"] > 0.95 * depth * st["cameraSamples"], (depth, st["rays"], st["cameraSamples"])
+    assert (bits(frames[32]) != bits(frames[200])).any(-1).mean() > 0.5 and (bits(frames[200]) != bits(frames[1024])).any(-1).mean() > 0.5
+    ses.close()
+    mats, sph, cub, c = helpers.procedural_case()
+    ses = binding.ProceduralSession(gpu_lib, mats, sph, cub, c["origin"], c["look_at"], c["fov"], c["aspect"], sun=c["sun"], sun_dir=c["sun_dir"],
+                                    aperture=c["aperture"], focal=c["focal"], shutter=c["shutter"])
+    for depth in (32, 200):
+        img = ses.render(96, 64, 4, max_path=depth)
+        assert np.array_equal(bits(img), bits(g["procedural_len%d" % depth])), "procedural maxPathLength %d: %.4f bit-equal" % (depth, frac_bit_equal(img, g["procedural_len%d" % depth]))
+    ses.close()
+
+
 def test_procedural_scene_through_the_abi(gpu_lib):
     """Spheres, a moving cube and every material class created through RaylibAMD_Create* + Raylib_AddSceneElement."""
     from raylib_amd import binding

@@ -330,6 +330,32 @@ def test_bench_multi_rank_frame_assembly_on_one_gpu():
     assert "reference-rendered windows bit-identical" in d["config"]["frame_check"]
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert d["multi_gpu"]["ranks"] == 2 and len(d["multi_gpu"]["rank_trace_ms"]) == 2 and min(d["multi_gpu"]["rank_trace_ms"]) > 0
+    check_multi_rank_roofline(d["roofline"], leaf_list=True)
+    # the pool schedule (the configs[2]-sized scene on the 8-wide tree) through the same two-rank path
+    cmd[cmd.index("29533")] = "29535"
+    out = subprocess.run(cmd + ["--workload", "breakfast_300k_1080p_128spp"], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["roofline"]["kernel"] == "k_trace_pool" and d["roofline"]["algorithmic"]["tree_width"] == 8
+    assert d["config"]["frame_check"].startswith("assembled frame bit-identical to a one-GPU render") and "MISMATCH" not in d["config"]["frame_check"]
+    check_multi_rank_roofline(d["roofline"], leaf_list=False)
+
+
+def check_multi_rank_roofline(r, leaf_list):
+    """What an N > 1 bench line may say about the roofline: a fraction of a peak is at most 1 or absent; bytes the leaf-list kernel was served
+    from LDS are never put over the HBM peak -- the algorithmic bytes are the tree walk's, from an untimed frame --; replayed N = 1 counters say that they are scaled."""
+    assert r["frac"] is None or 0.0 < r["frac"] <= 1.0, r["frac"]
+    a = r["algorithmic"]
+    assert a["frac_of_hbm_peak"] is None or a["frac_of_hbm_peak"] > 0.0
+    if leaf_list:
+        assert a["tree_width"] == 0 and a["served_elsewhere"] is not None
+        assert a["bytes_per_launch"] is None or a["bytes_per_launch"] < a["served_elsewhere"]["lds_served_bytes_per_launch"]
+        assert not (r["resource"].startswith("HBM (algorithmic") and a["bytes_per_launch"] is None)
+    if r["valu"] is not None:
+        assert r["valu"]["scaled_from_n1"] is True and "SCALED" in r["traffic_source"] and r["valu"]["frac_of_spec_peak"] <= 1.0
+    if r["frac"] is not None and r["achieved"] is not None:
+        assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
 
 
 def test_bench_default_run_times_the_boundary_and_checks_the_frame():
@@ -407,6 +433,16 @@ def test_bench_library_mode_runs_n_ranks_behind_raylib_render_or_refuses():
     m = d["multi_gpu"]
     assert m["ranks"] == 2 and m["devices"] == 1 and m["gather"] in ("rccl", "peer") and len(m["rank_kernel_ms"]) == 2 and min(m["rank_kernel_ms"]) > 0
     assert m["gather"] != "rccl" or m["rccl_comm_size"] == 1
+    check_multi_rank_roofline(d["roofline"], leaf_list=True)
+    assert d["roofline"]["algorithmic"]["gpus"] == 2 and "n1_reference" in d["config"]
+    # ... and the pool schedule on the 8-wide tree behind the same call
+    out = subprocess.run(cmd + ["--workload", "breakfast_300k_1080p_128spp"], env=dict(env, RAYLIB_GPU_MAP="0,0", RAYLIB_GATHER_SELF="1"), capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["roofline"]["kernel"] == "k_trace_pool" and d["roofline"]["algorithmic"]["tree_width"] == 8
+    assert d["config"]["frame_check"].endswith("reference-rendered windows bit-identical")
+    check_multi_rank_roofline(d["roofline"], leaf_list=False)
     # a mismatch between --gpus and the launcher is an error, not a silent one-GPU run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra"],
                          env=dict(env, RAYLIB_NUM_GPUS="2", RAYLIB_GPU_MAP="0,0"), capture_output=True, text=True, timeout=300)

@@ -162,6 +162,22 @@ KERNEL(cmp_x2_cndmask, float, float, STREAM8_VCC("v_cmp_lt_f32 vcc, %0, %1\n\tv_
 KERNEL(writelane, unsigned, unsigned, STREAM8("v_writelane_b32 %0, s20, 3", "v"(a)))
 KERNEL(cmpx_f32, unsigned, float, STREAM8("v_cmpx_le_f32 exec, %1, %1", "v"(a)))
 KERNEL(bpermute, unsigned, unsigned, STREAM8("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)", "v"(a)))
+// round 5: what a box plane could enter an f32 fma through without v_cvt_f32_ubyte, and gfx950's three-operand bit / min / max forms
+KERNEL(fma_mix_f32_lo, float, unsigned, STREAM8("v_fma_mix_f32 %0, %1, %0, %0 op_sel_hi:[1,0,0]", "v"(a)))                          /* src0 = low f16 half of a dword */
+KERNEL(fma_mix_f32_hi, float, unsigned, STREAM8("v_fma_mix_f32 %0, %1, %0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]", "v"(a)))           /* src0 = high f16 half */
+KERNEL(fma_mix_f32_f32, float, float, STREAM8("v_fma_mix_f32 %0, %0, %1, %2", "v"(a) COMMA "v"(b)))                                   /* all three sources f32 */
+KERNEL(bitop3_b32, unsigned, unsigned, STREAM8("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96", "v"(a) COMMA "v"(b)))
+KERNEL(maximum3_f32, float, float, STREAM8("v_maximum3_f32 %0, %0, %1, %2", "v"(a) COMMA "v"(b)))
+KERNEL(minimum3_f32, float, float, STREAM8("v_minimum3_f32 %0, %0, %1, %2", "v"(a) COMMA "v"(b)))
+KERNEL(cvt_f32_f16, unsigned, unsigned, STREAM8("v_cvt_f32_f16 %0, %1", "v"(a)))
+KERNEL(cvt_f32_f16_sdwa, unsigned, unsigned, STREAM8("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v"(a)))
+KERNEL(dot2_f32_f16, float, unsigned, STREAM8("v_dot2_f32_f16 %0, %1, %2, %0", "v"(a) COMMA "v"(b)))
+KERNEL(mul_f32_sdwa_byte, float, unsigned, STREAM8("v_mul_f32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD", "v"(a)))
+KERNEL(lshl_or_b32, unsigned, unsigned, STREAM8("v_lshl_or_b32 %0, %0, 8, %1", "v"(a)))
+KERNEL(fmac_f32_dpp, float, float, STREAM8("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf", "v"(a) COMMA "v"(b)))
+KERNEL(cvt_f32_ubyte3, unsigned, unsigned, STREAM8("v_cvt_f32_ubyte3 %0, %1", "v"(a)))
+KERNEL(ffbh_u32, unsigned, unsigned, STREAM8("v_ffbh_u32 %0, %0", "v"(a)))
+KERNEL(bcnt_u32, unsigned, unsigned, STREAM8("v_bcnt_u32_b32 %0, %0, %1", "v"(a)))
 
 struct Case { const char* name; const char* counterClass; double perCount; double ms[3]; };
 
@@ -313,6 +329,21 @@ int main(int argc, char** argv)
 	CASE(cmp_x2_cndmask, "", 3, float, float, 0.5f, 1.5f)
 	CASE(writelane, "", 1, unsigned, unsigned, 3u, 0)
 	CASE(bpermute, "", 1, unsigned, unsigned, 4u, 0)
+	CASE(fma_mix_f32_lo, "", 1, float, unsigned, 0x3c003c00u, 0)
+	CASE(fma_mix_f32_hi, "", 1, float, unsigned, 0x3c003c00u, 0)
+	CASE(fma_mix_f32_f32, "", 1, float, float, 1.0001f, 0.5f)
+	CASE(bitop3_b32, "INT32", 1, unsigned, unsigned, 3u, 5u)
+	CASE(maximum3_f32, "", 1, float, float, 0.5f, 0.25f)
+	CASE(minimum3_f32, "", 1, float, float, 0.5f, 0.25f)
+	CASE(cvt_f32_f16, "CVT", 1, unsigned, unsigned, 0x3c003c00u, 0)
+	CASE(cvt_f32_f16_sdwa, "CVT", 1, unsigned, unsigned, 0x3c003c00u, 0)
+	CASE(dot2_f32_f16, "", 1, float, unsigned, 0x3c003c00u, 0x38003800u)
+	CASE(mul_f32_sdwa_byte, "", 1, float, unsigned, 0x11223344u, 0)
+	CASE(lshl_or_b32, "INT32", 1, unsigned, unsigned, 3u, 0)
+	CASE(fmac_f32_dpp, "", 1, float, float, 1.0001f, 0.5f)
+	CASE(cvt_f32_ubyte3, "CVT", 1, unsigned, unsigned, 0x11223344u, 0)
+	CASE(ffbh_u32, "INT32", 1, unsigned, unsigned, 0, 0)
+	CASE(bcnt_u32, "INT32", 1, unsigned, unsigned, 3u, 0)
 	const double* base = cases[0].ms;
 	printf("%-16s %-10s | ms at 1 / 4 / 8 waves per SIMD | issue cycles per wave64 instruction (v_fma_f32 = 2) at 1 / 4 / 8\n", "opcode", "class");
 	std::string json = "{\n \"note\": \"issue cycles per wave64 VALU instruction at 4 waves per SIMD = 2 x (time of an independent stream of the opcode / time of the same stream of v_fma_f32), tools/valu_calib.hip on the bench box; v_fma_f32 = 2 cycles per MI355X_MICROARCH.md\",\n \"device\": \"";
