@@ -45,10 +45,15 @@ WORKLOADS = {
     "breakfast_300k_1080p_128spp": dict(scene="cornell", kw=dict(tess=91, displace_fraction=0.2), w=1920, h=1080, spp=128, max_path=5, camera="breakfast"),
     # the same scene from INSIDE (what the named scenes are: interiors): every pixel looks at geometry, no cell can be dropped (round 4)
     "breakfast_interior_300k_1080p_128spp": dict(scene="cornell", kw=dict(tess=91, displace_fraction=0.2), w=1920, h=1080, spp=128, max_path=5, camera="breakfast_interior"),
+    # ... and WITH textures and alpha cut-outs (round 5; SURVEY 8d: Breakfast Room / San Miguel use map_Kd throughout, C5 is "foliage cards with an alpha-cut-out
+    # texture"): albedo maps on every wall, a fifth of the triangles as foliage cards whose map is two thirds holes -- the cut-out test runs inside traversal for
+    # every candidate of a mapped material (reference geom/triangle.cc:54, render/material.cc:397-404, render/texture.cc:30-53); camera inside the room
+    "breakfast_textured_interior_300k_1080p_128spp": dict(scene="textured", kw=dict(tess=91, displace_fraction=0.2), w=1920, h=1080, spp=128, max_path=5, camera="breakfast_interior"),
 }
 HEADLINE = "cornell_1080p_64spp"
 EXTRA = "breakfast_300k_1080p_128spp"
 EXTRA2 = "breakfast_interior_300k_1080p_128spp"
+EXTRA3 = "breakfast_textured_interior_300k_1080p_128spp"
 
 
 def cpu_baseline(workload, cam, ref_rays_per_sample, gpu_frame_s):
@@ -61,7 +66,9 @@ def cpu_baseline(workload, cam, ref_rays_per_sample, gpu_frame_s):
     orc = ffi.load_oracle()
     tmp = tempfile.mkdtemp()
     obj, _ = getattr(scenes, workload["scene"])(os.path.join(tmp, "cpu.obj"), **workload["kw"])
-    flat = objflat.load_obj(obj, orc, sun_illuminance=cam["sun"], sun_direction=cam["sun_dir"])
+    tex = scenes.textured_textures()
+    flat = objflat.load_obj(obj, orc, sun_illuminance=cam["sun"], sun_direction=cam["sun_dir"],
+                            texture_loader=lambda p: scenes.texture_as_float(tex[os.path.basename(p)]) if os.path.basename(p) in tex else None)
     w, h = workload["w"], workload["h"]
     cores = os.cpu_count() or 1
     # bounded sample: ~10-30 s of CPU work.  Few cores: 1/8 of the samples; many cores: the whole step
@@ -101,11 +108,14 @@ def golden_windows(workload_name, frame_hw):
     """The timed frame against windows of the same frame rendered by the REAL reference build (tests/golden/gen_golden.py ->
     bench_windows.npz: data; only windows in which no sample met two surfaces at exactly the same t).  Bit for bit."""
     import numpy as np
-    path = os.path.join(ROOT, "tests", "golden", "bench_windows.npz")
-    if not os.path.exists(path):
-        return None
-    g = np.load(path)
-    if workload_name + "_pos" not in g.files:
+    g = None
+    for name in ("bench_windows.npz", "bench_windows_textured.npz"):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        if os.path.exists(path):
+            f = np.load(path)
+            if workload_name + "_pos" in f.files:
+                g = f
+    if g is None:
         return None
     pos, px = g[workload_name + "_pos"], g[workload_name + "_px"]
     bad = 0
@@ -143,7 +153,7 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None, gpus_in_
     sec = avg_launch_ms * 1e-3
     samples_per_launch = acc["samples"] / launches
     # ---- algorithmic bytes, SURVEY 8(d): a property of the WORKLOAD -- the records a tree walk of this scene fetches: 64 B per 4-wide
-    # grid-node step (a float-box step = 2 records) or 80 B per 8-wide one (the scenes deep enough to get that tree, RaylibAMDStats.treeWidth /
+    # grid-node step (a float-box step = 2 records) or 128 B per 8-wide one (the scenes deep enough to get that tree, RaylibAMDStats.treeWidth /
     # nodeBytes say which), 64 B per triangle test, 64 B per shading record, 16 B per texel and per pixel.
     # Where the kernel that ran walks something else (the Cornell class: the leaf list, every box of it per ray, from LDS), the tree-walk
     # counts come from one untimed frame with RAYLIB_LEAF_LIST=0 and the kernel's own LDS-served bytes are reported next to them.
@@ -164,7 +174,7 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None, gpus_in_
     alg_gbs = alg_bytes / sec / 1e9 if (sec > 0 and alg_bytes is not None) else None
     algorithmic = {"bytes_per_launch": alg_bytes, "bytes_per_camera_sample": None if alg_bytes is None else alg_bytes / max(1.0, samples_per_launch), "gbs": alg_gbs,
                    "frac_of_hbm_peak": None if alg_gbs is None else alg_gbs / hbm_peak, "hbm_peak_gbs": hbm_peak, "gpus": gpus_in_acc,
-                   "definition": "node bytes x node records of the tree walk (64 B on the 4-wide tree, 80 B on the 8-wide one) + 64 B x (triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran"
+                   "definition": "node bytes x node records of the tree walk (64 B on the 4-wide tree, 128 B on the 8-wide one) + 64 B x (triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran"
                                  + ("; summed over the %d ranks of this process, against %d GPUs' peak" % (gpus_in_acc, gpus_in_acc) if gpus_in_acc > 1 else ""),
                    "tree_width": acc.get("tree_width"), "node_bytes": acc.get("node_bytes"),
                    "served_elsewhere": served}
@@ -247,6 +257,7 @@ def accumulate(acc, stats, binding):
     acc["kernel_ms"] += stats.kernelMs
     acc["bytes"] += binding.algorithmic_bytes(stats)
     acc["samples"] += stats.cameraSamples
+    acc["texels"] = acc.get("texels", 0) + stats.texFetches; acc["nodes"] = acc.get("nodes", 0) + stats.nodesVisited; acc["tris"] = acc.get("tris", 0) + stats.trisTested
     acc["culled_rays"] += stats.culledRays; acc["culled_samples"] += stats.culledSamples; acc["culled_cells"] = stats.culledCells; acc["listed_cells"] = stats.listedCells
     acc["paths_per_wave"] = stats.pathsPerWave
     acc["job_heads"] = stats.jobHeads
@@ -264,6 +275,8 @@ def work_block(acc, steps):
     return {"rays_executed_per_step": acc["rays"] / k, "camera_samples_executed_per_step": acc["samples"] / k,
             "rays_accounted_not_traced_per_step": acc["culled_rays"] / k, "camera_samples_not_traced_per_step": acc["culled_samples"] / k,
             "cells_culled": acc["culled_cells"], "cells_listed": acc["listed_cells"],
+            "node_records_per_ray": acc.get("nodes", 0) / max(1, acc["rays"]), "triangle_records_per_ray": acc.get("tris", 0) / max(1, acc["rays"]),
+            "texel_fetches_per_ray": acc.get("texels", 0) / max(1, acc["rays"]),
             "definition": "a ray = one closest-hit or occlusion query EXECUTED by a kernel (reference renderer.cc:129,194); `value` counts only those. "
                           "Samples of cells outside the scene's silhouette are neither generated nor traced: k_resolve writes the miss shader's constant for them"}
 
@@ -446,7 +459,7 @@ def main():
         # further objects in the same invocation: the configs[2]-sized scene, whose megakernel (the pool schedule) waits on memory -- seen from outside
         # (SURVEY 8d's stand-in camera: 89 % of that frame is empty sky and is not traced) and from INSIDE (every pixel is geometry, nothing is dropped)
         k = max(3, min(20, args.steps // 5))
-        for key, name in (("extra", EXTRA), ("extra_interior", EXTRA2)):
+        for key, name in (("extra", EXTRA), ("extra_interior", EXTRA2), ("extra_textured", EXTRA3)):
             e = library_run(lib, binding, scenes, name, k, 1, 1, rank_tag="x", want_device_entry=False)
             ea = e["acc"]
             out[key] = {"workload": name, "value": ea["rays"] / e["elapsed"] / 1e6, "unit": "Mrays/s", "steps": k, "warmup": 1,

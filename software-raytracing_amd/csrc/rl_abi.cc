@@ -545,6 +545,12 @@ int32_t RaylibAMD_SceneBVH8Info(SceneHandle sh, uint32_t* nodes8, uint32_t* leve
 	if (steps8) *steps8 = s->bvh.sahNodes8;
 	return ValidateBVH8(s->bvh, s->triangles) ? 1 : -1;
 }
+int32_t RaylibAMD_SceneWalk8Host(SceneHandle sh, const float* rays, int32_t count, float tMin, const float* tMax, float* outT, uint32_t* outSteps)
+{
+	Scene* s = (Scene*)sh;
+	if (!s || !s->finalized || s->bvh.nodes8.empty() || !rays || !tMax || !outT || count < 0) return 0;
+	return Walk8Host(s->bvh, s->triangles, rays, count, tMin, tMax, outT, outSteps) ? 1 : -1;
+}
 int32_t RaylibAMD_SceneLeafListInfo(SceneHandle sh, uint32_t* maxPerLeaf)
 {
 	Scene* s = (Scene*)sh;

@@ -40,6 +40,9 @@ struct TmpNode {
 	Box box;
 	int32_t left = -1, right = -1;   // TmpNode indices; -1 => leaf
 	uint32_t first = 0, count = 0;
+	// soft: a leaf of the binary builder (<= kMaxLeaf triangles, first / count) that carries a split of its triangles below it for the 8-wide plan to open where a
+	// node has slots to spare (SplitLeaves); dead: below a soft node the plan left closed (not part of any tree)
+	uint8_t soft = 0, dead = 0;
 };
 
 constexpr int kBins = 16;
@@ -317,13 +320,15 @@ template <int W> struct WidePlan {
 	bool sameAsFewer(int i) const { return ((bits >> (21 + i)) & 1u) != 0u; }
 };
 template <int W>
-static void PlanWide(const std::vector<TmpNode>& T, int32_t root, std::vector<WidePlan<W>>& plan)
+static void PlanWide(const std::vector<TmpNode>& T, int32_t root, std::vector<WidePlan<W>>& plan, float triCost)
 {
 	plan.assign(T.size(), WidePlan<W>());
 	const double rootArea = std::max((double)T[root].box.halfArea(), 1e-30);
 	for (size_t t = T.size(); t-- > 0;) {   // children follow their parent in T: a reverse sweep sees them first
 		WidePlan<W>& P = plan[t];
-		if (T[t].left < 0) { for (int i = 0; i < W - 1; ++i) P.c[i] = 0.0f; P.bits = 0; continue; }
+		// a leaf child costs its expected triangle tests: (its box's area / the root's) x its triangles x triCost node steps
+		const float leafCost = triCost * (float)((double)T[t].box.halfArea() / rootArea) * (float)T[t].count;
+		if (T[t].left < 0) { for (int i = 0; i < W - 1; ++i) P.c[i] = leafCost; P.bits = 0; continue; }
 		const WidePlan<W>& L = plan[T[t].left]; const WidePlan<W>& R = plan[T[t].right];
 		float d[W + 1]; uint32_t bits = 0;   // d[j]: n's two children share j slots
 		for (int j = 2; j <= W; ++j) {
@@ -331,7 +336,8 @@ static void PlanWide(const std::vector<TmpNode>& T, int32_t root, std::vector<Wi
 			for (int k = 1; k < j; ++k) { if (k > W - 1 || j - k > W - 1) continue; const float v = L.c[k - 1] + R.c[j - k - 1]; if (v < best) { best = v; bestK = k; } }
 			d[j] = best; bits |= (uint32_t)bestK << (3 * (j - 2));
 		}
-		P.c[0] = (float)((double)T[t].box.halfArea() / rootArea) + d[W];
+		// one slot: an 8-wide node of its own -- or, for a split leaf (soft), the leaf as the binary builder made it
+		P.c[0] = T[t].soft ? leafCost : (float)((double)T[t].box.halfArea() / rootArea) + d[W];
 		for (int i = 2; i <= W - 1; ++i) {
 			if (d[i] < P.c[i - 2]) P.c[i - 1] = d[i];
 			else { P.c[i - 1] = P.c[i - 2]; bits |= 1u << (21 + i); }
@@ -342,7 +348,7 @@ static void PlanWide(const std::vector<TmpNode>& T, int32_t root, std::vector<Wi
 // the planned children of the W-wide node rooted at t: its two sub-trees share W slots as the plan says; a sub-tree given i slots is either opened (its own two
 // children share them) or, with one slot, a child of this node.  Returns their number.
 template <int W>
-static int PlannedChildren(const std::vector<TmpNode>& T, const std::vector<WidePlan<W>>& plan, int32_t t, int32_t* kids)
+static int PlannedChildren(std::vector<TmpNode>& T, const std::vector<WidePlan<W>>& plan, int32_t t, int32_t* kids)
 {
 	struct Share { int32_t t; int slots; } todo[2 * W]; int top = 0, nk = 0;
 	{ const int k = plan[t].kAt(W); todo[top++] = { T[t].right, W - k }; todo[top++] = { T[t].left, k }; }
@@ -353,15 +359,65 @@ static int PlannedChildren(const std::vector<TmpNode>& T, const std::vector<Wide
 		while (i > 1 && plan[sh.t].sameAsFewer(i)) --i;
 		if (i == 1) { kids[nk++] = sh.t; continue; }
 		const int k = plan[sh.t].kAt(i);
+		T[sh.t].soft = 0;   // (a split leaf the plan opens is an inner node from here on: the binary and the 4-wide tree are emitted from the same T)
 		todo[top++] = { T[sh.t].right, i - k }; todo[top++] = { T[sh.t].left, k };
 	}
 	return nk;
 }
 
-static void CollapseWide8(const std::vector<TmpNode>& T, int32_t root, Wide8& W)
+// Leaves of the binary tree hold up to kMaxLeaf triangles: below that the surface-area heuristic finds a node not worth its step.  In an 8-wide node a step tests
+// eight boxes whether or not eight children exist (5.4 did on the 298 k-triangle room), so a spare slot is a free box: every triangle leaf gets a binary split
+// of its triangles (sorted along the longest axis of their centroids; each range cut where the two halves' area x count is least) down to single triangles,
+// flagged `soft`; the plan (PlanWide) opens such a node where its parent has slots left and the smaller boxes save expected triangle tests, and leaves it the
+// leaf it was elsewhere (CollapseWide8 closes what the plan did not open).  No node is added to the 8-wide tree by this.
+static void SplitLeaves(std::vector<TmpNode>& T, Shared& B)
+{
+	const size_t n0 = T.size();
+	for (size_t t = 0; t < n0; ++t) {
+		if (T[t].left >= 0 || T[t].count < 2 || B.kind[B.order[T[t].first]] != PRIM_TRIANGLE) continue;
+		const uint32_t b = T[t].first, e = b + T[t].count;
+		Box cb; cb.reset();
+		for (uint32_t i = b; i < e; ++i) cb.grow(B.centroid[B.order[i]]);
+		int axis = 0;
+		const float ex = cb.mx.x - cb.mn.x, ey = cb.mx.y - cb.mn.y, ez = cb.mx.z - cb.mn.z;
+		if (ey > ex && ey >= ez) axis = 1; else if (ez > ex && ez > ey) axis = 2;
+		std::sort(B.order.begin() + b, B.order.begin() + e, [&](uint32_t x, uint32_t y) {
+			const float cx = axisOf(B.centroid[x], axis), cy = axisOf(B.centroid[y], axis);
+			return cx < cy || (cx == cy && x < y);
+		});
+		// ranges to split, depth first; a range's node exists before its children are appended (children follow their parent in T)
+		struct Range { int32_t node; uint32_t b, e; } todo[2 * kMaxLeaf]; int top = 0;
+		todo[top++] = { (int32_t)t, b, e };
+		while (top > 0) {
+			const Range r = todo[--top];
+			if (r.e - r.b < 2) continue;
+			uint32_t bestCut = r.b + 1; float bestCost = FLT_MAX;
+			for (uint32_t cut = r.b + 1; cut < r.e; ++cut) {
+				Box l, rr; l.reset(); rr.reset();
+				for (uint32_t i = r.b; i < cut; ++i) l.grow(B.triBox[B.order[i]]);
+				for (uint32_t i = cut; i < r.e; ++i) rr.grow(B.triBox[B.order[i]]);
+				const float cost = l.halfArea() * (float)(cut - r.b) + rr.halfArea() * (float)(r.e - cut);
+				if (cost < bestCost) { bestCost = cost; bestCut = cut; }
+			}
+			TmpNode kids[2];
+			const uint32_t lim[3] = { r.b, bestCut, r.e };
+			for (int k = 0; k < 2; ++k) {
+				kids[k].box.reset();
+				for (uint32_t i = lim[k]; i < lim[k + 1]; ++i) kids[k].box.grow(B.triBox[B.order[i]]);
+				kids[k].first = lim[k]; kids[k].count = lim[k + 1] - lim[k];
+			}
+			const int32_t li = (int32_t)T.size(); T.push_back(kids[0]);
+			const int32_t ri = (int32_t)T.size(); T.push_back(kids[1]);
+			T[r.node].left = li; T[r.node].right = ri; T[r.node].soft = 1;
+			todo[top++] = { ri, bestCut, r.e }; todo[top++] = { li, r.b, bestCut };
+		}
+	}
+}
+
+static void CollapseWide8(std::vector<TmpNode>& T, int32_t root, Wide8& W, bool greedy, float triCost)
 {
 	std::vector<WidePlan<8>> plan;
-	{ const char* e = getenv("RAYLIB_WIDE_GREEDY"); if (!(e && atoi(e) != 0)) PlanWide<8>(T, root, plan); }
+	if (!greedy) PlanWide<8>(T, root, plan, triCost);
 	struct Item { int32_t tmp; uint32_t level; };
 	std::vector<Item> queue;
 	queue.push_back({ root, 1u });
@@ -402,17 +458,88 @@ static void CollapseWide8(const std::vector<TmpNode>& T, int32_t root, Wide8& W)
 		for (int sl = 0; sl < 8; ++sl) {
 			const int32_t k = nd.kid[sl];
 			if (k < 0) continue;
-			if (T[k].left >= 0) queue.push_back({ k, it.level + 1u }); else W.leafOrder.push_back(k);
+			if (T[k].left >= 0 && !T[k].soft) queue.push_back({ k, it.level + 1u }); else W.leafOrder.push_back(k);
 		}
 		W.nodes.push_back(nd);
 	}
+	// split leaves the plan left closed are leaves again; what hangs below them belongs to no tree
+	for (size_t t = 0; t < T.size(); ++t) {
+		if (!T[t].soft || T[t].dead) continue;
+		int32_t st[4 * kMaxLeaf]; int top = 0;
+		st[top++] = T[t].left; st[top++] = T[t].right;
+		while (top > 0) { const int32_t k = st[--top]; T[k].dead = 1; if (T[k].left >= 0) { st[top++] = T[k].left; st[top++] = T[k].right; } }
+		T[t].left = T[t].right = -1; T[t].soft = 0;
+	}
 }
 
-// W + the leaf references (first triangle slot, count) -> out.nodes8.  Grid boxes as in QuantizeWide: every decision in double.
-static void EmitWide8(const std::vector<TmpNode>& T, const Wide8& W, const std::vector<int32_t>& leafCode, BVH& out)
+// the expected node steps of a random ray through the 4-wide collapse of T (sum of the wide nodes' areas over the root's), without building it: what decides
+// whether a scene's rays walk the 8-wide tree by default (rl_runtime.inl RL_BVH8_MIN_STEPS) -- and only then are its leaves split for that tree
+static double ExpectedSteps4(const std::vector<TmpNode>& T, int32_t root)
+{
+	const double rootArea = std::max((double)T[root].box.halfArea(), 1e-30);
+	double sum = 0.0;
+	std::vector<int32_t> work; work.push_back(root);
+	while (!work.empty()) {
+		const int32_t t = work.back(); work.pop_back();
+		sum += (double)T[t].box.halfArea() / rootArea;
+		int32_t kids[4]; int nk = 0;
+		kids[nk++] = T[t].left; kids[nk++] = T[t].right;
+		while (nk < 4) {
+			int best = -1; float bestArea = -1.0f;
+			for (int k = 0; k < nk; ++k) if (T[kids[k]].left >= 0) { const float a = T[kids[k]].box.halfArea(); if (a > bestArea) { bestArea = a; best = k; } }
+			if (best < 0) break;
+			const int32_t open = kids[best];
+			kids[best] = T[open].left; kids[nk++] = T[open].right;
+		}
+		for (int k = 0; k < nk; ++k) if (T[kids[k]].left >= 0) work.push_back(kids[k]);
+	}
+	return sum;
+}
+
+// IEEE halves as bit patterns (the device reads them through v_fma_mix_f32): value of a pattern, and the nearest pattern at or below / at or above a
+// non-negative double that a half can hold (<= 65504).  Non-negative halves are ordered like their patterns.
+static double HalfValue(uint16_t h)
+{
+	const int e = (h >> 10) & 31, m = h & 1023;
+	const double v = e == 0 ? ldexp((double)m, -24) : ldexp((double)(1024 + m), e - 25);
+	return (h & 0x8000u) ? -v : v;
+}
+static uint16_t HalfAtOrBelow(double x)
+{
+	if (!(x > 0.0)) return 0;
+	if (x >= 65504.0) return 0x7bffu;
+	int ex; (void)frexp(x, &ex);                      // x = f * 2^ex, f in [0.5, 1)
+	int e = ex - 1 + 15;                              // biased exponent of the half that holds x as 1.m * 2^(ex - 1)
+	uint32_t h;
+	if (e <= 0) h = (uint32_t)floor(ldexp(x, 24));   // subnormal halves: multiples of 2^-24
+	else h = ((uint32_t)e << 10) | ((uint32_t)floor(ldexp(x, 10 - (ex - 1))) - 1024u);
+	while (h > 0 && HalfValue((uint16_t)h) > x) --h;
+	while (h < 0x7bffu && HalfValue((uint16_t)(h + 1)) <= x) ++h;
+	return (uint16_t)h;
+}
+static uint16_t HalfAtOrAbove(double x)
+{
+	if (!(x > 0.0)) return 0;
+	uint16_t h = HalfAtOrBelow(x);
+	if (HalfValue(h) < x && h < 0x7bffu) ++h;
+	return h;
+}
+
+// W + the leaf references (first triangle slot, count) -> out.nodes8 (DNode8, rl_device.h).  Every decision in double: corner + half * step is exact there, so "the
+// half-float box contains the float box" holds exactly.
+static void EmitWide8(const std::vector<TmpNode>& T, const Wide8& W, const std::vector<int32_t>& leafCode, BVH& out, int32_t root)
 {
 	out.nodes8.assign(W.nodes.size(), DNode8());
 	out.depth8 = W.depth; out.sahNodes8 = (float)W.sah;
+	// the planes' unit: the smallest power of two of which the root's longest side is at most 2^15 (a half holds offsets up to 65504)
+	const Box& rb = T[root].box;
+	out.root8Min[0] = rb.mn.x; out.root8Min[1] = rb.mn.y; out.root8Min[2] = rb.mn.z; out.root8Max[0] = rb.mx.x; out.root8Max[1] = rb.mx.y; out.root8Max[2] = rb.mx.z;
+	double longest = 0.0;
+	for (int a = 0; a < 3; ++a) longest = std::max(longest, (double)axisOf(rb.mx, a) - (double)axisOf(rb.mn, a));
+	int se = -100;
+	if (longest > 0.0) { int x; (void)frexp(longest / 32768.0, &x); se = std::max(-100, std::min(100, x)); }   // 2^x >= longest / 2^15
+	const double step = ldexp(1.0, se);
+	out.step8 = (float)step;
 	auto run = [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) {
 		const Wide8Node& w = W.nodes[i];
 		DNode8 n; memset(&n, 0, sizeof(n));
@@ -425,31 +552,24 @@ static void EmitWide8(const std::vector<TmpNode>& T, const Wide8& W, const std::
 			leafMask |= ((1u << count) - 1u) << (4 * c);
 			if (!haveTri) { triBase = first; haveTri = true; }
 		}
-		uint32_t exps[3] = { 0, 0, 0 };
 		for (int a = 0; a < 3; ++a) {
 			float lo = FLT_MAX, hi = -FLT_MAX;
 			for (int c = 0; c < 8; ++c) if (w.kid[c] >= 0) { lo = std::min(lo, axisOf(T[w.kid[c]].box.mn, a)); hi = std::max(hi, axisOf(T[w.kid[c]].box.mx, a)); }
 			if (!(lo <= hi)) { lo = hi = 0.0f; }
 			n.origin[a] = lo;
-			const double extent = (double)hi - (double)lo;
-			int e = 1;
-			if (extent > 0.0) { int x; (void)frexp(extent / 255.0, &x); e = std::max(1, std::min(254, x + 127)); }
-			double step = ldexp(1.0, e - 127);
-			while (255.0 * step < extent && e < 254) { ++e; step *= 2.0; }
-			exps[a] = (uint32_t)e;
 			for (int c = 0; c < 8; ++c) {
-				if (w.kid[c] < 0) { n.qlo[a][c >> 2] |= 255u << (8 * (c & 3)); continue; }   // inverted: lower 255, upper 0
+				if (w.kid[c] < 0) { n.lo[a][c] = RL_NODE8_EMPTY_LO; n.hi[a][c] = RL_NODE8_EMPTY_HI; continue; }   // inverted
 				const double blo = axisOf(T[w.kid[c]].box.mn, a), bhi = axisOf(T[w.kid[c]].box.mx, a);
-				double l = floor((blo - (double)lo) / step), h = ceil((bhi - (double)lo) / step);
-				l = std::max(0.0, std::min(255.0, l)); h = std::max(0.0, std::min(255.0, h));
-				while (l > 0.0 && (double)lo + l * step > blo) l -= 1.0;
-				while (h < 255.0 && (double)lo + h * step < bhi) h += 1.0;
-				n.qlo[a][c >> 2] |= (uint32_t)l << (8 * (c & 3));
-				n.qhi[a][c >> 2] |= (uint32_t)h << (8 * (c & 3));
+				uint16_t l = HalfAtOrBelow((blo - (double)lo) / step), h = HalfAtOrAbove((bhi - (double)lo) / step);
+				while (l > 0 && (double)lo + HalfValue(l) * step > blo) --l;
+				while (h < 0x7bffu && (double)lo + HalfValue(h) * step < bhi) ++h;
+				n.lo[a][c] = l; n.hi[a][c] = h;
 			}
 		}
-		n.meta = exps[0] | (exps[1] << 8) | (exps[2] << 16) | (imask << 24);
-		n.childBase = w.firstChild; n.triBase = triBase; n.leafMask = leafMask; n.alphaMask = 0;
+		uint16_t ext[3] = { 0, 0, 0 };   // the node's extent per axis in plane units: the largest upper plane (non-negative halves are ordered like their patterns)
+		for (int a = 0; a < 3; ++a) for (int c = 0; c < 8; ++c) if (w.kid[c] >= 0) ext[a] = std::max(ext[a], n.hi[a][c]);
+		n.meta = imask | ((uint32_t)ext[0] << 16);   // (the alpha flags, bits 8 - 15, are set when the scene's materials are known: rl_scene.cc)
+		n.childBase = w.firstChild; n.triBase = triBase; n.leafMask = leafMask; n.extentYZ = (uint32_t)ext[1] | ((uint32_t)ext[2] << 16);
 		out.nodes8[i] = n;
 	} };
 	const size_t n = W.nodes.size();
@@ -462,7 +582,7 @@ static void EmitWide8(const std::vector<TmpNode>& T, const Wide8& W, const std::
 	for (std::thread& th : pool) th.join();
 }
 
-void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
+void BuildBVH(const std::vector<PrimRef>& prims, BVH& out, const BVHBuildOptions& opt)
 {
 	out.nodes.clear(); out.nodes4.clear(); out.nodes4q.clear(); out.nodes8.clear(); out.depth8 = 0; out.leafList.clear(); out.stackNeed4 = 0; out.triOrder.clear(); out.depth = 0; out.sahCost = 0.0f;
 	const uint32_t n = (uint32_t)prims.size();
@@ -540,7 +660,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 
 	// Leaf references.  Triangle leaves index the triangle arrays in leaf order (out.triOrder lists the
 	// original triangle index of every slot); an analytic primitive's leaf carries its index in its own array.
-	const std::vector<TmpNode>& T = merged;
+	std::vector<TmpNode>& T = merged;
 	// Triangle-only scenes of at least 8 triangles get the wide trees; the 8-wide one decides the order of the triangle slots (the leaf children of one of its
 	// nodes hold consecutive slots), every other format refers to the same slots through its leaf references.
 	bool trianglesOnly = true;
@@ -549,7 +669,11 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 	// (not for the scenes small enough for the leaf list: its leaves are sub-trees of this tree, whose triangles must stay one range of slots -- the depth-first order)
 	const bool wide8 = wideTrees && n > RL_LEAFLIST_MAXTRIS;
 	Wide8 W8;
-	if (wide8) CollapseWide8(T, root, W8);
+	if (wide8) {
+		// leaves split for the 8-wide plan (SplitLeaves) where that tree is the one the scene's rays will walk
+		if (!opt.wideGreedy && opt.splitLeaves8 && ExpectedSteps4(T, root) >= opt.minSteps8) SplitLeaves(T, B);
+		CollapseWide8(T, root, W8, opt.wideGreedy, opt.triCost8);
+	}
 	std::vector<int32_t> leafCode(T.size(), 0);
 	auto codeLeaf = [&](size_t t) {
 		const uint32_t k = B.kind[B.order[T[t].first]];
@@ -577,17 +701,20 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 	std::vector<int32_t> emitIndex(T.size(), -1);
 	int32_t next = 0;
 	{
-		std::vector<int32_t> st; st.push_back(root);
+		// (the depth is taken here, from the tree that is emitted: split leaves the 8-wide plan opened are inner nodes of it)
+		std::vector<std::pair<int32_t, uint32_t>> st; st.push_back({ root, 0u });
+		maxDepth = 0;
 		while (!st.empty()) {
-			int32_t t = st.back(); st.pop_back();
-			if (T[t].left < 0) continue;
+			const int32_t t = st.back().first; const uint32_t d = st.back().second; st.pop_back();
+			if (T[t].left < 0) { maxDepth = std::max(maxDepth, d); continue; }
 			emitIndex[t] = next++;
-			st.push_back(T[t].right); st.push_back(T[t].left);
+			st.push_back({ T[t].right, d + 1u }); st.push_back({ T[t].left, d + 1u });
 		}
 	}
 	out.nodes.resize((size_t)next);
 	double sah = 0.0; const float rootArea = std::max(T[root].box.halfArea(), 1e-30f);
 	for (size_t t = 0; t < T.size(); ++t) {
+		if (T[t].dead) continue;
 		if (T[t].left < 0) { sah += kCostTri * T[t].count * T[t].box.halfArea() / rootArea; continue; }
 		sah += kCostTraverse * T[t].box.halfArea() / rootArea;
 		DNode nd; memset(&nd, 0, sizeof(nd));
@@ -606,7 +733,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out)
 	// Starting from a node's two children, the inner child with the largest surface area is replaced by its own two
 	// children until there are four (or only leaves).  Only for scenes the pool schedule can run (triangles only, not tiny).
 	if (wideTrees) {
-		if (wide8) EmitWide8(T, W8, leafCode, out);
+		if (wide8) EmitWide8(T, W8, leafCode, out, root);
 		struct Item { int32_t tmp; int32_t slot; uint32_t need; };   // a BVH2 inner node that becomes wide node `slot`
 		std::vector<Item> work;
 		out.nodes4.clear();
@@ -833,11 +960,12 @@ bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
 	struct Frame { uint32_t node; int child; double lo[3], hi[3]; double clo[3], chi[3]; };   // lo / hi: bounds of what has been seen below this node so far; clo / chi: ... below the child being walked
 	// iterative post-order: for every node, the bounds of the triangles below each child are checked against that child's grid box
 	std::vector<Frame> st;
+	const double step = (double)bvh.step8;
+	{ int x; if (!(step > 0.0) || frexp(step, &x) != 0.5) return false; }   // a power of two
 	auto gridBox = [&](const DNode8& n, int c, double* lo, double* hi) {
 		for (int a = 0; a < 3; ++a) {
-			const double step = ldexp(1.0, (int)((n.meta >> (8 * a)) & 255u) - 127);
-			lo[a] = (double)n.origin[a] + (double)((n.qlo[a][c >> 2] >> (8 * (c & 3))) & 255u) * step;
-			hi[a] = (double)n.origin[a] + (double)((n.qhi[a][c >> 2] >> (8 * (c & 3))) & 255u) * step;
+			lo[a] = (double)n.origin[a] + HalfValue(n.lo[a][c]) * step;
+			hi[a] = (double)n.origin[a] + HalfValue(n.hi[a][c]) * step;
 		}
 	};
 	Frame f0; f0.node = 0; f0.child = -1; for (int a = 0; a < 3; ++a) { f0.lo[a] = 1e300; f0.hi[a] = -1e300; }
@@ -848,7 +976,7 @@ bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
 		depth = std::max<uint32_t>(depth, (uint32_t)st.size());
 		if (F.node >= bvh.nodes8.size()) return false;
 		const DNode8& n = bvh.nodes8[F.node];
-		const uint32_t imask = n.meta >> 24;
+		const uint32_t imask = n.meta & 255u;
 		if (++F.child >= 8) {
 			// done: hand this node's bounds to the parent's current child
 			const Frame done = F; st.pop_back();
@@ -873,7 +1001,7 @@ bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
 			continue;
 		}
 		if (!nib) {   // unused: the inverted box
-			for (int a = 0; a < 3; ++a) if (((n.qlo[a][c >> 2] >> (8 * (c & 3))) & 255u) != 255u || ((n.qhi[a][c >> 2] >> (8 * (c & 3))) & 255u) != 0u) return false;
+			for (int a = 0; a < 3; ++a) if (n.lo[a][c] != RL_NODE8_EMPTY_LO || n.hi[a][c] != RL_NODE8_EMPTY_HI) return false;
 			continue;
 		}
 		if (nib != 1u && nib != 3u && nib != 7u && nib != 15u) return false;
@@ -896,7 +1024,108 @@ bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
 		}
 	}
 	for (uint8_t v : seen) if (!v) return false;
+	// the extents a far plane's allowance is taken from: the largest upper plane of the node's children per axis
+	for (const DNode8& n : bvh.nodes8) for (int a = 0; a < 3; ++a) {
+		uint16_t e = 0;
+		for (int c = 0; c < 8; ++c) if (n.hi[a][c] != RL_NODE8_EMPTY_HI) e = std::max(e, n.hi[a][c]);
+		if (e != (uint16_t)(a == 0 ? n.meta >> 16 : (a == 1 ? n.extentYZ & 0xffffu : n.extentYZ >> 16))) return false;
+	}
+	// every corner and every plane of the tree within the root's box grown by a thousandth
+	for (const DNode8& n : bvh.nodes8) for (int a = 0; a < 3; ++a) {
+		const double span = (double)bvh.root8Max[a] - (double)bvh.root8Min[a], slack = 1e-3 * span + 1e-30;
+		if ((double)n.origin[a] < (double)bvh.root8Min[a] - slack) return false;
+		for (int c = 0; c < 8; ++c) if (n.hi[a][c] != RL_NODE8_EMPTY_HI && (double)n.origin[a] + HalfValue(n.hi[a][c]) * step > (double)bvh.root8Max[a] + slack) return false;
+	}
 	return depth <= bvh.depth8;
+}
+
+// The 8-wide walk of rl_render.hip (NodeStep8 / LeafStep8) on the host, operation by operation in float -- the ray's widened factors, one fma per plane, the
+// negated entry distance, the sign of fma(exit, widen, -entry), groups of hit children in visiting order, the stack of groups -- with the exit distance fixed at
+// tMax[i] and every triangle of every leaf child reached tested by a tolerant double-precision test: outT[i] = the least distance among them (FLT_MAX: none).  What
+// the box arithmetic must never do is skip the leaf that holds the closest hit; tests compare outT with the oracle's closest hit on the same rays without a GPU
+// (tests/test_host_logic.py).  outSteps (optional): node steps taken.
+bool Walk8Host(const BVH& bvh, const std::vector<HostTriangle>& tris, const float* rays, int n, float tMin, const float* tMax, float* outT, uint32_t* outSteps)
+{
+	if (bvh.nodes8.empty()) return false;
+	const float widen = 1.00001f, c21 = 4.76837158e-7f;
+	auto clampInv = [](float x) { return std::isinf(x) ? copysignf(1e30f, x) : x; };
+	for (int r = 0; r < n; ++r) {
+		const float* ray = rays + 6 * (size_t)r;
+		const float o[3] = { ray[0], ray[1], ray[2] }, d[3] = { ray[3], ray[4], ray[5] };
+		float inv[3], a8n[3], a8f[3], ac8[3]; uint32_t nearHi[3]; uint32_t oct = 0;
+		for (int a = 0; a < 3; ++a) {
+			inv[a] = clampInv(1.0f / d[a]);
+			const float A = bvh.step8 * inv[a], Ac = fabsf(A) * c21;
+			a8n[a] = A - Ac; a8f[a] = A + Ac; ac8[a] = Ac;
+			nearHi[a] = inv[a] < 0.0f ? 1u : 0u;
+			if (!(inv[a] < 0.0f)) oct |= 1u << a;
+		}
+		const float ntMin = -tMin, tmx = std::min(tMax[r], FLT_MAX);
+		std::vector<std::pair<uint32_t, uint32_t>> stack;
+		uint32_t gx = 0, gy = (1u << (24 + oct)) | 1u, steps = 0;
+		double best = (double)FLT_MAX;
+		for (;;) {
+			if ((gy >> 24) == 0u) { if (stack.empty()) break; gx = stack.back().first; gy = stack.back().second; stack.pop_back(); continue; }
+			const uint32_t pos = 31u - (uint32_t)__builtin_clz(gy);
+			gy &= ~(1u << pos);
+			const uint32_t slot = (pos - 24u) ^ oct;
+			const uint32_t node = gx + (uint32_t)__builtin_popcount(gy & 0xffu & ((1u << slot) - 1u));
+			if ((gy >> 24) != 0u) stack.push_back({ gx, gy });
+			if (node >= bvh.nodes8.size() || stack.size() > 64) return false;
+			const DNode8& nd = bvh.nodes8[node];
+			++steps;
+			float nB[3], Bf[3];
+			for (int a = 0; a < 3; ++a) {
+				const float B = (nd.origin[a] - o[a]) * inv[a];
+				const float ext = (float)HalfValue((uint16_t)(a == 0 ? nd.meta >> 16 : (a == 1 ? nd.extentYZ & 0xffffu : nd.extentYZ >> 16)));
+				nB[a] = fmaf(fabsf(B), c21, -B); Bf[a] = fmaf(ext, ac8[a], fmaf(fabsf(B), c21, B));
+			}
+			uint32_t hit = 0;
+			const uint32_t imask = nd.meta & 255u;
+			for (int ch = 0; ch < 8; ++ch) {
+				float ntn = ntMin, tf = tmx;
+				for (int a = 0; a < 3; ++a) {
+					const float hn = (float)HalfValue(nearHi[a] ? nd.hi[a][ch] : nd.lo[a][ch]), hf = (float)HalfValue(nearHi[a] ? nd.lo[a][ch] : nd.hi[a][ch]);
+					ntn = std::min(ntn, fmaf(hn, -a8n[a], nB[a])); tf = std::min(tf, fmaf(hf, a8f[a], Bf[a]));
+				}
+				if (!std::signbit(fmaf(tf, widen, ntn))) hit |= 1u << ch;
+				if (getenv("RAYLIB_WALK8_TRACE")) {
+					float pn[3], pf[3];
+					for (int a = 0; a < 3; ++a) { const float hn = (float)HalfValue(nearHi[a] ? nd.hi[a][ch] : nd.lo[a][ch]), hf = (float)HalfValue(nearHi[a] ? nd.lo[a][ch] : nd.hi[a][ch]); pn[a] = -fmaf(hn, -a8n[a], nB[a]); pf[a] = fmaf(hf, a8f[a], Bf[a]); }
+					fprintf(stderr, "  node %u child %d %s: near %.6g %.6g %.6g far %.6g %.6g %.6g  box x[%.9g %.9g] y[%.9g %.9g] z[%.9g %.9g] %s\n", node, ch, ((imask >> ch) & 1u) ? "inner" : (((nd.leafMask >> (4 * ch)) & 15u) ? "leaf" : "empty"),
+					        pn[0], pn[1], pn[2], pf[0], pf[1], pf[2], nd.origin[0] + HalfValue(nd.lo[0][ch]) * bvh.step8, nd.origin[0] + HalfValue(nd.hi[0][ch]) * bvh.step8, nd.origin[1] + HalfValue(nd.lo[1][ch]) * bvh.step8, nd.origin[1] + HalfValue(nd.hi[1][ch]) * bvh.step8,
+					        nd.origin[2] + HalfValue(nd.lo[2][ch]) * bvh.step8, nd.origin[2] + HalfValue(nd.hi[2][ch]) * bvh.step8, ((hit >> ch) & 1u) ? "HIT" : "culled");
+				}
+			}
+			uint32_t innerP = 0;
+			for (uint32_t b = 0; b < 8u; ++b) if (((hit & imask) >> b) & 1u) innerP |= 1u << (b ^ oct);
+			for (uint32_t ch = 0; ch < 8u; ++ch) {
+				if (!((hit & ~imask) >> ch & 1u)) continue;
+				const uint32_t nib = (nd.leafMask >> (4 * ch)) & 15u;
+				const uint32_t first = nd.triBase + (uint32_t)__builtin_popcount(nd.leafMask & ((1u << (4 * ch)) - 1u));
+				for (uint32_t k = 0; k < (uint32_t)__builtin_popcount(nib); ++k) {
+					if (first + k >= bvh.triOrder.size()) return false;
+					const HostTriangle& t = tris[bvh.triOrder[first + k]];
+					// tolerant double-precision test (edges and vertices count as inside by 1e-6): a superset of what the reference's float test accepts
+					const double e1[3] = { (double)t.v1.x - t.v0.x, (double)t.v1.y - t.v0.y, (double)t.v1.z - t.v0.z }, e2[3] = { (double)t.v2.x - t.v0.x, (double)t.v2.y - t.v0.y, (double)t.v2.z - t.v0.z };
+					const double dd[3] = { d[0], d[1], d[2] };
+					const double pv[3] = { dd[1] * e2[2] - dd[2] * e2[1], dd[2] * e2[0] - dd[0] * e2[2], dd[0] * e2[1] - dd[1] * e2[0] };
+					const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+					if (det == 0.0) continue;
+					const double tv[3] = { (double)o[0] - t.v0.x, (double)o[1] - t.v0.y, (double)o[2] - t.v0.z };
+					const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+					const double qv[3] = { tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0] };
+					const double v = (dd[0] * qv[0] + dd[1] * qv[1] + dd[2] * qv[2]) / det;
+					const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
+					if (u >= -1e-6 && v >= -1e-6 && u + v <= 1.0 + 1e-6 && tt >= (double)tMin * 0.999 && tt < best) best = tt;
+				}
+			}
+			gx = nd.childBase; gy = (innerP << 24) | imask;
+		}
+		outT[r] = best >= (double)FLT_MAX ? FLT_MAX : (float)best;
+		if (outSteps) outSteps[r] = steps;
+	}
+	return true;
 }
 
 } // namespace rl

@@ -117,6 +117,8 @@ struct BVH {
 	uint32_t stackNeed4 = 0;          // worst-case traversal-stack entries of nodes4 (sum of children - 1 along the deepest path)
 	std::vector<DNode8> nodes8;       // the 8-wide tree (DNode8, rl_device.h); its leaves are the BVH2's leaves, and the order of the triangle slots is ITS order (a node's leaf children hold consecutive slots)
 	uint32_t depth8 = 0;              // levels of nodes8: a traversal's stack holds at most one entry (the rest of a node's hit children) per level
+	float step8 = 1.0f;               // the unit of nodes8's half-float planes: a power of two, the root's longest side <= 2^15 of it
+	float root8Min[3] = { 0, 0, 0 }, root8Max[3] = { 0, 0, 0 };   // the root's box (bounds every corner and plane of nodes8)
 	float sahNodes4 = 0.0f, sahNodes8 = 0.0f;   // sum over the wide tree's nodes of (node's surface area / root's): the expected node steps of a random ray through either tree
 	std::vector<DNode4> leafList;     // scenes of <= 4 * RL_LEAFLIST_RECORDS leaves: every leaf's box, four to a record, no inner nodes (k_trace's flat walk; empty otherwise)
 	std::vector<uint32_t> triOrder;   // leaf order -> index into the flat triangle array
@@ -126,11 +128,20 @@ struct BVH {
 // Binned-SAH BVH2 over primitive bounds.  A leaf holds <= 4 triangles or one analytic primitive.
 enum PrimKind { PRIM_TRIANGLE = 0, PRIM_SPHERE = 1, PRIM_CUBE = 2 };
 struct PrimRef { f3 mn, mx; uint8_t kind; uint32_t index; };
-void BuildBVH(const std::vector<PrimRef>& prims, BVH& out);
+// wideGreedy: collapse the 8-wide tree by opening the largest child first instead of the plan that minimises the summed node area (an A/B switch: the scene reads
+// RAYLIB_WIDE_GREEDY once, when it is finalized).  The 8-wide collapse decides the ORDER OF THE TRIANGLE SLOTS, and with it which of two surfaces at exactly the
+// same distance wins (the lower slot: DESIGN.md section 4) -- frames of the two settings may differ in such tie pixels.
+// splitLeaves8: give every leaf of a scene whose rays are expected to take >= minSteps8 node steps on the 4-wide tree (the scenes that walk the 8-wide tree by
+// default) a split of its triangles for the 8-wide plan to open in otherwise empty slots (rl_bvh.cc SplitLeaves); triCost8: what an expected triangle test
+// weighs against an expected node step in that plan.
+struct BVHBuildOptions { bool wideGreedy = false; bool splitLeaves8 = true; float triCost8 = 0.5f; float minSteps8 = 40.0f; };
+void BuildBVH(const std::vector<PrimRef>& prims, BVH& out, const BVHBuildOptions& opt = BVHBuildOptions());
 bool BVHCapacityOk(size_t numPrimitives);   // a leaf reference addresses 2^25 primitive slots
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris);
 bool ValidateBVH4(const BVH& bvh, const std::vector<HostTriangle>& tris);
 bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris);   // true also when the scene has no 8-wide tree
+// the megakernel's 8-wide walk restated on the host (box arithmetic, visiting order, groups): least distance among the triangles of the leaf children it reaches
+bool Walk8Host(const BVH& bvh, const std::vector<HostTriangle>& tris, const float* rays, int n, float tMin, const float* tMax, float* outT, uint32_t* outSteps);
 
 // Scene elements created through include/raylib_amd.h (the reference's procedural scenes `new` C++ objects in the
 // application instead: src/main.cc:913-984).  A material is owned by the library and shared by reference.

@@ -278,6 +278,26 @@ bool Upload(T*& dst, const T* src, size_t count)
 	return true;
 }
 
+#define RL_BVH8_MIN_STEPS 40.0f
+#define RL_POOL_DEFAULT_MIN_TRIS 256u
+// what SelectTraceKernel's default choice comes to for a scene (no environment overrides): the pool schedule on the 8-wide tree
+static bool Walks8ByDefault(const DeviceScene* D, size_t numTriangles)
+{
+	return D->hasNodes8 && D->depth8 <= RL_POOL8_MAXLEVELS && D->sahNodes4 >= RL_BVH8_MIN_STEPS && numTriangles >= RL_POOL_DEFAULT_MIN_TRIS;
+}
+// the wide tree a render is about to walk, on this rank's device (uploaded with the scene only when it is the default choice)
+static bool EnsureWideTree(DeviceSceneCopy* C, const Scene& sc, int width, bool gridNodes)
+{
+	if (width == 8 && !C->nodes8 && !sc.bvh.nodes8.empty()) {
+		if (!Upload(C->nodes8, sc.bvh.nodes8.data(), sc.bvh.nodes8.size())) return false;
+		C->view.nodes8 = C->nodes8;
+	}
+	if (width == 4 && gridNodes && RL_Q4 && !C->nodes4 && !sc.bvh.nodes4q.empty()) {
+		if (!Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size())) return false;
+		C->view.nodes4 = C->nodes4;
+	}
+	return true;
+}
 void FreeCopy(DeviceSceneCopy* C)
 {
 	if (!C) return;
@@ -437,8 +457,12 @@ bool UploadScene(Scene& sc)
 		// the grid nodes for the pool schedule; the float-box nodes for scenes small enough to stay in the caches (k_trace's class),
 		// where the grid's extra arithmetic buys nothing (Cornell frame: 22.8 ms on float boxes, 23.8 ms on the grid)
 		const bool wantFull = D->hasNodes4 && (!RL_Q4 || sc.triangles.size() < 4096);
-		if (ok && D->hasNodes4 && RL_Q4) ok = Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size());
-		if (ok && D->hasNodes8) ok = Upload(C->nodes8, sc.bvh.nodes8.data(), sc.bvh.nodes8.size());
+		// Of the two wide trees the pool schedule can walk, the one its default choice walks (SelectTraceKernel: the 8-wide tree for scenes whose rays are expected to take
+		// many steps) goes to the device now; the other follows the first time a render asks for it (EnsureWideTree: RAYLIB_BVH8 / RAYLIB_BVH4 / RAYLIB_POOL are read
+		// per render).  A 10 M-triangle scene keeps 190 MB of nodes per device instead of 290.
+		const bool walks8 = Walks8ByDefault(D, sc.triangles.size());
+		if (ok && D->hasNodes4 && RL_Q4 && !walks8) ok = Upload(C->nodes4, sc.bvh.nodes4q.data(), sc.bvh.nodes4q.size());
+		if (ok && D->hasNodes8 && walks8) ok = Upload(C->nodes8, sc.bvh.nodes8.data(), sc.bvh.nodes8.size());
 		if (ok && wantFull) ok = Upload(C->nodes4f, sc.bvh.nodes4.data(), sc.bvh.nodes4.size());
 		if (ok && wantFull && !sc.bvh.leafList.empty()) ok = Upload(C->leafList, sc.bvh.leafList.data(), sc.bvh.leafList.size());
 		ok = ok && Upload(C->isect, isect.data(), n) && Upload(C->shade, shade.data(), n);
@@ -456,6 +480,8 @@ bool UploadScene(Scene& sc)
 		V.numNodes4 = (int32_t)sc.bvh.nodes4.size(); V.numMaterials = (int32_t)mats.size();
 		V.leafList = C->leafList; V.numLeafRecords = C->leafList ? (int32_t)sc.bvh.leafList.size() : 0;
 		V.fastBary = fastBary.load();
+		V.step8 = sc.bvh.step8; V.numNodes8 = (int32_t)sc.bvh.nodes8.size();
+
 	}
 	HIP_OK(hipSetDevice(g_rt.devices[0]));
 	sc.device = D;
@@ -488,7 +514,6 @@ bool SyncSky(Scene& sc)
 	return true;
 }
 
-#define RL_BVH8_MIN_STEPS 40.0f
 typedef void (*TraceKernel)(const DRenderParams, const DSceneView, const SkyRot, SampleRGB*, float*, unsigned long long*, unsigned int*);
 
 // poolK = 0: k_trace (one path per lane); poolK = K: k_trace_pool with 64*K paths per wave
@@ -510,7 +535,12 @@ TraceKernel SelectTraceKernel(int& poolK, const DeviceScene* D, bool& shortStack
 			// (tools/gpu_bvh8_sweep.py, profiles/r04_bvh8_sweep.log) the 8-wide walk loses 2 - 8 % below ~30 expected steps of the 4-wide tree (the builder's sum of
 			// node areas over the root's), breaks even between 30 and 42 and wins 3 - 9 % from 59 up.  RAYLIB_BVH8=0|1 overrides the choice.
 			const char* w8 = getenv("RAYLIB_BVH8");
-			if (D->hasNodes8 && D->depth8 <= 16 && (w8 ? atoi(w8) != 0 : D->sahNodes4 >= RL_BVH8_MIN_STEPS)) { width = 8; return (TraceKernel)k_trace_pool<32, PRIMS, 2, 16, 3>; }
+			const bool want8 = D->hasNodes8 && (w8 ? atoi(w8) != 0 : D->sahNodes4 >= RL_BVH8_MIN_STEPS);
+			if (want8 && D->depth8 <= RL_POOL8_MAXLEVELS) { width = 8; return (TraceKernel)k_trace_pool<2 * RL_POOL8_MAXLEVELS, PRIMS, 2, RL_POOL8_LSTACK, 3>; }
+			if (want8) {   // (the kernel's stack holds one group of hit children per level: a deeper 8-wide tree is not walked, and that is said once per scene)
+				static const DeviceScene* told = nullptr;
+				if (told != D) { told = D; Log("Raylib_Render: the scene's 8-wide tree has %u levels, the pool kernel's stack holds %d: walking the 4-wide tree", D->depth8, (int)RL_POOL8_MAXLEVELS); }
+			}
 			return D->stackNeed4 <= 32 ? (TraceKernel)k_trace_pool<32, PRIMS, 2, RL_POOL_SHORT_LSTACK, 1> : (TraceKernel)k_trace_pool<64, PRIMS, 2, RL_POOL_SHORT_LSTACK, 1>;
 		}
 		if constexpr (STACK == 32) {
@@ -597,13 +627,15 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 		// (the Cornell class: tens of triangles, shading-bound).  Measured crossover (tools/gpu_crossover.py, tessellated rooms at
 		// 1080p x 16 spp, pool time / k_trace time): 36 triangles 1.07, 144: 0.97, 324: 0.95, 1296: 0.89, 5184: 0.80, 20736: 0.67.
 		// RAYLIB_POOL=0|2|3|4 overrides.
-		uint32_t minTris = 256; if (const char* e = getenv("RAYLIB_POOL_MIN_TRIS")) minTris = (uint32_t)atoi(e);
+		uint32_t minTris = RL_POOL_DEFAULT_MIN_TRIS; if (const char* e = getenv("RAYLIB_POOL_MIN_TRIS")) minTris = (uint32_t)atoi(e);
 		int poolK = (STACK <= 32 && !PRIMS && sc.triangles.size() >= minTris) ? 2 : 0;
 		if (const char* e = getenv("RAYLIB_POOL")) poolK = atoi(e);
 		bool shortStack = false; int width = 2;
 		TraceKernel traceKernel = SelectTraceKernel<STACK, PRIMS>(poolK, DS, shortStack, width);
 		// k_trace walks the 4-wide tree too when the scene has one whose worst-case stack fits this instantiation's LDS stack:
 		// on float boxes if the scene carries them (small scenes), else on the grid nodes
+		// (k_trace walks the grid nodes too when the scene carries no float-box ones)
+		if (!EnsureWideTree(D, sc, poolK > 0 ? width : (DS->hasNodes4 ? 4 : 2), poolK > 0 || !D->nodes4f)) return false;
 		DSceneView traceView = D->view;
 #if !RL_Q4
 		traceView.nodes4 = nullptr;
@@ -684,6 +716,7 @@ bool EnqueueRender(RankCtx& R, Scene& sc, const RenderRequest& req, PendingRende
 			if (it == R.occupancy.end()) {
 				HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, traceKernel, RL_BLOCK, 0));
 				R.occupancy[(const void*)traceKernel] = blocksPerCU;
+				if (getenv("RAYLIB_PRINT_OCCUPANCY")) Log("megakernel (%u paths per lane, tree width %d): %d workgroups per CU", pathsPerThread, width, blocksPerCU);
 			} else blocksPerCU = it->second;
 		}
 		if (blocksPerCU < 1) blocksPerCU = 1;
@@ -843,6 +876,18 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 		}
 	}
 #endif
+#ifdef RL_DIAG_TOPN
+	if (getenv("RAYLIB_PRINT_STAMPS")) {
+		const double n = (double)cnt[CNT_NODES] + 1e-9;
+		Log("node steps by node number (breadth first): < 9: %.3f  < 22: %.3f  < 53: %.3f  < 73: %.3f  < 128: %.3f  < 256: %.3f  < 1024: %.3f  beyond: %.3f (cumulative shares of %.0f steps)",
+		    cnt[CNT_COUNT + 4] / n, (cnt[CNT_COUNT + 4] + cnt[CNT_COUNT + 5]) / n, (cnt[CNT_COUNT + 4] + cnt[CNT_COUNT + 5] + cnt[CNT_COUNT + 6]) / n,
+		    (cnt[CNT_COUNT + 4] + cnt[CNT_COUNT + 5] + cnt[CNT_COUNT + 6] + cnt[CNT_COUNT + 7]) / n, (cnt[CNT_COUNT + 4] + cnt[CNT_COUNT + 5] + cnt[CNT_COUNT + 6] + cnt[CNT_COUNT + 7] + cnt[CNT_COUNT + 8]) / n,
+		    (cnt[CNT_COUNT + 4] + cnt[CNT_COUNT + 5] + cnt[CNT_COUNT + 6] + cnt[CNT_COUNT + 7] + cnt[CNT_COUNT + 8] + cnt[CNT_COUNT + 9]) / n,
+		    (cnt[CNT_COUNT + 4] + cnt[CNT_COUNT + 5] + cnt[CNT_COUNT + 6] + cnt[CNT_COUNT + 7] + cnt[CNT_COUNT + 8] + cnt[CNT_COUNT + 9] + cnt[CNT_COUNT + 10]) / n, cnt[CNT_COUNT + 11] / n, n);
+		Log("groups on the stack at a node step: 0: %.3f  1: %.3f  2: %.3f  3: %.3f  4: %.3f  5: %.3f  6-7: %.3f  8+: %.3f", cnt[CNT_COUNT + 16] / n, cnt[CNT_COUNT + 17] / n, cnt[CNT_COUNT + 18] / n,
+		    cnt[CNT_COUNT + 19] / n, cnt[CNT_COUNT + 20] / n, cnt[CNT_COUNT + 21] / n, cnt[CNT_COUNT + 22] / n, cnt[CNT_COUNT + 23] / n);
+	}
+#else
 	if (getenv("RAYLIB_PRINT_STAMPS")) {
 		const double tot = (double)(cnt[CNT_COUNT] + cnt[CNT_COUNT + 1] + cnt[CNT_COUNT + 2] + cnt[CNT_COUNT + 3]);
 		Log("wave steps: node %llu (lane steps %llu, eff %.3f)  tri %llu (lane %llu, eff %.3f)  leaf rounds %llu  trips %llu", cnt[CNT_COUNT + 4], cnt[CNT_NODES], cnt[CNT_NODES] / (64.0 * cnt[CNT_COUNT + 4] + 1), cnt[CNT_COUNT + 5], cnt[CNT_TRIS], cnt[CNT_TRIS] / (64.0 * cnt[CNT_COUNT + 5] + 1), cnt[CNT_COUNT + 6], cnt[CNT_TRIPS]);
@@ -858,6 +903,7 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 		}
 		if (tot > 0) Log("phase shares (shader clock): refill %.3f traverse %.3f shade %.3f fold %.3f", cnt[CNT_COUNT] / tot, cnt[CNT_COUNT + 1] / tot, cnt[CNT_COUNT + 2] / tot, cnt[CNT_COUNT + 3] / tot);
 	}
+#endif
 	return true;
 }
 

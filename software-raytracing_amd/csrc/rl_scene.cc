@@ -131,7 +131,11 @@ bool Scene::BuildAccel(float t0, float t1)
 		prims.push_back(p);
 	}
 	const auto tBuild = std::chrono::steady_clock::now();
-	BuildBVH(prims, bvh);
+	BVHBuildOptions bopt;
+	{ const char* e = getenv("RAYLIB_WIDE_GREEDY"); bopt.wideGreedy = e && atoi(e) != 0; }   // read here, once per scene: rl_host.h BVHBuildOptions
+	if (const char* e = getenv("RAYLIB_W8_SPLIT")) bopt.splitLeaves8 = atoi(e) != 0;
+	if (const char* e = getenv("RAYLIB_W8_TRI_COST")) bopt.triCost8 = (float)atof(e);
+	BuildBVH(prims, bvh, bopt);
 	const double buildSec = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
 	// leaves that contain a triangle whose material has an albedo texture run the
 	// cut-out test inside traversal (reference geom/triangle.cc:54, material.cc:397-404)
@@ -154,12 +158,12 @@ bool Scene::BuildAccel(float t0, float t1)
 		for (DNode4Q& n : bvh.nodes4q) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 		for (DNode4& n : bvh.leafList) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 		for (DNode8& n : bvh.nodes8) {   // the 8-wide node names its leaf children's triangles through triBase + leafMask; the flag is a bit per child
-			n.alphaMask = 0;
+			n.meta &= 0xffff00ffu;   // imask | alphaMask << 8 | extent x << 16
 			for (int c = 0; c < 8; ++c) {
 				const uint32_t nib = (n.leafMask >> (4 * c)) & 15u;
 				if (!nib) continue;
 				const uint32_t first = n.triBase + (uint32_t)__builtin_popcount(n.leafMask & ((1u << (4 * c)) - 1u)), count = (uint32_t)__builtin_popcount(nib);
-				for (uint32_t k = 0; k < count; ++k) if (alpha[bvh.triOrder[first + k]]) { n.alphaMask |= 1u << c; break; }
+				for (uint32_t k = 0; k < count; ++k) if (alpha[bvh.triOrder[first + k]]) { n.meta |= 1u << (8 + c); break; }
 			}
 		}
 	}

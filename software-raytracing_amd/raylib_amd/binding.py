@@ -130,6 +130,7 @@ _EXPORTS = {
     "RaylibAMD_SceneBVH4Info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "RaylibAMD_SceneBVH8Info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "RaylibAMD_SceneLeafListInfo": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "RaylibAMD_SceneWalk8Host": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "RaylibAMD_SceneBVHHash": (C.c_uint64, [C.c_void_p]),
     "RaylibAMD_CameraExport": (None, [C.c_void_p, C.POINTER(C.c_float)]),
     "RaylibAMD_CreateImageFromData": (C.c_void_p, [C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
@@ -145,6 +146,8 @@ def load(path=LIB_PATH):
         raise FileNotFoundError(path + " -- build it with `make -C software-raytracing_amd` (or __graft_entry__.build())")
     lib = C.CDLL(path)
     for name, (res, args) in _EXPORTS.items():
+        if os.environ.get("RAYLIB_LIB") and name.startswith("RaylibAMD_") and not hasattr(lib, name):
+            continue              # (an older build named by RAYLIB_LIB for an A/B run may lack a newer introspection hook; the tree's own library must export everything)
         fn = getattr(lib, name)   # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
     return lib

@@ -162,7 +162,10 @@ def build_arrays(objects, tess=1, displace_fraction=0.0, displace_seed=7, room=(
     nrm = np.cross(e1, e2)
     length = np.sqrt(np.einsum("ij,ij->i", nrm, nrm))
     nrm = (nrm / np.maximum(length, 1e-30)[:, None]).astype(np.float32)
-    return dict(tri=tri, uv=uv, normal=nrm, owner=owner, objects=meta)
+    was_moved = np.zeros(n, bool)
+    if displace_fraction > 0:
+        was_moved[m] = True
+    return dict(tri=tri, uv=uv, normal=nrm, owner=owner, objects=meta, moved=was_moved)
 
 
 def write_obj(path, objects, mtl_text, tess=1, with_normals=True, with_uvs=True,
@@ -242,6 +245,135 @@ def colonnade_objects(n_columns=24, segments=24):
 def colonnade(path, tess=6, **kw):
     """C4: 24 columns x 24 facets + 5 walls = 581 quads; tess=6 -> 41 832, tess=12 -> 167 328 triangles."""
     return write_obj(path, colonnade_objects(), CORNELL_MTL, tess=tess, **kw)
+
+
+# ---------------------------------------------------------------------------------
+# The BASELINE-size rooms WITH textures and alpha cut-outs (SURVEY 8d: "tessellated room + instanced foliage cards with an alpha-cut-out
+# texture"; Breakfast Room, Sponza and San Miguel all use map_Kd): every wall of the tessellated room carries an albedo map, and the fifth of
+# the triangles that build_arrays displaces into the room are FOLIAGE CARDS -- one object with a cut-out albedo map (alpha 0 / 255, about half
+# of it holes), UVs spread so that a card spans a few leaves.  A material with an albedo map is alpha-tested inside Triangle::Hit for every
+# candidate (reference geom/triangle.cc:54, render/material.cc:397-404, render/texture.cc:30-53): walls pass (alpha 1), cards cut rays' paths
+# open -- any-hit work in the traversal of a deep tree, texel traffic, divergence.
+
+WALL_W, WALL_R, WALL_G, FOLIAGE = "white", "red", "green", "foliage"
+
+TEXTURED_MTL = """# tessellated room with albedo maps; foliage cards with an alpha cut-out
+newmtl white
+Ns 10
+Kd 0.725 0.71 0.68
+Ks 0 0 0
+map_Kd wall_white.png
+illum 2
+
+newmtl red
+Ns 10
+Kd 0.63 0.065 0.05
+Ks 0 0 0
+map_Kd wall_red.png
+illum 2
+
+newmtl green
+Ns 10
+Kd 0.14 0.45 0.091
+Ks 0 0 0
+map_Kd wall_green.png
+illum 2
+
+newmtl light
+Ns 10
+Kd 0.78 0.78 0.78
+Ks 0 0 0
+Ke 17 12 4
+illum 2
+
+newmtl mirror
+Ns 10
+Kd 0.9 0.9 0.9
+Ks 0 0 0
+illum 3
+
+newmtl foliage
+Ns 10
+Kd 0.5 0.6 0.3
+Ks 0 0 0
+map_Kd foliage.png
+illum 2
+"""
+FOLIAGE_UV_SCALE = 24.0
+
+
+def wall_texture(tint, size=128):
+    """Opaque RGBA8 'plaster and bricks': a brick bond in two tones of `tint` (0..255 per channel) with darker joints; alpha 255 everywhere."""
+    yy, xx = np.mgrid[0:size, 0:size]
+    row = yy // 16
+    col = (xx + 16 * (row % 2)) // 32
+    joint = ((yy % 16) < 2) | (((xx + 16 * (row % 2)) % 32) < 2)
+    tone = 200 + 17 * ((row * 7 + col * 13) % 4)
+    img = np.zeros((size, size, 4), np.uint8)
+    for c in range(3):
+        v = (tint[c] * tone) // 255
+        img[..., c] = np.where(joint, (v * 5) // 8, v)
+    img[..., 3] = 255
+    return img
+
+
+def foliage_texture(size=64):
+    """RGBA8 leaves: elliptic blobs of greens on a fully transparent ground (alpha 0 / 255 only; a little under half of the texels are leaf)."""
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    img = np.zeros((size, size, 4), np.uint8)
+    rng = np.random.RandomState(11)
+    for _ in range(30):
+        cx, cy = rng.uniform(0, size, 2)
+        a, b = rng.uniform(5, 11), rng.uniform(2.5, 5)
+        th = rng.uniform(0, np.pi)
+        g = (70 + rng.randint(0, 120), 110 + rng.randint(0, 130), 30 + rng.randint(0, 60))
+        for ox in (-size, 0, size):            # leaves wrap around the edges: the sampler repeats the texture (render/texture.cc:38-41)
+            for oy in (-size, 0, size):
+                dx, dy = xx - cx - ox, yy - cy - oy
+                u, v = dx * np.cos(th) + dy * np.sin(th), -dx * np.sin(th) + dy * np.cos(th)
+                inside = (u / a) ** 2 + (v / b) ** 2 <= 1.0
+                img[inside, 0], img[inside, 1], img[inside, 2], img[inside, 3] = g[0], g[1], g[2], 255
+    return img
+
+
+def textured_textures():
+    """file name -> (H, W, 4) uint8, what `textured` writes next to the OBJ."""
+    return {"wall_white.png": wall_texture((185, 181, 173)), "wall_red.png": wall_texture((161, 17, 13)), "wall_green.png": wall_texture((36, 115, 23)),
+            "foliage.png": foliage_texture()}
+
+
+def build_arrays_textured(tess=1, displace_fraction=0.2, displace_seed=7):
+    """build_arrays of the Cornell room with the displaced triangles gathered into ONE extra object, the foliage cards (material `foliage`, UVs spread by
+    FOLIAGE_UV_SCALE so that the sampler's repeat wrap lays several leaves over a card).  Same dictionary as build_arrays."""
+    A = build_arrays(cornell_objects(), tess, displace_fraction, displace_seed)
+    mv = A["moved"]
+    keep = np.nonzero(~mv)[0]; cards = np.nonzero(mv)[0]
+    order = np.concatenate([keep, cards])
+    uv = A["uv"].copy()
+    uv[cards] = (uv[cards].astype(np.float64) * FOLIAGE_UV_SCALE).astype(np.float32)
+    owner = A["owner"].copy()
+    objects = list(A["objects"])
+    if len(cards):
+        owner[cards] = len(objects)
+        objects.append(("foliage", FOLIAGE))
+    return dict(tri=A["tri"][order], uv=uv[order], normal=A["normal"][order], owner=owner[order], objects=objects, moved=mv[order])
+
+
+def write_textures(directory, textures):
+    for name, img in textures.items():
+        write_png_rgba(os.path.join(directory, name), img)
+
+
+def textured(path, tess=91, displace_fraction=0.2):
+    """The configs[2]-sized room with albedo maps on its walls and a fifth of its triangles as alpha-cut-out foliage cards (tess = 91: 298 116 triangles,
+    59 662 of them cards).  Writes <path>.obj, .mtl and the four PNG maps; returns the .obj path and the triangle count."""
+    base = os.path.splitext(path)[0]
+    A = build_arrays_textured(tess, displace_fraction)
+    write_obj_text(base + ".obj", A, os.path.basename(base) + ".mtl")
+    with open(base + ".mtl", "w") as f:
+        f.write(TEXTURED_MTL)
+    write_textures(os.path.dirname(os.path.abspath(path)), textured_textures())
+    return base + ".obj", len(A["tri"])
 
 
 # Cameras / suns per config (reference scenes.json, src/main.cc:64-155)

@@ -77,3 +77,21 @@ def mid_scene(gpu_lib, workdir):
     ses = binding.SceneSession(gpu_lib, obj, (0, 1, 5), (0, 1, -1), 60.0, 96 / 64, sun=(20, 20, 20), sun_dir=(-1.0, -1.0, 0.0))
     yield ses, obj, n
     ses.close()
+
+
+@pytest.fixture(scope="session")
+def config2_scene(gpu_lib, oracle, workdir):
+    """BASELINE configs[2]'s stand-in (tessellated room, 298 116 triangles, a fifth of them displaced, sun) through the OBJ path, loaded once for the contract tier's
+    whole-frame comparison and for tests/test_gpu_01_configs.py; the product must have loaded exactly the generator's arrays.  Yields (session, flat scene, obj path)."""
+    from raylib_amd import binding
+    h = _helpers()
+    cam = h.scenes.CONFIG_CAMERAS["breakfast"]
+    d = os.path.join(str(workdir), "config2"); os.makedirs(d, exist_ok=True)
+    obj, flat = h.big_scene(os.path.join(d, "c2.obj"), h.scenes.cornell_objects(), h.scenes.CORNELL_MTL, oracle, 91, 0.2, sun=cam["sun"], sun_dir=cam["sun_dir"])
+    assert len(flat.triangles) == 298116
+    ses = binding.SceneSession(gpu_lib, obj, cam["origin"], cam["look_at"], cam["fov"], 1920 / 1080, sun=cam["sun"], sun_dir=cam["sun_dir"])
+    tris, mats = ses.export_flat()
+    assert tris.tobytes() == flat.triangles.tobytes(), "the product's loader and the generator's arrays disagree"
+    assert mats.tobytes() == flat.materials.tobytes()
+    yield ses, flat, obj
+    ses.close()

@@ -105,6 +105,33 @@ def main(only=None):
             print("bench windows", wl, len(pos), "of", len(wins))
         np.savez_compressed(os.path.join(HERE, "bench_windows.npz"), **out)
 
+    # ---- ... and of the textured / alpha-cut-out workload (round 5), a file of its own so that the fixtures above stay untouched ----
+    if want("bench_windows_textured"):
+        out = {}
+        for wl, camname, w, h, spp, wins in (
+                ("breakfast_textured_interior_300k_1080p_128spp", "breakfast_interior", 1920, 1080, 128,
+                 ((952, 536), (100, 100), (1800, 60), (40, 1000), (1850, 1040), (600, 300), (1300, 760), (480, 880), (1500, 200))),):
+            c = scenes.CONFIG_CAMERAS[camname]
+            obj, _ = scenes.textured(os.path.join(tmp, wl + ".obj"), tess=91, displace_fraction=0.2)
+            flat = objflat.load_obj(obj, orc, texture_loader=helpers.texture_loader, sun_illuminance=c["sun"], sun_direction=c["sun_dir"])
+            assert len(flat.textures) == 4
+            sr, so = ref.scene_create(flat, BUILD_SEED), orc.scene_create(flat, BUILD_SEED)
+            cam = ffi.make_camera(c["origin"], c["look_at"], c["fov"], w / h)
+            st = ffi.make_settings(w, h, spp)
+            pos, px = [], []
+            for (x0, y0) in wins:
+                a = ref.render_region(sr, cam, st, x0, y0, 16, 16, seed=SEED)
+                b = orc.render_region(so, cam, st, x0, y0, 16, 16, seed=SEED)
+                cn = orc.counters(so)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+                if cn["closest_hit_ties"] == 0 and cn["hits_outside_own_box"] == 0:
+                    pos.append((x0, y0)); px.append(a)
+                else:
+                    print("   window", x0, y0, "of", wl, "left out:", cn["closest_hit_ties"], "ties")
+            out[wl + "_pos"] = np.asarray(pos, np.int32); out[wl + "_px"] = np.asarray(px, np.float32)
+            print("bench windows", wl, len(pos), "of", len(wins))
+        np.savez_compressed(os.path.join(HERE, "bench_windows_textured.npz"), **out)
+
     # ---- statistics of the UNTOUCHED reference (oracle/_ref/libref_native.so: its own std::random_device RNG, core/random.h:17-29) ----
     # Every other fixture goes through the determinism overlay (oracle/ref_shim/core/random.h).  This one pins the link the overlay
     # cannot: that the seeded stream contract samples the same distribution as the reference's own generator in the reference's own

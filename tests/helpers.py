@@ -20,6 +20,8 @@ def texture_loader(path):
     name = os.path.basename(path)
     if name == "leaf.png":
         return scenes.texture_as_float(scenes.leaf_texture())
+    if name in scenes.textured_textures():
+        return scenes.texture_as_float(scenes.textured_textures()[name])
     stem, ext = os.path.splitext(name)
     if ext == ".png" and stem in scenes.pbr_textures():
         return scenes.texture_as_float(scenes.pbr_textures()[stem])
@@ -77,23 +79,33 @@ def session_for_case(lib, name, tmpdir):
                                 sky_image=scenes.sky_panorama() if c["sky"] else None)
 
 
-def big_scene(path, objects, mtl_text, oracle, tess, displace_fraction=0.0, sun=(0, 0, 0), sun_dir=(0.0, -1.0, -0.5)):
-    """A large synthetic scene for the BASELINE-size tests: the arrays of scenes.build_arrays, written as OBJ text by the checker
-    library's multi-threaded writer (the Python writer needs minutes for millions of triangles; same format, same digits), and the
-    flat scene the arrays ARE -- every float32 survives its 9 printed digits -- for the oracle.  The caller checks that the product
-    loaded exactly this flat scene.  Returns (obj path, FlatScene)."""
-    A = scenes.build_arrays(objects, tess, displace_fraction)
+def big_scene(path, objects, mtl_text, oracle, tess, displace_fraction=0.0, sun=(0, 0, 0), sun_dir=(0.0, -1.0, -0.5), arrays=None, textures=None):
+    """A large synthetic scene for the BASELINE-size tests: the arrays of scenes.build_arrays (or `arrays`, the same dictionary), written as OBJ
+    text by the checker library's multi-threaded writer (the Python writer needs minutes for millions of triangles; same format, same digits),
+    and the flat scene the arrays ARE -- every float32 survives its 9 printed digits -- for the oracle.  `textures`: file name -> (H, W, 4)
+    uint8, written as PNG next to the OBJ and handed to the oracle as byte / 255 floats, numbered as the reference numbers them (in the order
+    the MTL's materials name their albedo maps, obj_loader.cc:372-395).  The caller checks that the product loaded exactly this flat scene.
+    Returns (obj path, FlatScene)."""
+    A = arrays if arrays is not None else scenes.build_arrays(objects, tess, displace_fraction)
     base = os.path.splitext(path)[0]
     oracle.write_obj(base + ".obj", os.path.basename(base) + ".mtl", A["tri"], A["uv"], A["normal"], A["owner"], A["objects"])
     with open(base + ".mtl", "w") as f:
         f.write(mtl_text)
+    if textures:
+        scenes.write_textures(os.path.dirname(os.path.abspath(path)), textures)
     mtl = objflat.parse_mtl(base + ".mtl")
     names = [m["name"] for m in mtl]
     mats = np.zeros(len(mtl) + 1, ffi.MAT_DTYPE)
+    flat_textures, tex_index = [], {}
     for i, m in enumerate(mtl):
         mats[i] = oracle.material_from_mtl(m["Kd"], m["Ks"], m["Ke"], m["Tf"], m["Ns"], m["Ni"], m["illum"], m["Pr"], m["Pm"], bool(m["map_Kd"]))
         for k in ("texAlbedo", "texNormal", "texRoughness", "texMetallic", "texEmissive"):
             mats[i][k] = -1
+        if textures and m["map_Kd"] in textures and mats[i]["type"] == ffi.MAT_MICROFACET:
+            if m["map_Kd"] not in tex_index:
+                tex_index[m["map_Kd"]] = len(flat_textures)
+                flat_textures.append(scenes.texture_as_float(textures[m["map_Kd"]]))
+            mats[i]["texAlbedo"] = tex_index[m["map_Kd"]]
     mats[-1]["type"] = ffi.MAT_LAMBERTIAN; mats[-1]["albedo"] = (0.5, 0.5, 0.5)
     for k in ("texAlbedo", "texNormal", "texRoughness", "texMetallic", "texEmissive"):
         mats[-1][k] = -1
@@ -105,7 +117,7 @@ def big_scene(path, objects, mtl_text, oracle, tess, displace_fraction=0.0, sun=
     per_object = np.array([names.index(m) if m in names else len(mtl) for _, m in A["objects"]], np.int32)
     tris["material"] = per_object[A["owner"]]
     tris["shape"] = A["owner"]
-    flat = ffi.FlatScene(tris, mats, num_shapes=len(A["objects"]), sun_illuminance=sun, sun_direction=sun_dir)
+    flat = ffi.FlatScene(tris, mats, flat_textures, num_shapes=len(A["objects"]), sun_illuminance=sun, sun_direction=sun_dir)
     return base + ".obj", flat
 
 

@@ -113,6 +113,49 @@ def test_full_size_every_pixel_against_the_oracle(full_size, oracle, workdir):
     oracle.scene_destroy(scene)
 
 
+def whole_frame_vs_oracle(oracle, scene, cam, w, h, spp, img, what, max_tied):
+    """EVERY pixel of a frame against the CPU oracle (same pixel keys).  A pixel may differ only if one of its samples met two surfaces at exactly the same t (or was
+    accepted by the reference outside the triangle's own box): the reference's own answer depends on its randomly shaped tree there, the oracle counts the event."""
+    ocam = ffi.make_camera(cam["origin"], cam["look_at"], cam["fov"], w / h)
+    st = ffi.make_settings(w, h, spp)
+    want = oracle.render(scene, ocam, st, seed=1)
+    differ = ~helpers.same(img[..., :3], want[..., :3]).all(-1)
+    untied = 0
+    for (py, px) in zip(*np.nonzero(differ)):
+        oracle.render_region(scene, ocam, st, int(px), int(py), 1, 1, seed=1)
+        cn = oracle.counters(scene)
+        if not (cn["closest_hit_ties"] > 0 or cn["hits_outside_own_box"] > 0):
+            untied += 1
+    n = int(differ.sum())
+    print("%s: %d of %d pixels differ from the oracle (%d of them without a tie among their samples); frame RMS L2 %.3e" % (what, n, differ.size, untied, l2(img, want)))
+    assert untied == 0, "%s: %d pixels differ without a closest-hit tie among their samples" % (what, untied)
+    assert n <= max_tied, (what, n)
+    assert (img[..., 3] == 1.0).all()
+
+
+def test_config2_whole_frames_against_the_oracle(config2_scene, gpu_lib, oracle):
+    """BASELINE configs[2]'s stand-in (298 116 triangles + sun), ALL 2 073 600 pixels of the 1080p frame against the CPU oracle -- from the workload's camera outside
+    the room at 4 spp and from the camera inside it at 2 spp (until round 4 only windows of these frames were compared; the full-spp frames are
+    compared window by window in tests/test_gpu_01_configs.py).  The oracle walks the reference's own random-axis median tree, the device its 8-wide SAH tree."""
+    ses, flat, obj = config2_scene
+    scene = oracle.scene_create(flat, 1)
+    cam = helpers.scenes.CONFIG_CAMERAS["breakfast"]
+    img = ses.render(1920, 1080, 4)
+    st = ses.stats().as_dict()
+    assert st["treeWidth"] == 8 and st["pathsPerWave"] == 128 and st["frameSamples"] == 1920 * 1080 * 4
+    whole_frame_vs_oracle(oracle, scene, cam, 1920, 1080, 4, img, "configs[2] exterior, 4 spp", max_tied=40)
+    cin = helpers.scenes.CONFIG_CAMERAS["breakfast_interior"]
+    gpu_lib.Raylib_CameraSetPosition(ses.camera, *[float(x) for x in cin["origin"]]); gpu_lib.Raylib_CameraSetLookAt(ses.camera, *[float(x) for x in cin["look_at"]])
+    try:
+        inside = ses.render(1920, 1080, 2)
+        si = ses.stats().as_dict()
+        assert si["culledCells"] == 0 and si["cameraSamples"] == 1920 * 1080 * 2
+        whole_frame_vs_oracle(oracle, scene, cin, 1920, 1080, 2, inside, "configs[2] interior, 2 spp", max_tied=120)
+    finally:
+        gpu_lib.Raylib_CameraSetPosition(ses.camera, *[float(x) for x in cam["origin"]]); gpu_lib.Raylib_CameraSetLookAt(ses.camera, *[float(x) for x in cam["look_at"]])
+    oracle.scene_destroy(scene)
+
+
 def test_full_size_properties(full_size, gpu_lib):
     ses, img, stats = full_size
     assert np.isfinite(img).all() and (img[..., :3] >= 0).all()

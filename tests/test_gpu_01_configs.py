@@ -11,6 +11,7 @@ path (Raylib_LoadOBJModel).  What is checked at full size:
     rank layout when it initialises): the gathered frame is the one-rank frame bit for bit, with the same ray count.
 The oracle's tree for the multi-million-triangle scene is its n log n median build (oracle.cc BuildBVHFast): the closest hit does not
 depend on the tree."""
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -54,14 +55,13 @@ def check_windows(oracle, scene, cam, aspect, w, h, spp, img, windows, size, max
     assert eq + tied == total and tied <= max_tied and with_geometry >= min_with_geometry, (eq, tied, total, with_geometry)
 
 
-def test_config2_300k_triangles_1080p_128spp(gpu_lib, oracle, workdir, monkeypatch):
+def test_config2_300k_triangles_1080p_128spp(gpu_lib, oracle, workdir, monkeypatch, config2_scene):
     """configs[2] "Breakfast Room OBJ (~300k tris) 1080p, 128 spp, 1 MI355X": the workload bench.py --workload breakfast times --
-    tessellated room, 298 116 triangles, a fifth of them displaced into the room, sun."""
+    tessellated room, 298 116 triangles, a fifth of them displaced into the room, sun.  (The scene is the session's: tests/conftest.py config2_scene,
+    which also checks that the product loaded exactly the generator's arrays; the whole frame at low spp is in the contract tier.)"""
     cam = scenes.CONFIG_CAMERAS["breakfast"]
-    d = os.path.join(str(workdir), "config2"); os.makedirs(d, exist_ok=True)
-    obj, flat = helpers.big_scene(os.path.join(d, "c2.obj"), scenes.cornell_objects(), scenes.CORNELL_MTL, oracle, 91, 0.2, sun=cam["sun"], sun_dir=cam["sun_dir"])
-    assert len(flat.triangles) == 298116
-    ses = load_and_check(gpu_lib, obj, flat, cam, 1920 / 1080)
+    d = os.path.join(str(workdir), "config2")
+    ses, flat, obj = config2_scene
     img = ses.render(1920, 1080, 128)
     st = ses.stats().as_dict()
     assert st["frameSamples"] == 1920 * 1080 * 128 and st["pathsPerWave"] == 128 and st["traceLaunches"] == 1
@@ -87,7 +87,7 @@ def test_config2_300k_triangles_1080p_128spp(gpu_lib, oracle, workdir, monkeypat
     # every schedule of the megakernel gives the same bits and the same ray / shading counts (2 spp keeps this part short)
     base = ses.render(1920, 1080, 2)
     sb = ses.stats().as_dict()
-    assert sb["treeWidth"] == 8 and sb["nodeBytes"] == 80     # a scene this deep walks the 8-wide tree by default (RaylibAMD_SceneBVH8Info: 59 expected steps on the 4-wide one)
+    assert sb["treeWidth"] == 8 and sb["nodeBytes"] == 128    # a scene this deep walks the 8-wide tree by default (RaylibAMD_SceneBVH8Info: 59 expected steps on the 4-wide one)
     for env in (dict(RAYLIB_POOL="0"), dict(RAYLIB_POOL_SHORT_STACK="0"), dict(RAYLIB_BVH4="0"), dict(RAYLIB_BVH8="0")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -111,6 +111,58 @@ def test_config2_300k_triangles_1080p_128spp(gpu_lib, oracle, workdir, monkeypat
     assert np.array_equal(bits(three["img"]), bits(base)), "Raylib_Render over three ranks differs from the one-rank frame"
     assert three["stats"][0] == 3 and three["stats"][1] == sb["cameraSamples"] and three["stats"][3] == sb["rays"], three["stats"]
     os.remove(out)
+
+
+def textured_scene(gpu_lib, oracle, workdir, tag, tess, cam, aspect):
+    """The tessellated room with albedo maps on its walls and a fifth of its triangles as alpha-cut-out foliage cards (scenes.build_arrays_textured; SURVEY 8d's
+    stand-in for Breakfast Room / San Miguel, which use map_Kd throughout), through the OBJ path; the product must have loaded the generator's arrays and decoded its maps."""
+    d = os.path.join(str(workdir), tag); os.makedirs(d, exist_ok=True)
+    obj, flat = helpers.big_scene(os.path.join(d, tag + ".obj"), None, scenes.TEXTURED_MTL, oracle, tess, sun=cam["sun"], sun_dir=cam["sun_dir"],
+                                  arrays=scenes.build_arrays_textured(tess, 0.2), textures=scenes.textured_textures())
+    ses = load_and_check(gpu_lib, obj, flat, cam, aspect)
+    assert gpu_lib.RaylibAMD_SceneNumTextures(ses.scene) == len(flat.textures) == 4
+    for i, t in enumerate(flat.textures):
+        got = np.zeros_like(t)
+        gpu_lib.RaylibAMD_SceneExportTexture(ses.scene, i, got.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(got, t)
+    return ses, flat, obj
+
+
+def test_config2_textured_room_with_alpha_cutout_cards_1080p_128spp(gpu_lib, oracle, workdir, monkeypatch):
+    """configs[2] size WITH textures and cut-outs (VERDICT r04 missing 1): 298 116 triangles, albedo maps on every wall, 59 662 foliage cards whose map is two thirds
+    holes -- the any-hit cut-out test inside the traversal of the deep tree (reference geom/triangle.cc:54, render/material.cc:387-404, render/texture.cc:30-53) --
+    at 1080p x 128 spp from outside and from inside, windows of the full frames against the oracle, every schedule on the same bits."""
+    cam = scenes.CONFIG_CAMERAS["breakfast"]
+    ses, flat, obj = textured_scene(gpu_lib, oracle, workdir, "c2tex", 91, cam, 1920 / 1080)
+    assert len(flat.triangles) == 298116 and (flat.materials["texAlbedo"][flat.triangles["material"]] >= 0).mean() > 0.95
+    scene = oracle.scene_create(flat, 1)
+    img = ses.render(1920, 1080, 128)
+    st = ses.stats().as_dict()
+    assert st["frameSamples"] == 1920 * 1080 * 128 and st["treeWidth"] == 8 and st["texFetches"] > st["rays"] // 4 and np.isfinite(img).all()
+    print("textured, exterior: %.1f ms, %.0f Mrays/s executed, %.2f texel fetches per ray, %.1f node records and %.2f triangle records per ray" % (
+        st["traceKernelMs"], st["rays"] / st["traceKernelMs"] / 1e3, st["texFetches"] / st["rays"], st["nodesVisited"] / st["rays"], st["trisTested"] / st["rays"]))
+    check_windows(oracle, scene, cam, 1920 / 1080, 1920, 1080, 128, img, ((952, 536), (760, 340), (1150, 700), (800, 650), (1100, 380), (1000, 560)), 16, max_tied=24, min_with_geometry=5)
+    cin = scenes.CONFIG_CAMERAS["breakfast_interior"]
+    gpu_lib.Raylib_CameraSetPosition(ses.camera, *[float(x) for x in cin["origin"]]); gpu_lib.Raylib_CameraSetLookAt(ses.camera, *[float(x) for x in cin["look_at"]])
+    inside = ses.render(1920, 1080, 128)
+    si = ses.stats().as_dict()
+    assert si["culledCells"] == 0 and si["cameraSamples"] == 1920 * 1080 * 128 and si["texFetches"] > si["rays"] // 2 and np.isfinite(inside).all()
+    print("textured, interior: %.1f ms, %.0f Mrays/s executed, %.2f rays per camera sample, %.2f texel fetches per ray, %.1f node records and %.2f triangle records per ray" % (
+        si["traceKernelMs"], si["rays"] / si["traceKernelMs"] / 1e3, si["rays"] / si["cameraSamples"], si["texFetches"] / si["rays"], si["nodesVisited"] / si["rays"], si["trisTested"] / si["rays"]))
+    check_windows(oracle, scene, cin, 1920 / 1080, 1920, 1080, 128, inside, ((952, 536), (100, 100), (1850, 1040), (600, 300), (480, 880), (1500, 200)), 16, max_tied=24, min_with_geometry=6)
+    # the cut-outs are seen through: the same room with opaque cards (no map on the foliage material) gives another image where cards are in view
+    base = ses.render(1920, 1080, 2)
+    sb = ses.stats().as_dict()
+    for env in (dict(RAYLIB_POOL="0"), dict(RAYLIB_BVH4="0"), dict(RAYLIB_BVH8="0"), dict(RAYLIB_POOL_SHORT_STACK="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = ses.render(1920, 1080, 2)
+        so = ses.stats().as_dict()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(bits(other), bits(base)), env
+        assert so["rays"] == sb["rays"] and so["shadedHits"] == sb["shadedHits"], env
+    oracle.scene_destroy(scene)
     ses.close()
 
 
@@ -143,6 +195,36 @@ def test_config3_167k_triangles_1080p_256spp_whole_frame_and_8_rank_split(gpu_li
     scene = oracle.scene_create(flat, 1)
     check_windows(oracle, scene, cam, 1920 / 1080, 1920, 1080, 256, img, ((952, 536), (300, 700), (1500, 400), (1200, 900), (640, 300), (1700, 760)), 8,
                   max_tied=8, min_with_geometry=5)
+    oracle.scene_destroy(scene)
+    ses.close()
+
+
+def test_config4_textured_10M_triangles_with_cutout_cards_4k(gpu_lib, oracle, workdir):
+    """configs[4] size WITH textures and cut-outs ("tessellated room + instanced foliage cards with an alpha-cut-out texture"): 10 112 400 triangles,
+    2 022 991 of them cards, 3840 x 2160 -- 64 spp from outside, 16 spp from inside (every pixel geometry; the view costs an order of magnitude more per sample) --,
+    windows of both frames against the oracle."""
+    cam = scenes.CONFIG_CAMERAS["breakfast"]
+    t0 = time.time()
+    ses, flat, obj = textured_scene(gpu_lib, oracle, workdir, "c4tex", 530, cam, 3840 / 2160)
+    os.remove(obj)
+    t1 = time.time()
+    W, H = 3840, 2160
+    img = ses.render(W, H, 64)
+    st = ses.stats().as_dict()
+    print("%d triangles (%d cards): generated, written, loaded + trees in %.1f s; exterior %d x %d x 64 spp: %.1f ms, %.0f Mrays/s executed, %.2f texel fetches, %.1f node records, %.2f triangle records per ray" % (
+        len(flat.triangles), int((flat.triangles["material"] == 5).sum()), t1 - t0, W, H, st["traceKernelMs"], st["rays"] / st["traceKernelMs"] / 1e3,
+        st["texFetches"] / st["rays"], st["nodesVisited"] / st["rays"], st["trisTested"] / st["rays"]))
+    assert len(flat.triangles) == 10112400 and st["frameSamples"] == W * H * 64 and st["texFetches"] > 0 and np.isfinite(img).all() and (img[..., 3] == 1.0).all()
+    scene = oracle.scene_create(flat, 0)
+    check_windows(oracle, scene, cam, W / H, W, H, 64, img, ((1900, 1072), (1500, 900), (2300, 1500), (1700, 1300), (2100, 700)), 8, max_tied=12, min_with_geometry=4)
+    cin = scenes.CONFIG_CAMERAS["breakfast_interior"]
+    gpu_lib.Raylib_CameraSetPosition(ses.camera, *[float(x) for x in cin["origin"]]); gpu_lib.Raylib_CameraSetLookAt(ses.camera, *[float(x) for x in cin["look_at"]])
+    inside = ses.render(W, H, 16)
+    si = ses.stats().as_dict()
+    assert si["culledCells"] == 0 and si["cameraSamples"] == W * H * 16 and np.isfinite(inside).all()
+    print("interior %d x %d x 16 spp: %.1f ms, %.0f Mrays/s executed, %.2f rays per camera sample, %.2f texel fetches, %.1f node records, %.2f triangle records per ray" % (
+        W, H, si["traceKernelMs"], si["rays"] / si["traceKernelMs"] / 1e3, si["rays"] / si["cameraSamples"], si["texFetches"] / si["rays"], si["nodesVisited"] / si["rays"], si["trisTested"] / si["rays"]))
+    check_windows(oracle, scene, cin, W / H, W, H, 16, inside, ((1900, 1072), (64, 64), (3700, 2100), (1200, 600), (960, 1760)), 8, max_tied=12, min_with_geometry=5)
     oracle.scene_destroy(scene)
     ses.close()
 

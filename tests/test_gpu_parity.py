@@ -407,6 +407,11 @@ def test_bench_default_run_times_the_boundary_and_checks_the_frame():
     assert ei["workload"] == "breakfast_interior_300k_1080p_128spp" and ei["value"] > 0 and ei["scene_triangles"] == e["scene_triangles"]
     assert ei["work"]["cells_culled"] == 0 and ei["work"]["rays_accounted_not_traced_per_step"] == 0 and ei["work"]["camera_samples_executed_per_step"] == 1920 * 1080 * 128
     assert ei["frame_check"].endswith("reference-rendered windows bit-identical") and ei["roofline"]["kernel"] == "k_trace_pool"
+    # ... and with albedo maps on the walls and a fifth of the triangles as alpha-cut-out foliage cards (round 5): texels are fetched inside traversal
+    et = d["extra_textured"]
+    assert et["workload"] == "breakfast_textured_interior_300k_1080p_128spp" and et["value"] > 0 and et["scene_triangles"] == e["scene_triangles"]
+    assert et["frame_check"].endswith("reference-rendered windows bit-identical") and et["roofline"]["kernel"] == "k_trace_pool"
+    assert et["work"]["cells_culled"] == 0 and et["work"]["texel_fetches_per_ray"] > 0.5
 
 
 def test_bench_library_mode_runs_n_ranks_behind_raylib_render_or_refuses():

@@ -85,6 +85,34 @@ def test_obj_ingestion_matches_oracle_side_parser(name, lib, oracle, workdir):
     ses.close()
 
 
+def test_textured_room_generator_loader_and_checker_agree(lib, oracle, workdir):
+    """The BASELINE-size textured / alpha-cut-out room (scenes.textured: albedo maps on every wall, a fifth of the triangles as foliage cards with a cut-out map;
+    SURVEY 8d) at a small tessellation: the product's loader, the checker-side parser and the generator's own arrays (helpers.big_scene, what the full-size GPU tests
+    hand the oracle) give the same flat scene -- triangles, materials with their texture numbers, decoded texels."""
+    from raylib_amd import binding
+    d = os.path.join(str(workdir), "textured_small"); os.makedirs(d, exist_ok=True)
+    obj, n = scenes.textured(os.path.join(d, "t.obj"), tess=9, displace_fraction=0.2)
+    flat = helpers.objflat.load_obj(obj, oracle, texture_loader=helpers.texture_loader)
+    ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+    tris, mats = ses.export_flat()
+    assert len(tris) == n == 2916 and tris.tobytes() == flat.triangles.tobytes() and mats.tobytes() == flat.materials.tobytes()
+    cards = flat.triangles["material"] == [m["name"] for m in helpers.objflat.parse_mtl(obj[:-4] + ".mtl")].index("foliage")
+    assert 0.1 * n < cards.sum() < 0.3 * n                                  # at least a tenth of the triangles are cut-out cards
+    assert (flat.materials["texAlbedo"] >= 0).sum() == 4 and lib.RaylibAMD_SceneNumTextures(ses.scene) == 4
+    for i, t in enumerate(flat.textures):
+        got = np.zeros_like(t)
+        lib.RaylibAMD_SceneExportTexture(ses.scene, i, got.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(got, t)
+    leaf = scenes.foliage_texture()
+    assert set(np.unique(leaf[..., 3])) == {0, 255} and 0.3 < (leaf[..., 3] > 0).mean() < 0.7
+    ses.close()
+    d2 = os.path.join(str(workdir), "textured_small_arrays"); os.makedirs(d2, exist_ok=True)
+    obj2, flat2 = helpers.big_scene(os.path.join(d2, "t.obj"), None, scenes.TEXTURED_MTL, oracle, 9, arrays=scenes.build_arrays_textured(9, 0.2), textures=scenes.textured_textures())
+    assert open(obj2).read() == open(obj).read()                          # the checker library's fast writer prints what the Python writer prints
+    assert flat2.triangles.tobytes() == flat.triangles.tobytes() and flat2.materials.tobytes() == flat.materials.tobytes()
+    assert len(flat2.textures) == len(flat.textures) and all(np.array_equal(a, b) for a, b in zip(flat2.textures, flat.textures))
+
+
 def test_golden_scene_matches_product_loader(lib, workdir):
     """The flat scene stored in the fixtures (what the reference rendered) is what the product loads."""
     for name in helpers.CASES:
@@ -187,6 +215,53 @@ def test_larger_scenes_carry_a_valid_eight_wide_tree(lib, workdir, monkeypatch):
         assert s8.value <= gs8.value * (1 + 1e-5), (make.__name__, kw, s8.value, gs8.value)
         ses.close()
         monkeypatch.delenv("RAYLIB_WIDE_GREEDY")
+
+
+@pytest.mark.parametrize("make,kw", [(scenes.cornell, dict(tess=24, displace_fraction=0.2)), (scenes.cornell, dict(tess=64, displace_fraction=0.2)),
+                                      (scenes.soup, dict(n_tris=6000, seed=9)), (scenes.colonnade, dict(tess=3))], ids=["room_21k", "room_147k_split_leaves", "soup_6k", "colonnade_10k"])
+def test_eight_wide_walk_restated_on_the_host_never_skips_the_closest_hit(make, kw, lib, oracle, workdir):
+    """The megakernel's 8-wide walk restated on the host (RaylibAMD_SceneWalk8Host: the same float operations as rl_render.hip NodeStep8 -- half-float planes
+    through one fma each, the ray's widened factors, visiting order, groups) against the oracle's closest hit: with the exit distance fixed just behind the
+    oracle's hit the walk must reach the leaf that holds it, for rays in random directions AND for rays that lie IN the planes of the scene's walls -- second
+    generation rays from hit points towards a sun whose direction has exact zero components (+0 and -0), origins exactly on a plane, where (corner - o) * inv is
+    0 * 1e30 and the reference's slab test is all NaNs and lets the ray through (geom/aabb.h:39-54).  (Round 5 found a variant of the error bound that culled
+    exactly those rays only on the device: this test is that bug's, and runs without one.)"""
+    from raylib_amd import binding
+    d = os.path.join(str(workdir), "walk8_%s_%s" % (make.__name__, "_".join(str(v) for v in kw.values()))); os.makedirs(d, exist_ok=True)
+    obj = make(os.path.join(d, "w.obj"), **kw)[0]
+    ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+    assert lib.RaylibAMD_SceneBVH8Info(ses.scene, None, None, None, None) == 1
+    flat = helpers.objflat.load_obj(obj, oracle)
+    sc = oracle.scene_create(flat, 1)
+    lo, hi = flat.triangles["v0"].min(0), flat.triangles["v0"].max(0)
+    rng = np.random.RandomState(5)
+    n = 6000
+    o = rng.uniform(lo + 0.02 * (hi - lo), hi - 0.02 * (hi - lo), (n, 3)).astype(np.float32)
+    dd = rng.normal(size=(n, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    rays = np.concatenate([o, dd.astype(np.float32)], 1).astype(np.float32)
+    first = oracle.closest_hit(sc, rays, 1e-4)
+    p = first["p"][first["hit"] == 1][:3000]
+    groups = [("random", rays)]
+    for k, sun in enumerate(((1.0, 1.0, -0.0), (-1.0, 0.0, 1.0), (0.0, -1.0, -1.0), (1.0, 0.0, 0.0), (-0.0, -0.0, -1.0), (0.0, 1.0, -0.0))):
+        sd = np.asarray(sun, np.float32)
+        sd = np.where(sd == 0, sd, sd / np.float32(np.sqrt(float((sd * sd).sum())))).astype(np.float32)     # (keeps the signed zeros)
+        groups.append(("in-plane %d" % k, np.concatenate([p, np.repeat(sd[None], len(p), 0)], 1).astype(np.float32)))
+    for name, R in groups:
+        R = np.ascontiguousarray(R, np.float32)
+        h = oracle.closest_hit(sc, R, 1e-4)
+        hit = h["hit"] == 1
+        tmax = np.where(hit, h["t"] * np.float32(1.00002), np.float32(3.4e38)).astype(np.float32)
+        out_t = np.zeros(len(R), np.float32); steps = np.zeros(len(R), np.uint32)
+        assert lib.RaylibAMD_SceneWalk8Host(ses.scene, R.ctypes.data_as(C.POINTER(C.c_float)), len(R), 1e-4, tmax.ctypes.data_as(C.POINTER(C.c_float)),
+                                            out_t.ctypes.data_as(C.POINTER(C.c_float)), steps.ctypes.data_as(C.POINTER(C.c_uint32))) == 1
+        # (rays that graze the triangle they hit -- |n . d| tiny: the reference's float plane formula and the restatement's double-precision test can disagree about
+        #  such a hit; the box arithmetic, which is what is tested, reaches the leaf either way -- are left out)
+        grazing = np.abs((h["n"].astype(np.float64) * R[:, 3:6]).sum(1)) < 1e-3
+        missed = hit & ~grazing & ~(out_t <= h["t"] * np.float32(1.0001) + np.float32(1e-5))     # (the restatement's distances are double precision, the reference's float)
+        assert not missed.any(), "%s: the walk skipped the closest hit of %d of %d rays, e.g. %s (oracle t %s)" % (name, missed.sum(), hit.sum(), R[missed][0], h["t"][missed][0])
+        assert (name != "random" or hit.sum() > len(R) // 10) and steps.mean() >= 1
+    oracle.scene_destroy(sc)
+    ses.close()
 
 
 def test_bvh_build_is_the_same_tree_for_any_thread_count(lib, workdir, monkeypatch):
