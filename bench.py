@@ -153,7 +153,7 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None, gpus_in_
     sec = avg_launch_ms * 1e-3
     samples_per_launch = acc["samples"] / launches
     # ---- algorithmic bytes, SURVEY 8(d): a property of the WORKLOAD -- the records a tree walk of this scene fetches: 64 B per 4-wide
-    # grid-node step (a float-box step = 2 records) or 128 B per 8-wide one (the scenes deep enough to get that tree, RaylibAMDStats.treeWidth /
+    # grid-node step (a float-box step = 2 records) or 80 B per 8-wide one (the scenes deep enough to get that tree, RaylibAMDStats.treeWidth /
     # nodeBytes say which), 64 B per triangle test, 64 B per shading record, 16 B per texel and per pixel.
     # Where the kernel that ran walks something else (the Cornell class: the leaf list, every box of it per ray, from LDS), the tree-walk
     # counts come from one untimed frame with RAYLIB_LEAF_LIST=0 and the kernel's own LDS-served bytes are reported next to them.
@@ -174,7 +174,7 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None, gpus_in_
     alg_gbs = alg_bytes / sec / 1e9 if (sec > 0 and alg_bytes is not None) else None
     algorithmic = {"bytes_per_launch": alg_bytes, "bytes_per_camera_sample": None if alg_bytes is None else alg_bytes / max(1.0, samples_per_launch), "gbs": alg_gbs,
                    "frac_of_hbm_peak": None if alg_gbs is None else alg_gbs / hbm_peak, "hbm_peak_gbs": hbm_peak, "gpus": gpus_in_acc,
-                   "definition": "node bytes x node records of the tree walk (64 B on the 4-wide tree, 128 B on the 8-wide one) + 64 B x (triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran"
+                   "definition": "node bytes x node records of the tree walk (64 B on the 4-wide tree, 80 B on the 8-wide one) + 64 B x (triangle records + shading records) + 16 B x (texels + pixels): the tree walk's counts whatever schedule ran"
                                  + ("; summed over the %d ranks of this process, against %d GPUs' peak" % (gpus_in_acc, gpus_in_acc) if gpus_in_acc > 1 else ""),
                    "tree_width": acc.get("tree_width"), "node_bytes": acc.get("node_bytes"),
                    "served_elsewhere": served}
@@ -220,15 +220,34 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None, gpus_in_
                 "hw_active_inst_valu_x4_over_pass_cycles": rec.get("valu_hw_active_x4_fraction"), "hw_refined_fraction_of_pass_cycles": rec.get("valu_hw_refined_fraction"),
                 "lane_utilisation": rec.get("valu_lane_utilisation"), "wave_wait_fraction": rec.get("wave_wait_fraction"),
                 "waves_per_simd": rec.get("waves_per_simd"), "salu_insts_per_launch": rec.get("salu_insts_per_launch"),
-                "profiled_clock_ghz": rec.get("profiled_clock_ghz")}
+                "profiled_clock_ghz": rec.get("profiled_clock_ghz"),
+                # round 5: the mix weighted by the code that runs (tools/dynamic_mix.py): the loop's straight-line regions counted by a diagnostic build and priced
+                # opcode by opcode, the rest by the hardware's class counters -- a narrower band than the static mix's
+                "dynamic_mix": None if not rec.get("valu_dynamic_mix") else {
+                    "anchored_regions": rec["valu_dynamic_mix"]["anchored"]["regions"],
+                    "anchored_share_of_valu_instructions": rec["valu_dynamic_mix"]["anchored"]["share_of_valu_instructions"],
+                    "frac_of_profiled_pass_cycles": rec["valu_dynamic_mix"]["anchored"]["valu_weighted_busy_fraction"],
+                    "bounds_of_profiled_pass": rec["valu_dynamic_mix"]["anchored"]["valu_weighted_busy_bounds"],
+                    "issue_clock_budget_by_region": {r: v["share_of_valu_issue_clocks"] for r, v in rec["valu_dynamic_mix"]["regions"].items() if v["share_of_valu_issue_clocks"] >= 0.005}}}
+    # ---- the vector memory path's request rate (round 5): one access per lane and load instruction whatever the width; with the VALU port the tree walk's other ceiling
+    vmem = None
+    if rec and sec > 0 and rec.get("tcp_accesses_per_launch") and not stale:
+        clk = rec["cycles_per_launch"]
+        vmem = {"tcp_accesses_per_launch": rec["tcp_accesses_per_launch"] * share, "per_clock_and_cu_in_the_profiled_pass": rec.get("tcp_accesses_per_clock_and_cu"),
+                "ceiling_per_clock_and_cu": rec.get("tcp_request_ceiling_per_clock_and_cu"), "frac": (rec.get("tcp_accesses_per_clock_and_cu") or 0.0) / (rec.get("tcp_request_ceiling_per_clock_and_cu") or 1.0),
+                "definition": "TCP_TOTAL_CACHE_ACCESSES per clock and CU of the profiled pass over the rate a kernel of nothing but scattered 16-byte loads reaches (tools/vmem_width_bench.hip)"}
     # ---- headline: the resource nearest its roof among those measured with fresh counters; else this run's algorithmic bytes
     scaled = " -- replayed from the N = 1 passes, scaled by executed camera samples" if world > 1 else ""
     if valu and not stale and (not hbm or valu["frac_of_spec_peak"] >= hbm["frac"]):
         head = {"achieved": valu["achieved_gcyc_per_s"], "peak": valu_peak, "unit": "G SIMD-issue-cycles/s", "frac": valu["frac_of_spec_peak"], "resource": "VALU issue (class-weighted)" + scaled}
     elif hbm and not stale:
         head = {"achieved": hbm["gbs"], "peak": hbm_peak, "unit": "GB/s", "frac": hbm["frac"], "resource": "HBM (measured bytes)" + scaled}
-    elif alg_gbs is not None:
+    elif alg_gbs is not None and alg_gbs <= hbm_peak:
         head = {"achieved": alg_gbs, "peak": hbm_peak, "unit": "GB/s", "frac": alg_gbs / hbm_peak, "resource": "HBM (algorithmic bytes of the tree walk; no fresh counters)"}
+    elif alg_gbs is not None:
+        # more bytes per second than HBM can deliver: the walk's records came out of the caches -- a demand figure, not a fraction of a roof
+        head = {"achieved": alg_gbs, "peak": hbm_peak, "unit": "GB/s", "frac": None,
+                "resource": "none: the tree walk's algorithmic bytes (%.2f x the HBM peak in this time) were served by the caches, and there are no fresh counter passes for this build" % (alg_gbs / hbm_peak)}
     else:
         head = {"achieved": None, "peak": hbm_peak, "unit": "GB/s", "frac": None,
                 "resource": "none: no fresh counter passes for this build, and the kernel that ran reads its scene from LDS (its bytes are not an HBM figure)"}
@@ -246,7 +265,7 @@ def roofline_block(workload_name, acc, world, build_id, tree_walk=None, gpus_in_
     line.update(head)
     line.update({"traffic": traffic, "traffic_source": source})
     line.update(out)
-    line.update({"hbm": hbm, "valu": valu,
+    line.update({"hbm": hbm, "valu": valu, "vmem_requests": vmem,
                  "replayed_pmc": None if not rec else {"file": "profiles/pmc_traffic.json", "round": rec.get("round"), "build_id": rec.get("build_id"),
                                                        "loaded_build_id": build_id, "stale": stale, "kernel": rec.get("kernel")}})
     return line

@@ -67,9 +67,9 @@ typedef struct RaylibAMDStats {
 	uint64_t culledSamples;   /* camera samples of those cells: pixels of the culled cells x spp */
 	uint64_t culledRays;      /* queries (= root node records) those samples stand for: culledSamples x (2 with a sun, else 1) */
 	/* ---- which tree the megakernel walked ---- */
-	uint32_t treeWidth;       /* children per node: 2, 4 (64-byte grid nodes), 8 (128-byte nodes with half-float planes, octant-ordered children; scenes whose rays are expected to take
+	uint32_t treeWidth;       /* children per node: 2, 4 (64-byte grid nodes), 8 (80-byte grid nodes, octant-ordered children; scenes whose rays are expected to take
 	                             many steps, RAYLIB_BVH8=0|1 overrides) or 0 = no tree (the leaf list of a scene of few leaves) */
-	uint32_t nodeBytes;       /* bytes of one record counted in nodesVisited: 64, or 128 for the 8-wide tree */
+	uint32_t nodeBytes;       /* bytes of one record counted in nodesVisited: 64, or 80 for the 8-wide tree */
 } RaylibAMDStats;
 
 /* Seed of the per-(pixel, sample) streams of include/raylib_amd_rng.h. */
@@ -178,7 +178,7 @@ RAYLIB_API int32_t RaylibAMD_SceneBVHInfo(SceneHandle scene, uint32_t* outNodes,
 /* The 4-wide collapse of the tree that the pool schedule traverses on large scenes: 0 = the scene has none (fewer than 8 triangles, or
  * analytic primitives), 1 = present and structurally valid (every triangle once, boxes nested, stack bound holds), -1 = invalid. */
 RAYLIB_API int32_t RaylibAMD_SceneBVH4Info(SceneHandle scene, uint32_t* outNodes4, uint32_t* outWorstCaseStack);
-/* The 8-wide collapse (128-byte nodes, half-float planes, children in octant order; scenes of more than 108 triangles): 0 = none, 1 = present and valid (every triangle slot
+/* The 8-wide collapse (80-byte grid nodes, children in octant order; scenes of more than 108 triangles): 0 = none, 1 = present and valid (every triangle slot
  * reached once, every node's 8-bit grid boxes contain the triangles below them, no path longer than *outLevels), -1 = invalid.  outSteps4 / outSteps8: the sum
  * over the 4-wide / 8-wide tree's nodes of (node area / root area) -- the node steps a random ray is expected to take; the megakernel walks the 8-wide
  * tree when outSteps4 >= 40 (RAYLIB_BVH8=0|1 overrides; RaylibAMDStats.treeWidth says which tree a frame walked). */

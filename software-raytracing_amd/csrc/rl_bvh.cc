@@ -496,50 +496,11 @@ static double ExpectedSteps4(const std::vector<TmpNode>& T, int32_t root)
 	return sum;
 }
 
-// IEEE halves as bit patterns (the device reads them through v_fma_mix_f32): value of a pattern, and the nearest pattern at or below / at or above a
-// non-negative double that a half can hold (<= 65504).  Non-negative halves are ordered like their patterns.
-static double HalfValue(uint16_t h)
-{
-	const int e = (h >> 10) & 31, m = h & 1023;
-	const double v = e == 0 ? ldexp((double)m, -24) : ldexp((double)(1024 + m), e - 25);
-	return (h & 0x8000u) ? -v : v;
-}
-static uint16_t HalfAtOrBelow(double x)
-{
-	if (!(x > 0.0)) return 0;
-	if (x >= 65504.0) return 0x7bffu;
-	int ex; (void)frexp(x, &ex);                      // x = f * 2^ex, f in [0.5, 1)
-	int e = ex - 1 + 15;                              // biased exponent of the half that holds x as 1.m * 2^(ex - 1)
-	uint32_t h;
-	if (e <= 0) h = (uint32_t)floor(ldexp(x, 24));   // subnormal halves: multiples of 2^-24
-	else h = ((uint32_t)e << 10) | ((uint32_t)floor(ldexp(x, 10 - (ex - 1))) - 1024u);
-	while (h > 0 && HalfValue((uint16_t)h) > x) --h;
-	while (h < 0x7bffu && HalfValue((uint16_t)(h + 1)) <= x) ++h;
-	return (uint16_t)h;
-}
-static uint16_t HalfAtOrAbove(double x)
-{
-	if (!(x > 0.0)) return 0;
-	uint16_t h = HalfAtOrBelow(x);
-	if (HalfValue(h) < x && h < 0x7bffu) ++h;
-	return h;
-}
-
-// W + the leaf references (first triangle slot, count) -> out.nodes8 (DNode8, rl_device.h).  Every decision in double: corner + half * step is exact there, so "the
-// half-float box contains the float box" holds exactly.
-static void EmitWide8(const std::vector<TmpNode>& T, const Wide8& W, const std::vector<int32_t>& leafCode, BVH& out, int32_t root)
+// W + the leaf references (first triangle slot, count) -> out.nodes8.  Grid boxes as in QuantizeWide: every decision in double.
+static void EmitWide8(const std::vector<TmpNode>& T, const Wide8& W, const std::vector<int32_t>& leafCode, BVH& out)
 {
 	out.nodes8.assign(W.nodes.size(), DNode8());
 	out.depth8 = W.depth; out.sahNodes8 = (float)W.sah;
-	// the planes' unit: the smallest power of two of which the root's longest side is at most 2^15 (a half holds offsets up to 65504)
-	const Box& rb = T[root].box;
-	out.root8Min[0] = rb.mn.x; out.root8Min[1] = rb.mn.y; out.root8Min[2] = rb.mn.z; out.root8Max[0] = rb.mx.x; out.root8Max[1] = rb.mx.y; out.root8Max[2] = rb.mx.z;
-	double longest = 0.0;
-	for (int a = 0; a < 3; ++a) longest = std::max(longest, (double)axisOf(rb.mx, a) - (double)axisOf(rb.mn, a));
-	int se = -100;
-	if (longest > 0.0) { int x; (void)frexp(longest / 32768.0, &x); se = std::max(-100, std::min(100, x)); }   // 2^x >= longest / 2^15
-	const double step = ldexp(1.0, se);
-	out.step8 = (float)step;
 	auto run = [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) {
 		const Wide8Node& w = W.nodes[i];
 		DNode8 n; memset(&n, 0, sizeof(n));
@@ -552,24 +513,31 @@ static void EmitWide8(const std::vector<TmpNode>& T, const Wide8& W, const std::
 			leafMask |= ((1u << count) - 1u) << (4 * c);
 			if (!haveTri) { triBase = first; haveTri = true; }
 		}
+		uint32_t exps[3] = { 0, 0, 0 };
 		for (int a = 0; a < 3; ++a) {
 			float lo = FLT_MAX, hi = -FLT_MAX;
 			for (int c = 0; c < 8; ++c) if (w.kid[c] >= 0) { lo = std::min(lo, axisOf(T[w.kid[c]].box.mn, a)); hi = std::max(hi, axisOf(T[w.kid[c]].box.mx, a)); }
 			if (!(lo <= hi)) { lo = hi = 0.0f; }
 			n.origin[a] = lo;
+			const double extent = (double)hi - (double)lo;
+			int e = 1;
+			if (extent > 0.0) { int x; (void)frexp(extent / 255.0, &x); e = std::max(1, std::min(254, x + 127)); }
+			double step = ldexp(1.0, e - 127);
+			while (255.0 * step < extent && e < 254) { ++e; step *= 2.0; }
+			exps[a] = (uint32_t)e;
 			for (int c = 0; c < 8; ++c) {
-				if (w.kid[c] < 0) { n.lo[a][c] = RL_NODE8_EMPTY_LO; n.hi[a][c] = RL_NODE8_EMPTY_HI; continue; }   // inverted
+				if (w.kid[c] < 0) { n.qlo[a][c >> 2] |= 255u << (8 * (c & 3)); continue; }   // inverted: lower 255, upper 0
 				const double blo = axisOf(T[w.kid[c]].box.mn, a), bhi = axisOf(T[w.kid[c]].box.mx, a);
-				uint16_t l = HalfAtOrBelow((blo - (double)lo) / step), h = HalfAtOrAbove((bhi - (double)lo) / step);
-				while (l > 0 && (double)lo + HalfValue(l) * step > blo) --l;
-				while (h < 0x7bffu && (double)lo + HalfValue(h) * step < bhi) ++h;
-				n.lo[a][c] = l; n.hi[a][c] = h;
+				double l = floor((blo - (double)lo) / step), h = ceil((bhi - (double)lo) / step);
+				l = std::max(0.0, std::min(255.0, l)); h = std::max(0.0, std::min(255.0, h));
+				while (l > 0.0 && (double)lo + l * step > blo) l -= 1.0;
+				while (h < 255.0 && (double)lo + h * step < bhi) h += 1.0;
+				n.qlo[a][c >> 2] |= (uint32_t)l << (8 * (c & 3));
+				n.qhi[a][c >> 2] |= (uint32_t)h << (8 * (c & 3));
 			}
 		}
-		uint16_t ext[3] = { 0, 0, 0 };   // the node's extent per axis in plane units: the largest upper plane (non-negative halves are ordered like their patterns)
-		for (int a = 0; a < 3; ++a) for (int c = 0; c < 8; ++c) if (w.kid[c] >= 0) ext[a] = std::max(ext[a], n.hi[a][c]);
-		n.meta = imask | ((uint32_t)ext[0] << 16);   // (the alpha flags, bits 8 - 15, are set when the scene's materials are known: rl_scene.cc)
-		n.childBase = w.firstChild; n.triBase = triBase; n.leafMask = leafMask; n.extentYZ = (uint32_t)ext[1] | ((uint32_t)ext[2] << 16);
+		n.meta = exps[0] | (exps[1] << 8) | (exps[2] << 16) | (imask << 24);
+		n.childBase = w.firstChild; n.triBase = triBase; n.leafMask = leafMask; n.alphaMask = 0;
 		out.nodes8[i] = n;
 	} };
 	const size_t n = W.nodes.size();
@@ -733,7 +701,7 @@ void BuildBVH(const std::vector<PrimRef>& prims, BVH& out, const BVHBuildOptions
 	// Starting from a node's two children, the inner child with the largest surface area is replaced by its own two
 	// children until there are four (or only leaves).  Only for scenes the pool schedule can run (triangles only, not tiny).
 	if (wideTrees) {
-		if (wide8) EmitWide8(T, W8, leafCode, out, root);
+		if (wide8) EmitWide8(T, W8, leafCode, out);
 		struct Item { int32_t tmp; int32_t slot; uint32_t need; };   // a BVH2 inner node that becomes wide node `slot`
 		std::vector<Item> work;
 		out.nodes4.clear();
@@ -960,12 +928,11 @@ bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
 	struct Frame { uint32_t node; int child; double lo[3], hi[3]; double clo[3], chi[3]; };   // lo / hi: bounds of what has been seen below this node so far; clo / chi: ... below the child being walked
 	// iterative post-order: for every node, the bounds of the triangles below each child are checked against that child's grid box
 	std::vector<Frame> st;
-	const double step = (double)bvh.step8;
-	{ int x; if (!(step > 0.0) || frexp(step, &x) != 0.5) return false; }   // a power of two
 	auto gridBox = [&](const DNode8& n, int c, double* lo, double* hi) {
 		for (int a = 0; a < 3; ++a) {
-			lo[a] = (double)n.origin[a] + HalfValue(n.lo[a][c]) * step;
-			hi[a] = (double)n.origin[a] + HalfValue(n.hi[a][c]) * step;
+			const double step = ldexp(1.0, (int)((n.meta >> (8 * a)) & 255u) - 127);
+			lo[a] = (double)n.origin[a] + (double)((n.qlo[a][c >> 2] >> (8 * (c & 3))) & 255u) * step;
+			hi[a] = (double)n.origin[a] + (double)((n.qhi[a][c >> 2] >> (8 * (c & 3))) & 255u) * step;
 		}
 	};
 	Frame f0; f0.node = 0; f0.child = -1; for (int a = 0; a < 3; ++a) { f0.lo[a] = 1e300; f0.hi[a] = -1e300; }
@@ -976,7 +943,7 @@ bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
 		depth = std::max<uint32_t>(depth, (uint32_t)st.size());
 		if (F.node >= bvh.nodes8.size()) return false;
 		const DNode8& n = bvh.nodes8[F.node];
-		const uint32_t imask = n.meta & 255u;
+		const uint32_t imask = n.meta >> 24;
 		if (++F.child >= 8) {
 			// done: hand this node's bounds to the parent's current child
 			const Frame done = F; st.pop_back();
@@ -1001,7 +968,7 @@ bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
 			continue;
 		}
 		if (!nib) {   // unused: the inverted box
-			for (int a = 0; a < 3; ++a) if (n.lo[a][c] != RL_NODE8_EMPTY_LO || n.hi[a][c] != RL_NODE8_EMPTY_HI) return false;
+			for (int a = 0; a < 3; ++a) if (((n.qlo[a][c >> 2] >> (8 * (c & 3))) & 255u) != 255u || ((n.qhi[a][c >> 2] >> (8 * (c & 3))) & 255u) != 0u) return false;
 			continue;
 		}
 		if (nib != 1u && nib != 3u && nib != 7u && nib != 15u) return false;
@@ -1024,42 +991,25 @@ bool ValidateBVH8(const BVH& bvh, const std::vector<HostTriangle>& tris)
 		}
 	}
 	for (uint8_t v : seen) if (!v) return false;
-	// the extents a far plane's allowance is taken from: the largest upper plane of the node's children per axis
-	for (const DNode8& n : bvh.nodes8) for (int a = 0; a < 3; ++a) {
-		uint16_t e = 0;
-		for (int c = 0; c < 8; ++c) if (n.hi[a][c] != RL_NODE8_EMPTY_HI) e = std::max(e, n.hi[a][c]);
-		if (e != (uint16_t)(a == 0 ? n.meta >> 16 : (a == 1 ? n.extentYZ & 0xffffu : n.extentYZ >> 16))) return false;
-	}
-	// every corner and every plane of the tree within the root's box grown by a thousandth
-	for (const DNode8& n : bvh.nodes8) for (int a = 0; a < 3; ++a) {
-		const double span = (double)bvh.root8Max[a] - (double)bvh.root8Min[a], slack = 1e-3 * span + 1e-30;
-		if ((double)n.origin[a] < (double)bvh.root8Min[a] - slack) return false;
-		for (int c = 0; c < 8; ++c) if (n.hi[a][c] != RL_NODE8_EMPTY_HI && (double)n.origin[a] + HalfValue(n.hi[a][c]) * step > (double)bvh.root8Max[a] + slack) return false;
-	}
 	return depth <= bvh.depth8;
 }
 
-// The 8-wide walk of rl_render.hip (NodeStep8 / LeafStep8) on the host, operation by operation in float -- the ray's widened factors, one fma per plane, the
-// negated entry distance, the sign of fma(exit, widen, -entry), groups of hit children in visiting order, the stack of groups -- with the exit distance fixed at
-// tMax[i] and every triangle of every leaf child reached tested by a tolerant double-precision test: outT[i] = the least distance among them (FLT_MAX: none).  What
-// the box arithmetic must never do is skip the leaf that holds the closest hit; tests compare outT with the oracle's closest hit on the same rays without a GPU
-// (tests/test_host_logic.py).  outSteps (optional): node steps taken.
+// The 8-wide walk of rl_render.hip (NodeStep8 / LeafStep8) on the host, operation by operation in float -- A = step * inv and B = (corner - o) * inv per axis, the
+// rounding bound E = (|B| + 255 |A|) 2^-21, one fma per 8-bit plane, the NEGATED entry distance, the sign of fma(exit, widen, -entry), groups of hit children in
+// visiting order, the stack of groups -- with the exit distance fixed at tMax[i] and every triangle of every leaf child reached tested by a tolerant
+// double-precision test: outT[i] = the least distance among them (FLT_MAX: none).  What the box arithmetic must never do is skip the leaf that holds the closest
+// hit; tests compare outT with the oracle's closest hit on the same rays without a GPU (tests/test_host_logic.py).  outSteps (optional): node steps taken.
 bool Walk8Host(const BVH& bvh, const std::vector<HostTriangle>& tris, const float* rays, int n, float tMin, const float* tMax, float* outT, uint32_t* outSteps)
 {
 	if (bvh.nodes8.empty()) return false;
-	const float widen = 1.00001f, c21 = 4.76837158e-7f;
+	const float widen = 1.00001f;
 	auto clampInv = [](float x) { return std::isinf(x) ? copysignf(1e30f, x) : x; };
+	auto plane = [](const uint32_t q[2], int c) { return (float)((q[c >> 2] >> (8 * (c & 3))) & 255u); };
 	for (int r = 0; r < n; ++r) {
 		const float* ray = rays + 6 * (size_t)r;
 		const float o[3] = { ray[0], ray[1], ray[2] }, d[3] = { ray[3], ray[4], ray[5] };
-		float inv[3], a8n[3], a8f[3], ac8[3]; uint32_t nearHi[3]; uint32_t oct = 0;
-		for (int a = 0; a < 3; ++a) {
-			inv[a] = clampInv(1.0f / d[a]);
-			const float A = bvh.step8 * inv[a], Ac = fabsf(A) * c21;
-			a8n[a] = A - Ac; a8f[a] = A + Ac; ac8[a] = Ac;
-			nearHi[a] = inv[a] < 0.0f ? 1u : 0u;
-			if (!(inv[a] < 0.0f)) oct |= 1u << a;
-		}
+		float inv[3]; bool neg[3]; uint32_t oct = 0;
+		for (int a = 0; a < 3; ++a) { inv[a] = clampInv(1.0f / d[a]); neg[a] = inv[a] < 0.0f; if (!neg[a]) oct |= 1u << a; }
 		const float ntMin = -tMin, tmx = std::min(tMax[r], FLT_MAX);
 		std::vector<std::pair<uint32_t, uint32_t>> stack;
 		uint32_t gx = 0, gy = (1u << (24 + oct)) | 1u, steps = 0;
@@ -1074,28 +1024,23 @@ bool Walk8Host(const BVH& bvh, const std::vector<HostTriangle>& tris, const floa
 			if (node >= bvh.nodes8.size() || stack.size() > 64) return false;
 			const DNode8& nd = bvh.nodes8[node];
 			++steps;
-			float nB[3], Bf[3];
+			float A[3], nB[3], Bf[3];
 			for (int a = 0; a < 3; ++a) {
+				uint32_t sb = ((nd.meta >> (8 * a)) & 255u) << 23; float st; memcpy(&st, &sb, 4);
+				A[a] = st * inv[a];
 				const float B = (nd.origin[a] - o[a]) * inv[a];
-				const float ext = (float)HalfValue((uint16_t)(a == 0 ? nd.meta >> 16 : (a == 1 ? nd.extentYZ & 0xffffu : nd.extentYZ >> 16)));
-				nB[a] = fmaf(fabsf(B), c21, -B); Bf[a] = fmaf(ext, ac8[a], fmaf(fabsf(B), c21, B));
+				const float E = fabsf(A[a] * 1.21593475e-4f) + fabsf(B * 4.76837158e-7f);
+				nB[a] = E - B; Bf[a] = B + E;
 			}
 			uint32_t hit = 0;
-			const uint32_t imask = nd.meta & 255u;
+			const uint32_t imask = nd.meta >> 24;
 			for (int ch = 0; ch < 8; ++ch) {
 				float ntn = ntMin, tf = tmx;
 				for (int a = 0; a < 3; ++a) {
-					const float hn = (float)HalfValue(nearHi[a] ? nd.hi[a][ch] : nd.lo[a][ch]), hf = (float)HalfValue(nearHi[a] ? nd.lo[a][ch] : nd.hi[a][ch]);
-					ntn = std::min(ntn, fmaf(hn, -a8n[a], nB[a])); tf = std::min(tf, fmaf(hf, a8f[a], Bf[a]));
+					const float qn = plane(neg[a] ? nd.qhi[a] : nd.qlo[a], ch), qf = plane(neg[a] ? nd.qlo[a] : nd.qhi[a], ch);
+					ntn = std::min(ntn, fmaf(qn, -A[a], nB[a])); tf = std::min(tf, fmaf(qf, A[a], Bf[a]));
 				}
 				if (!std::signbit(fmaf(tf, widen, ntn))) hit |= 1u << ch;
-				if (getenv("RAYLIB_WALK8_TRACE")) {
-					float pn[3], pf[3];
-					for (int a = 0; a < 3; ++a) { const float hn = (float)HalfValue(nearHi[a] ? nd.hi[a][ch] : nd.lo[a][ch]), hf = (float)HalfValue(nearHi[a] ? nd.lo[a][ch] : nd.hi[a][ch]); pn[a] = -fmaf(hn, -a8n[a], nB[a]); pf[a] = fmaf(hf, a8f[a], Bf[a]); }
-					fprintf(stderr, "  node %u child %d %s: near %.6g %.6g %.6g far %.6g %.6g %.6g  box x[%.9g %.9g] y[%.9g %.9g] z[%.9g %.9g] %s\n", node, ch, ((imask >> ch) & 1u) ? "inner" : (((nd.leafMask >> (4 * ch)) & 15u) ? "leaf" : "empty"),
-					        pn[0], pn[1], pn[2], pf[0], pf[1], pf[2], nd.origin[0] + HalfValue(nd.lo[0][ch]) * bvh.step8, nd.origin[0] + HalfValue(nd.hi[0][ch]) * bvh.step8, nd.origin[1] + HalfValue(nd.lo[1][ch]) * bvh.step8, nd.origin[1] + HalfValue(nd.hi[1][ch]) * bvh.step8,
-					        nd.origin[2] + HalfValue(nd.lo[2][ch]) * bvh.step8, nd.origin[2] + HalfValue(nd.hi[2][ch]) * bvh.step8, ((hit >> ch) & 1u) ? "HIT" : "culled");
-				}
 			}
 			uint32_t innerP = 0;
 			for (uint32_t b = 0; b < 8u; ++b) if (((hit & imask) >> b) & 1u) innerP |= 1u << (b ^ oct);

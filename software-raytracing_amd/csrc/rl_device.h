@@ -50,54 +50,48 @@ struct alignas(64) DNode4Q {
 	int32_t child[4];
 };
 static_assert(sizeof(DNode4Q) == 64, "DNode4Q");
-// The 8-wide node, 128 bytes = ONE cache line = eight 16-byte rows (round 5; round 4's node was 80 bytes on an 8-bit grid).
-// The tree walk of a large scene is a chain of dependent steps -- fetch a node, test its boxes, fetch the next -- and since the 8-wide tree made the chain short
-// enough the kernel sits on the VALU issue port: what a step costs there is what it costs the frame.  The 8-bit planes cost a v_cvt_f32_ubyte
-// (4 issue clocks) AND a v_fma_f32 (2) each, 48 planes a step, plus twelve selects for near / far, three exponent decodes and the per-node error terms.  Here:
-//   * planes are IEEE halves: the offset of the plane from the node's minimum corner in units of ONE power-of-two step for the whole scene (DSceneView::step8:
-//     the root's longest side is <= 2^15 steps), lower planes rounded DOWN to a half, upper planes UP (rl_bvh.cc EmitWide8; every decision in double) -- 11
-//     significant bits relative to the offset, i.e. a box at most 2^-11 of its own distance from the corner larger than the float box (the 8-bit grid: 1 / 255 of
-//     the NODE).  A plane enters the slab arithmetic through ONE v_fma_mix_f32 (4 clocks: conversion and fma in f32, t = half * (step8 * inv) + (corner - o) * inv),
-//     and step8 * inv is a constant of the ray, not of the node;
-//   * rows: 0 = corner (3 floats), meta; 1 - 3 = lower planes of x, y, z (eight halves each, child c = half c); 4 = childBase, triBase, leafMask; 5 - 7 = upper
-//     planes of x, y, z.  The row of an axis' upper planes is the row of its lower planes XOR 64 bytes: a ray adds ITS near-row offsets (16 / 32 / 48, + 64 where it
-//     travels in the negative direction) to the node's address and flips bit 6 for the far rows -- no select anywhere;
-//   * an unused child is the inverted box: lower planes +65504, upper planes -65504 (the largest halves), which no ray enters;
+// The 8-wide grid node, 80 bytes = five 16-byte loads (round 4).  The tree walk of a large scene is a chain of dependent steps -- fetch a node (about a
+// microsecond under load), test its boxes, fetch the next -- of which a SIMD keeps four in flight: fewer loads per step, fuller turns of
+// the vote and cheaper pops did not shorten it; FEWER STEPS do.  Eight children per node: 0.6 x the steps of the 4-wide tree.
+//   * boxes as in DNode4Q: the node's minimum corner as three floats, a power-of-two step per axis (here as biased exponents, one byte each), 8-bit planes
+//     (byte c of qlo[a][c >> 2] / qhi[a][c >> 2] = child c); an unused child has the inverted box lo 255 / hi 0, which no ray enters;
 //   * children are NOT named one by one: the inner children of a node are consecutive nodes (childBase + rank among the inner children, in slot order:
 //     imask bit c = child c is an inner node), the triangles of its leaf children are consecutive triangle slots (triBase + rank among the bits of leafMask,
 //     whose nibble c holds as many low bits as leaf child c has triangles, <= 4) -- so a traversal keeps the hit children of a node as ONE stack entry
 //     (base, hit bits) however many they are, and needs no sort: children sit in the slot whose three bits say on which side of the node they lie
 //     (bit 0: +x, bit 1: +y, bit 2: +z; the builder assigns them greedily), and a ray visits the slots in the order slot XOR (signs of its direction)
 //     (Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", HPG 2017 -- the layout idea; the arithmetic here
-//     is this library's: exact-corner boxes, the candidate rule, the tie rule);
+//     is this library's: exact-corner grid boxes, the candidate rule, the tie rule);
 //   * alphaMask bit c = leaf child c holds a triangle whose material is alpha-tested (the cut-out test runs inside traversal, DNode's flag).
-#define RL_NODE8_ROW_LO 16u      /* byte offset of the lower planes of x; y and z follow at + 16, + 32; the upper planes at these XOR 64 */
-#define RL_NODE8_EMPTY_LO 0x7bffu   /* +65504 */
-#define RL_NODE8_EMPTY_HI 0xfbffu   /* -65504 */
-#define RL_POOL8_MAXLEVELS 16    /* levels of an 8-wide tree the pool kernel's stack of groups holds (k_trace_pool<2 * this, ..., 3>; rl_runtime.inl selects the walk only then) */
-// The top of the 8-wide tree lives in LDS (rl_render.hip k_trace_pool, NodeStep8): nodes are numbered breadth first, so the first RL_TOP8_NODES of them are the
-// levels every ray starts with -- 23 % of all node steps on the 298 k-triangle room, 10 % on the 10 M-triangle one (diagnostic build -DRL_DIAG_TOPN) -- and a step on
-// one of them costs the vector memory path nothing: that path takes one clock per lane and load instruction whatever the width (tools/vmem_width_bench.hip),
-// eight per step of this node, and with them the walk sits on it as it sat on the VALU port with round 4's node.  71 nodes = 9 088 bytes: what four workgroups
-// per CU leave of the 160 KB once the LDS part of the stack is RL_POOL8_LSTACK words (four groups: 99.6 % / 94.5 % of the steps of the two scenes never hold more).
-#ifndef RL_TOP8_NODES
-#define RL_TOP8_NODES 71
-#endif
-#ifndef RL_POOL8_LSTACK
-#define RL_POOL8_LSTACK 8
-#endif
-struct alignas(128) DNode8 {
+// Round 5 built and measured the other end of the trade (git 530c313: a 128-byte node of half-float planes, one v_fma_mix_f32 per plane -- 4 issue clocks where a byte
+// costs v_cvt_f32_ubyte + v_fma_f32 = 6 -- near / far rows by XOR, the ray's own factors: 169 VALU instructions per step where this node takes 248): the vector memory
+// path charges a wave one clock per lane and LOAD INSTRUCTION whatever its width (tools/vmem_width_bench.hip: 0.88 clocks, dword or dwordx4; four lanes of a quad
+// on one address count once), eight loads per step put the walk on that path's ceiling (TCP_TOTAL_CACHE_ACCESSES 1.05 per clock and CU of 1.14) as the 248
+// instructions had it on the VALU port's, and the frames came out - 2 % (298 k triangles), + 8 % (2.36 M), + 17 % (10.1 M).  Five loads and bytes stay.
+struct alignas(16) DNode8 {
 	float origin[3];
-	uint32_t meta;        // imask | alphaMask << 8 | extent of the node along x << 16
-	uint16_t lo[3][8];    // IEEE half bit patterns
+	uint32_t meta;        // ex | ey << 8 | ez << 16 (biased exponents of the steps) | imask << 24
 	uint32_t childBase;   // node index of the first inner child
 	uint32_t triBase;     // triangle slot of the first triangle of the first leaf child
 	uint32_t leafMask;    // nibble c: (1 << count) - 1 for leaf child c, else 0
-	uint32_t extentYZ;    // extent along y | extent along z << 16.  The extents are halves too: the largest upper plane of the node's children per axis (0 for a node
-	                      // that is flat there) -- what a far plane is allowed on top of its own rounding (rl_render.hip NodeStep8)
-	uint16_t hi[3][8];
+	uint32_t alphaMask;   // bit c (c < 8)
+	uint32_t qlo[3][2], qhi[3][2];
 };
-static_assert(sizeof(DNode8) == 128, "DNode8");
+static_assert(sizeof(DNode8) == 80, "DNode8");
+#define RL_POOL8_MAXLEVELS 16    /* levels of an 8-wide tree the pool kernel's stack of groups holds (k_trace_pool<2 * this, ..., 3>; rl_runtime.inl selects the walk only then) */
+// An LDS copy of the top of the 8-wide tree (round 5, measured and not kept: RL_TOP8_NODES > 0 builds it).  Nodes are numbered breadth first, so the first N of them
+// are the levels every ray starts with -- 23 % of all node steps on the 298 k-triangle room for N = 73, 10 % on the 10 M-triangle one (diagnostic build
+// -DRL_DIAG_TOPN) -- and a step on one of them costs the vector memory path nothing (ds_read_b128 instead of global_load_dwordx4) and waits for no cache.  Four
+// workgroups per CU leave room for it only if the LDS part of the stack shrinks from eight groups to four (RL_POOL8_LSTACK 8: 113 nodes of 80 bytes); the 298 k
+// room never holds more than four groups in 99.6 % of its steps, the 10 M room in 94.5 % -- and there a pop from the private overflow is one more trip to memory
+// in the chain.  With this node (the walk sits on the VALU port, not on memory): 298 k room 90.4 ms with and without the copy, 2.36 M + 2.7 %, 10.1 M + 7.8 %.
+// (With the 128-byte half-float node, which sits on the vector memory path: 93.9 -> 90.1 ms.)
+#ifndef RL_TOP8_NODES
+#define RL_TOP8_NODES 0
+#endif
+#ifndef RL_POOL8_LSTACK
+#define RL_POOL8_LSTACK 16       /* words of the 8-wide walk's stack that live in LDS: two per group */
+#endif
 // which of the two the POOL schedule walks (a build-time switch so that both can be timed: make variant EXTRA=-DRL_Q4=0);
 // k_trace has both as instantiations and takes the float boxes whenever the scene carries them
 #ifndef RL_Q4
@@ -180,7 +174,6 @@ struct DSceneView {
 	const DNode4Q* nodes4;     // the wide tree on the 8-bit grid: what the pool schedule walks (nullptr: the scene has none)
 	const DNode4* nodes4f;     // the wide tree with float boxes: uploaded for small, cache-resident scenes (k_trace), where the grid saves nothing
 	const DNode8* nodes8;      // the 8-wide tree (the pool schedule's default when the scene carries one; nullptr: none)
-	float step8;               // its planes' unit: a power of two, the root's longest side <= 2^15 of it (DNode8)
 	int32_t numNodes8;
 	const DTriIsect* isect;
 	const DTriShade* shade;

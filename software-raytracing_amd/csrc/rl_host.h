@@ -117,8 +117,6 @@ struct BVH {
 	uint32_t stackNeed4 = 0;          // worst-case traversal-stack entries of nodes4 (sum of children - 1 along the deepest path)
 	std::vector<DNode8> nodes8;       // the 8-wide tree (DNode8, rl_device.h); its leaves are the BVH2's leaves, and the order of the triangle slots is ITS order (a node's leaf children hold consecutive slots)
 	uint32_t depth8 = 0;              // levels of nodes8: a traversal's stack holds at most one entry (the rest of a node's hit children) per level
-	float step8 = 1.0f;               // the unit of nodes8's half-float planes: a power of two, the root's longest side <= 2^15 of it
-	float root8Min[3] = { 0, 0, 0 }, root8Max[3] = { 0, 0, 0 };   // the root's box (bounds every corner and plane of nodes8)
 	float sahNodes4 = 0.0f, sahNodes8 = 0.0f;   // sum over the wide tree's nodes of (node's surface area / root's): the expected node steps of a random ray through either tree
 	std::vector<DNode4> leafList;     // scenes of <= 4 * RL_LEAFLIST_RECORDS leaves: every leaf's box, four to a record, no inner nodes (k_trace's flat walk; empty otherwise)
 	std::vector<uint32_t> triOrder;   // leaf order -> index into the flat triangle array
@@ -134,7 +132,9 @@ struct PrimRef { f3 mn, mx; uint8_t kind; uint32_t index; };
 // splitLeaves8: give every leaf of a scene whose rays are expected to take >= minSteps8 node steps on the 4-wide tree (the scenes that walk the 8-wide tree by
 // default) a split of its triangles for the 8-wide plan to open in otherwise empty slots (rl_bvh.cc SplitLeaves); triCost8: what an expected triangle test
 // weighs against an expected node step in that plan.
-struct BVHBuildOptions { bool wideGreedy = false; bool splitLeaves8 = true; float triCost8 = 0.5f; float minSteps8 = 40.0f; };
+// (Round 5, measured: triangle tests per ray 2.26 -> 1.96 ... 2.03 on the 298 k room whatever triCost8 between 0.25 and 2, no frame gets shorter -- the triangle steps
+//  are a twelfth of the walk --, and the binary and 4-wide trees, emitted from the same nodes, gain a level or two: off unless RAYLIB_W8_SPLIT=1 asks for it.)
+struct BVHBuildOptions { bool wideGreedy = false; bool splitLeaves8 = false; float triCost8 = 0.5f; float minSteps8 = 40.0f; };
 void BuildBVH(const std::vector<PrimRef>& prims, BVH& out, const BVHBuildOptions& opt = BVHBuildOptions());
 bool BVHCapacityOk(size_t numPrimitives);   // a leaf reference addresses 2^25 primitive slots
 bool ValidateBVH(const BVH& bvh, const std::vector<HostTriangle>& tris);

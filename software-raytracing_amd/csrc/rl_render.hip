@@ -1937,14 +1937,8 @@ struct Trav {
 	// in VISITING order (bit 24 + (slot XOR oct), highest first) | the node's alphaMask << 8 | its imask --; the triangles of its hit leaf children still to be tested:
 	// tx the node's triBase, tz its leafMask, ty the bits of tz that are left; oct: bit 0 / 1 / 2 set when the ray travels towards +x / +y / +z
 	uint32_t gx, gy, tx, ty, tz, oct;
-	// ... and what a ray brings to every node of that tree (NodeStep8): a8n / a8f = step8 * inv (a plane's half times this is its distance along the ray from the
-	// node's corner) moved by 2^-21 of itself towards earlier (near planes) / later (far planes), off8 = the byte offsets of the ray's NEAR plane rows in a node
-	// (DNode8: x 16, y 32, z 48, + 64 where the ray travels in the negative direction; the far rows are these XOR 64)
-	// ac8 = |step8 * inv| 2^-21: times the node's extent along the axis, what a far plane is moved later by on top of that (a ray that lies IN a far plane -- a sun ray
-	// leaving a wall, its direction with a zero component -- has B = 0 and a plane offset 0 there: no rounding to bound, and the slab would end at 0 where the reference's
-	// NaN-ignoring test (geom/aabb.h:39-54) lets the ray through; in a node that is FLAT along the axis the allowance is 0 and such a ray stays out of its boxes,
-	// whose triangles it could only meet at 0 / 0: round 4's (|B| + 255 |A|) 2^-21 had both properties through the node's own grid step)
-	V3 a8n, a8f, ac8; uint32_t off8x, off8y, off8z;
+	// ... and per axis all ones where the ray travels in the negative direction (NodeStep8 selects a node's near / far planes with them)
+	uint32_t m8x, m8y, m8z;
 };
 
 // Single steps on the resumable state, for the vote-driven loop of k_trace_pool: a lane is either at an inner node
@@ -2085,10 +2079,9 @@ __device__ __forceinline__ bool LeafStep(const DSceneView& S, Trav& T, float tMi
 // A lane's state is (T.gx, T.gy): the group of hit inner children it is working through, (T.tx, T.ty, T.tz): the triangles of hit leaf children it still has
 // to test, and a stack of groups (two words each: the LDS stack's entries pairwise, then the private overflow).  T.cur only says which party of the vote the
 // lane belongs to: 0 at a node (a group with a child left), -1 at a leaf (a triangle left), TRAV-idle without a ray.  One node step = take the group's next
-// child in visiting order, push the rest of the group (ONE entry however many children it holds), fetch the child (eight 16-byte loads: ONE cache line), test
-// its eight boxes, and turn the hits into the next group and the next triangles -- no sort, no per-child pushes.  The triangles of a node's leaf children are
-// tested before any of its inner children is entered (they are the geometry nearest to hand); the order of two candidates never decides a hit (candidate rule,
-// tie rule).
+// child in visiting order, push the rest of the group (ONE entry however many children it holds), fetch the child (five 16-byte loads), test its eight boxes,
+// and turn the hits into the next group and the next triangles -- no sort, no per-child pushes.  The triangles of a node's leaf children are tested before any
+// of its inner children is entered (they are the geometry nearest to hand); the order of two candidates never decides a hit (candidate rule, tie rule).
 // T.gy = the group's bits in VISITING order (bit 24 + (slot XOR oct), highest first) | the node's imask; T.ty = the hit leaf children (bits 0 - 7, slot order) |
 // the next triangle of the lowest of them (bits 8 - 9) | the node's alphaMask << 16; T.tx / T.tz = the node's triBase / leafMask.
 __device__ __forceinline__ void Push8(Trav& T, int* stk, int* ovf, const int G, const int GMAX)
@@ -2108,45 +2101,34 @@ __device__ __forceinline__ bool Next8(Trav& T, int* stk, int* ovf, const int G)
 	T.cur = 0;
 	return false;
 }
-// A ray's constants for this walk (Trav::a8n, a8f, off8*), once per ray.  The planes of a node are halves h >= 0: offsets from the node's corner in units of S.step8, so
-// plane h's distance along the ray is fma(h, step8 * inv, (corner - o) * inv) = h A + B: ONE v_fma_mix_f32 per plane, no conversion, and A belongs to the ray.
-// The fused form rounds differently from the reference's (bound - o) * inv (geom/aabb.h:39-54), in absolute terms by at most (|B| + |h A|) 2^-23 (cancellation when
-// the ray starts inside the node); four times that bound widens every slab, near planes earlier, far planes later -- a box test only has to be conservative (the
-// candidate rule decides what counts as a hit).  Round 4 worked (|B| + 255 |A|) 2^-21 out per node; here the two parts go where they cost least: A -/+ |A| 2^-21
-// are the ray's two factors (h >= 0, so h (A + |A| c) = h A + |h A| c), and B -/+ |B| 2^-21 are one fma each per node and axis.  (The bound has to follow |B|: a
-// sun ray that leaves a wall lies IN the wall's plane, one ulp off it; with B's own rounding as the measure the wall's flat boxes stay culled for it, with a bound
-// taken from the scene's size -- measured -- it enters every one of them and the triangle tests per ray go from 2.3 to 3.9.)
-__device__ __forceinline__ void RaySetup8(const DSceneView& S, Trav& T)
+// a ray's constants for this walk: the octant (visiting order = slot XOR oct) and, per axis, all ones where the ray travels in the negative direction -- the
+// near planes of a node are then (upper & m) | (lower & ~m): one v_bitop3_b32, 2 issue clocks, where a v_cndmask on a lane mask in SGPRs takes 4
+__device__ __forceinline__ void RaySetup8(Trav& T)
 {
-	const V3 A = v3(S.step8 * T.inv.x, S.step8 * T.inv.y, S.step8 * T.inv.z);
-	const V3 Ac = v3(fabsf(A.x) * 4.76837158e-7f, fabsf(A.y) * 4.76837158e-7f, fabsf(A.z) * 4.76837158e-7f);   // 2^-21
-	T.a8n = A - Ac; T.a8f = A + Ac; T.ac8 = Ac;
-	T.off8x = RL_NODE8_ROW_LO + (T.inv.x < 0.0f ? 64u : 0u);
-	T.off8y = RL_NODE8_ROW_LO + 16u + (T.inv.y < 0.0f ? 64u : 0u);
-	T.off8z = RL_NODE8_ROW_LO + 32u + (T.inv.z < 0.0f ? 64u : 0u);
+	T.m8x = T.inv.x < 0.0f ? 0xffffffffu : 0u; T.m8y = T.inv.y < 0.0f ? 0xffffffffu : 0u; T.m8z = T.inv.z < 0.0f ? 0xffffffffu : 0u;
 	T.oct = (T.inv.x < 0.0f ? 0u : 1u) | (T.inv.y < 0.0f ? 0u : 2u) | (T.inv.z < 0.0f ? 0u : 4u);
 }
-typedef _Float16 rl_h2 __attribute__((ext_vector_type(2)));
-// One child: six planes (word w of a row holds the halves of children 2w and 2w + 1), the NEGATED entry distance = min of the negated near distances, exit = min of the
-// far ones, and "culled" (exit * widen < entry in real arithmetic) as the SIGN of fma(exit, widen, -entry) -- v_fmamk with the literal, 2 issue clocks -- shifted into a
-// mask with one v_alignbit (mask = mask << 1 | sign).
-#define RL_HSLAB8(w, k) { \
-	const float nx_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, nX_.w)[k], -T.a8n.x, nBx_), fx_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, fX_.w)[k], T.a8f.x, Bfx_); \
-	const float ny_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, nY_.w)[k], -T.a8n.y, nBy_), fy_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, fY_.w)[k], T.a8f.y, Bfy_); \
-	const float nz_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, nZ_.w)[k], -T.a8n.z, nBz_), fz_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, fZ_.w)[k], T.a8f.z, Bfz_); \
+// One child: six planes, the NEGATED entry distance = min of the negated near distances (fma(q, -A, -(B - E)): the modifier is free), exit = min of the far ones,
+// and "culled" (exit * widen < entry in real arithmetic) as the SIGN of fma(exit, widen, -entry) -- with the entry negated the widening is the instruction's literal
+// (v_fmac with a constant: 2 issue clocks; round 4's fma(exit, widen, -entry) held the constant in an SGPR: 4) -- shifted into a mask with one v_alignbit.
+#define RL_QSLAB8(wn, wf, sh) { \
+	const float nx_ = __builtin_fmaf((float)((nX##wn >> sh) & 0xffu), -Ax_, nBx_), fx_ = __builtin_fmaf((float)((fX##wf >> sh) & 0xffu), Ax_, Bfx_); \
+	const float ny_ = __builtin_fmaf((float)((nY##wn >> sh) & 0xffu), -Ay_, nBy_), fy_ = __builtin_fmaf((float)((fY##wf >> sh) & 0xffu), Ay_, Bfy_); \
+	const float nz_ = __builtin_fmaf((float)((nZ##wn >> sh) & 0xffu), -Az_, nBz_), fz_ = __builtin_fmaf((float)((fZ##wf >> sh) & 0xffu), Az_, Bfz_); \
 	const float ntn_ = fminf(ntMin_, __builtin_fminf(__builtin_fminf(nx_, ny_), nz_)), tf_ = fminf(tmxL_, __builtin_fminf(__builtin_fminf(fx_, fy_), fz_)); \
 	culled = __builtin_amdgcn_alignbit(culled, __float_as_uint(__builtin_fmaf(tf_, RL_POOL_WIDEN, ntn_)), 31u); }
+#define RL_SEL8(hi_, lo_, m_) __builtin_amdgcn_bitop3_b32((hi_), (lo_), (m_), 0xE4)   /* (hi & m) | (lo & ~m): truth table over (hi, lo, m) */
 __device__ __forceinline__ bool NodeStep8(const DSceneView& S, Trav& T, float tMin, int* stk, int* ovf, Counters& c, const unsigned char* perm, const uint4* top, const int G, const int GMAX)
 {
 	RL_WSTEP(4);
-	c.nodes++;   // one 128-byte record
+	c.nodes++;   // one 80-byte record
 	// the group's next child in visiting order; the rest of the group, if any, is one stack entry
 	const uint32_t pos = 31u - (uint32_t)__clz((int)T.gy);
 	T.gy &= ~(1u << pos);
 	const uint32_t slot = (pos - 24u) ^ T.oct;
 	const uint32_t node = T.gx + (uint32_t)__popc(T.gy & 0xffu & ((1u << slot) - 1u));
 	if ((T.gy >> 24) != 0u) Push8(T, stk, ovf, G, GMAX);
-#ifdef RL_DIAG_TOPN   /* which nodes the steps go to (breadth-first numbers: a prefix is the top of the tree) and how many groups the stack holds: what an LDS copy of the top would serve */
+#ifdef RL_DIAG_TOPN   /* which nodes the steps go to (breadth-first numbers: a prefix is the top of the tree) and how many groups the stack holds: what an LDS copy of the top serves */
 	if (c.diag) {
 		const uint32_t lim_[8] = { 9u, 22u, 53u, 73u, 128u, 256u, 1024u, 0xffffffffu };
 		uint32_t lo_ = 0;
@@ -2156,38 +2138,41 @@ __device__ __forceinline__ bool NodeStep8(const DSceneView& S, Trav& T, float tM
 		for (int b_ = 0; b_ < 8; ++b_) { const unsigned long long m_ = Ballot((uint32_t)T.sp >= lo_ && (uint32_t)T.sp < dl_[b_]); if (m_ && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)Ballot(1)) - 1u) atomicAdd(&c.diag[CNT_COUNT + 16 + b_], (unsigned long long)__popcll(m_)); lo_ = dl_[b_]; }
 	}
 #endif
-	// eight rows of one line.  The first RL_TOP8_NODES nodes (breadth first: the top of the tree) are read from the workgroup's LDS copy -- ds_read_b128, which the
-	// vector memory path never sees --, the others from global memory: the base is the kernel's (uniform), the offsets are 32-bit -- global_load with an SGPR base,
-	// no 64-bit address arithmetic.
-	const uint32_t at_ = node << 7;
-	const uint32_t ax_ = at_ + T.off8x, ay_ = at_ + T.off8y, az_ = at_ + T.off8z;
-	uint4 h_, k_, nX_, nY_, nZ_, fX_, fY_, fZ_;
+	// five 16-byte rows from global memory: the base is the kernel's (uniform), the offset 32-bit -- global_load with an SGPR base.  (RL_TOP8_NODES > 0, an
+	// experiment: the first nodes -- breadth first, the top of the tree -- from the workgroup's LDS copy: rl_device.h.)
+	const uint32_t at_ = node * 80u;
+	uint4 h_, k_, p0_, p1_, p2_;
+#if RL_TOP8_NODES > 0
 	if (node < (uint32_t)RL_TOP8_NODES) {
-		const char* lp_ = (const char*)top;
-		h_ = *(const uint4*)(lp_ + at_); k_ = *(const uint4*)(lp_ + at_ + 64u);
-		nX_ = *(const uint4*)(lp_ + ax_); nY_ = *(const uint4*)(lp_ + ay_); nZ_ = *(const uint4*)(lp_ + az_);
-		fX_ = *(const uint4*)(lp_ + (ax_ ^ 64u)); fY_ = *(const uint4*)(lp_ + (ay_ ^ 64u)); fZ_ = *(const uint4*)(lp_ + (az_ ^ 64u));
-	} else {
-		const char* np_ = (const char*)S.nodes8;
-		h_ = GLoadU4(np_ + at_, 0); k_ = GLoadU4(np_ + at_, 4);
-		nX_ = GLoadU4(np_ + ax_, 0); nY_ = GLoadU4(np_ + ay_, 0); nZ_ = GLoadU4(np_ + az_, 0);
-		fX_ = GLoadU4(np_ + (ax_ ^ 64u), 0); fY_ = GLoadU4(np_ + (ay_ ^ 64u), 0); fZ_ = GLoadU4(np_ + (az_ ^ 64u), 0);
+		const char* lp_ = (const char*)top + at_;
+		h_ = *(const uint4*)(lp_); k_ = *(const uint4*)(lp_ + 16); p0_ = *(const uint4*)(lp_ + 32); p1_ = *(const uint4*)(lp_ + 48); p2_ = *(const uint4*)(lp_ + 64);
+	} else
+#endif
+	{
+		(void)top;
+		const char* np_ = (const char*)S.nodes8 + at_;
+		h_ = GLoadU4(np_, 0); k_ = GLoadU4(np_, 1); p0_ = GLoadU4(np_, 2); p1_ = GLoadU4(np_, 3); p2_ = GLoadU4(np_, 4);
 	}
+	const float Ax_ = __uint_as_float((h_.w & 0xffu) << 23) * T.inv.x, Ay_ = __uint_as_float(((h_.w >> 8) & 0xffu) << 23) * T.inv.y, Az_ = __uint_as_float(((h_.w >> 16) & 0xffu) << 23) * T.inv.z;
 	const float Bx_ = (__uint_as_float(h_.x) - T.o.x) * T.inv.x, By_ = (__uint_as_float(h_.y) - T.o.y) * T.inv.y, Bz_ = (__uint_as_float(h_.z) - T.o.z) * T.inv.z;
-	// -(B - |B| 2^-21) and B + |B| 2^-21
-	// ... + (the node's extent along the axis) |A| 2^-21 on the far side: one v_fma_mix_f32 (the extents are halves in the header)
-	const float nBx_ = __builtin_fmaf(fabsf(Bx_), 4.76837158e-7f, -Bx_), Bfx_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, h_.w)[1], T.ac8.x, __builtin_fmaf(fabsf(Bx_), 4.76837158e-7f, Bx_));
-	const float nBy_ = __builtin_fmaf(fabsf(By_), 4.76837158e-7f, -By_), Bfy_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, k_.w)[0], T.ac8.y, __builtin_fmaf(fabsf(By_), 4.76837158e-7f, By_));
-	const float nBz_ = __builtin_fmaf(fabsf(Bz_), 4.76837158e-7f, -Bz_), Bfz_ = __builtin_fmaf((float)__builtin_bit_cast(rl_h2, k_.w)[1], T.ac8.z, __builtin_fmaf(fabsf(Bz_), 4.76837158e-7f, Bz_));
+	// (|B| + 255 |A|) * 2^-21, as in RL_WIDE_STEP_Q: four times the rounding of q * A + B against the reference's (bound - o) * inv; -(B - E) and B + E
+	const float Ex_ = fabsf(Ax_ * 1.21593475e-4f) + fabsf(Bx_ * 4.76837158e-7f), Ey_ = fabsf(Ay_ * 1.21593475e-4f) + fabsf(By_ * 4.76837158e-7f), Ez_ = fabsf(Az_ * 1.21593475e-4f) + fabsf(Bz_ * 4.76837158e-7f);
+	const float nBx_ = Ex_ - Bx_, Bfx_ = Bx_ + Ex_, nBy_ = Ey_ - By_, Bfy_ = By_ + Ey_, nBz_ = Ez_ - Bz_, Bfz_ = Bz_ + Ez_;
+	// planes: p0 = qlo x (children 0-3, 4-7), qlo y (0-3, 4-7); p1 = qlo z (0-3, 4-7), qhi x (0-3, 4-7); p2 = qhi y (0-3, 4-7), qhi z (0-3, 4-7)
+	const uint32_t nX0 = RL_SEL8(p1_.z, p0_.x, T.m8x), fX0 = RL_SEL8(p0_.x, p1_.z, T.m8x), nX1 = RL_SEL8(p1_.w, p0_.y, T.m8x), fX1 = RL_SEL8(p0_.y, p1_.w, T.m8x);
+	const uint32_t nY0 = RL_SEL8(p2_.x, p0_.z, T.m8y), fY0 = RL_SEL8(p0_.z, p2_.x, T.m8y), nY1 = RL_SEL8(p2_.y, p0_.w, T.m8y), fY1 = RL_SEL8(p0_.w, p2_.y, T.m8y);
+	const uint32_t nZ0 = RL_SEL8(p2_.z, p1_.x, T.m8z), fZ0 = RL_SEL8(p1_.x, p2_.z, T.m8z), nZ1 = RL_SEL8(p2_.w, p1_.y, T.m8z), fZ1 = RL_SEL8(p1_.y, p2_.w, T.m8z);
 	const float ntMin_ = -tMin, tmxL_ = ClampToFltMax(T.best.t);
 	uint32_t culled = 0u;   // child 7 first: child c ends up in bit c
-	RL_HSLAB8(w, 1) RL_HSLAB8(w, 0) RL_HSLAB8(z, 1) RL_HSLAB8(z, 0) RL_HSLAB8(y, 1) RL_HSLAB8(y, 0) RL_HSLAB8(x, 1) RL_HSLAB8(x, 0)
+	RL_QSLAB8(1, 1, 24) RL_QSLAB8(1, 1, 16) RL_QSLAB8(1, 1, 8) RL_QSLAB8(1, 1, 0)
+	RL_QSLAB8(0, 0, 24) RL_QSLAB8(0, 0, 16) RL_QSLAB8(0, 0, 8) RL_QSLAB8(0, 0, 0)
 	const uint32_t hitSlot = ~culled & 0xffu;
-	// hits -> the next group (inner children, bits moved to visiting order by the workgroup's 8 x 256 table) and the next triangles (leaf children)
-	const uint32_t imask = h_.w & 0xffu;
+	// hits -> the next group (inner children, bits moved to visiting order by the workgroup's 8 x 256 table) and the next triangles (leaf children: their bits as
+	// they are -- LeafStep8 works out which triangle a bit stands for; round 4 spread every bit into a nibble here, ten instructions on every node step)
+	const uint32_t imask = h_.w >> 24;
 	const uint32_t innerP = (uint32_t)perm[T.oct * 256u + (hitSlot & imask)];
 	T.gx = k_.x; T.gy = (innerP << 24) | imask;
-	T.tx = k_.y; T.tz = k_.z; T.ty = (hitSlot & ~imask) | ((h_.w << 8) & 0x00ff0000u);
+	T.tx = k_.y; T.tz = k_.z; T.ty = (hitSlot & ~imask) | ((k_.w & 0xffu) << 16);
 	return Next8(T, stk, ovf, G);
 }
 template <bool PRIMS>
@@ -2310,15 +2295,17 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 	__shared__ float s_pool[RL_BLOCK / 64][PoolOcc<LSTACK, PRIMS, K>::kFields][PP];
 	__shared__ unsigned char s_free[RL_BLOCK / 64][PP];
 	// the 8-wide walk: s_perm[oct * 256 + y] = the byte y with every bit b moved to bit b XOR oct (slot order -> visiting order of a ray of octant oct)
-	// ... and the top of that tree: its first RL_TOP8_NODES nodes (rl_device.h), 128-byte aligned like the nodes in global memory (a row's partner is the row XOR 64)
-	__shared__ __attribute__((aligned(128))) uint4 s_top[WIDE == 3 ? RL_TOP8_NODES * 8 : 1];
+	// ... and the top of that tree: its first RL_TOP8_NODES nodes (rl_device.h), five 16-byte rows each
+	__shared__ uint4 s_top[(WIDE == 3 && RL_TOP8_NODES > 0) ? RL_TOP8_NODES * 5 : 1];
 	__shared__ unsigned char s_perm[WIDE == 3 ? 8 * 256 : 1];
 	if constexpr (WIDE == 3) {
+#if RL_TOP8_NODES > 0
 		{
 			RL_ARGS();
-			const uint32_t rows = (uint32_t)(S.numNodes8 < RL_TOP8_NODES ? S.numNodes8 : RL_TOP8_NODES) * 8u;
-			for (uint32_t i = threadIdx.x; i < (uint32_t)RL_TOP8_NODES * 8u; i += RL_BLOCK) s_top[i] = i < rows ? GLoadU4(S.nodes8, (int)i) : make_uint4(0u, 0u, 0u, 0u);
+			const uint32_t rows = (uint32_t)(S.numNodes8 < RL_TOP8_NODES ? S.numNodes8 : RL_TOP8_NODES) * 5u;
+			for (uint32_t i = threadIdx.x; i < (uint32_t)RL_TOP8_NODES * 5u; i += RL_BLOCK) s_top[i] = i < rows ? GLoadU4(S.nodes8, (int)i) : make_uint4(0u, 0u, 0u, 0u);
 		}
+#endif
 		for (uint32_t i = threadIdx.x; i < 8u * 256u; i += RL_BLOCK) {
 			const uint32_t m = i >> 8, y = i & 255u;
 			uint32_t r = 0;
@@ -2366,7 +2353,7 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 	Trav T;
 	T.o = T.d = T.inv = v3s(0.0f); T.rayTime = 0.0f; T.nx = T.ny = T.nz = T.anyhit = false;
 	T.best.t = INFINITY; T.best.a = T.best.b = 0.0f; T.best.tri = -1; T.cur = IDLE; T.sp = 0; T.leafI = 0;
-	T.gx = T.gy = T.tx = T.ty = T.tz = T.oct = 0u; T.a8n = T.a8f = T.ac8 = v3s(0.0f); T.off8x = T.off8y = T.off8z = 0u;
+	T.gx = T.gy = T.tx = T.ty = T.tz = T.oct = 0u; T.m8x = T.m8y = T.m8z = 0u;
 #ifdef RL_DIAG_STAMPS
 	unsigned long long stampAcc[4] = { 0, 0, 0, 0 };
 	{ RL_ARGS(); c.diag = counters; }
@@ -2419,6 +2406,7 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 			WaveLdsSync();
 			uint32_t filled = 0;
 			for (int round = 0; round < RL_REFILL_ROUNDS && filled < nFree; ++round) {
+				RL_WSTEP(6);   // (level-2 diagnostic build: refill rounds, wave level -- tools/dynamic_mix.py)
 				if (chunkNext >= chunkEnd && !globalDone) {
 					uint32_t base = 0, bend = 0;
 					// (a chunk shared by the workgroup's waves in 64-job batches, as in the leaf-list kernel, was measured here too: 44.5 ms against 43.9)
@@ -2558,7 +2546,7 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 							T.cur = 0; T.sp = 0; T.leafI = 0;
 							if constexpr (WIDE == 3) {
 								// the root as a group of one: base 0, imask 1, its bit at the visiting position of slot 0
-								RaySetup8(S, T);
+								RaySetup8(T);
 								T.gx = 0u; T.gy = (1u << (24u + T.oct)) | 1u; T.tx = T.ty = T.tz = 0u;
 							}
 							mySlot = (int)slot;
@@ -2671,6 +2659,7 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 #ifdef RL_POOL_WATCHDOG
 			if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); wdAbort = true; break; }
 #endif
+			RL_WSTEP(7);   // (level-2 diagnostic build: rounds of hit shading, wave level)
 			const uint32_t idx = shadedEnd + lane;
 			const bool on = idx < nHit;
 			const int slot = on ? (int)freeList[idx] : 0;

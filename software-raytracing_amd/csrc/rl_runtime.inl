@@ -480,7 +480,7 @@ bool UploadScene(Scene& sc)
 		V.numNodes4 = (int32_t)sc.bvh.nodes4.size(); V.numMaterials = (int32_t)mats.size();
 		V.leafList = C->leafList; V.numLeafRecords = C->leafList ? (int32_t)sc.bvh.leafList.size() : 0;
 		V.fastBary = fastBary.load();
-		V.step8 = sc.bvh.step8; V.numNodes8 = (int32_t)sc.bvh.nodes8.size();
+		V.numNodes8 = (int32_t)sc.bvh.nodes8.size();
 
 	}
 	HIP_OK(hipSetDevice(g_rt.devices[0]));
@@ -894,6 +894,8 @@ bool FinishRender(PendingRender& pend, RaylibAMDStats& stats)
 #if defined(RL_DIAG_STAMPS) && RL_DIAG_STAMPS >= 2
 		if (cnt[CNT_COUNT + 7]) Log("leaf list: %llu triangle wave steps taken; %llu if every round's (ray, triangle) pairs were dealt evenly to the wave's 64 lanes (the bound of any regrouping: a round cannot take less than one step)", cnt[CNT_COUNT + 5], cnt[CNT_COUNT + 7]);
 #endif
+		Log("diagnostic slots (wave level): [4] %llu [5] %llu [6] %llu [7] %llu [16] %llu [17] %llu [18] %llu [19] %llu trips %llu", cnt[CNT_COUNT + 4], cnt[CNT_COUNT + 5], cnt[CNT_COUNT + 6], cnt[CNT_COUNT + 7],
+		    cnt[CNT_COUNT + 16], cnt[CNT_COUNT + 17], cnt[CNT_COUNT + 18], cnt[CNT_COUNT + 19], cnt[CNT_TRIPS]);
 		if (tot > 0) Log("shade split (of all): surface+material %.3f scatter %.3f emit+store %.3f", cnt[CNT_COUNT + 8] / tot, cnt[CNT_COUNT + 9] / tot, cnt[CNT_COUNT + 10] / tot);
 		if (tot > 0) Log("microfacet split (of all): setup %.3f beckmann sample %.3f brdf+pdf %.3f | newton wave iters %llu lane iters %llu (eff %.3f) | microfacet wave calls %llu lanes %llu (eff %.3f)", cnt[CNT_COUNT + 12] / tot, cnt[CNT_COUNT + 13] / tot, cnt[CNT_COUNT + 14] / tot, cnt[CNT_COUNT + 16], cnt[CNT_COUNT + 17], cnt[CNT_COUNT + 17] / (64.0 * cnt[CNT_COUNT + 16] + 1), cnt[CNT_COUNT + 18], cnt[CNT_COUNT + 19], cnt[CNT_COUNT + 19] / (64.0 * cnt[CNT_COUNT + 18] + 1));
 		{

@@ -158,12 +158,12 @@ bool Scene::BuildAccel(float t0, float t1)
 		for (DNode4Q& n : bvh.nodes4q) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 		for (DNode4& n : bvh.leafList) for (int k = 0; k < 4; ++k) patch(n.child[k]);
 		for (DNode8& n : bvh.nodes8) {   // the 8-wide node names its leaf children's triangles through triBase + leafMask; the flag is a bit per child
-			n.meta &= 0xffff00ffu;   // imask | alphaMask << 8 | extent x << 16
+			n.alphaMask = 0;
 			for (int c = 0; c < 8; ++c) {
 				const uint32_t nib = (n.leafMask >> (4 * c)) & 15u;
 				if (!nib) continue;
 				const uint32_t first = n.triBase + (uint32_t)__builtin_popcount(n.leafMask & ((1u << (4 * c)) - 1u)), count = (uint32_t)__builtin_popcount(nib);
-				for (uint32_t k = 0; k < count; ++k) if (alpha[bvh.triOrder[first + k]]) { n.meta |= 1u << (8 + c); break; }
+				for (uint32_t k = 0; k < count; ++k) if (alpha[bvh.triOrder[first + k]]) { n.alphaMask |= 1u << c; break; }
 			}
 		}
 	}

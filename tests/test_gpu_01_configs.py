@@ -87,7 +87,7 @@ def test_config2_300k_triangles_1080p_128spp(gpu_lib, oracle, workdir, monkeypat
     # every schedule of the megakernel gives the same bits and the same ray / shading counts (2 spp keeps this part short)
     base = ses.render(1920, 1080, 2)
     sb = ses.stats().as_dict()
-    assert sb["treeWidth"] == 8 and sb["nodeBytes"] == 128    # a scene this deep walks the 8-wide tree by default (RaylibAMD_SceneBVH8Info: 59 expected steps on the 4-wide one)
+    assert sb["treeWidth"] == 8 and sb["nodeBytes"] == 80     # a scene this deep walks the 8-wide tree by default (RaylibAMD_SceneBVH8Info: 59 expected steps on the 4-wide one)
     for env in (dict(RAYLIB_POOL="0"), dict(RAYLIB_POOL_SHORT_STACK="0"), dict(RAYLIB_BVH4="0"), dict(RAYLIB_BVH8="0")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -57,7 +57,7 @@ def test_random_scenes_against_oracle(seed, gpu_lib, oracle, workdir, monkeypatc
             # these scenes are too shallow for the 8-wide tree to be the default (RaylibAMD_SceneBVH8Info): force it, same bits required
             monkeypatch.setenv("RAYLIB_BVH8", "1"); monkeypatch.setenv("RAYLIB_POOL", "2")
             img8 = ses.render(w, h, spp, max_path=max_path)
-            assert ses.stats().treeWidth == 8 and ses.stats().nodeBytes == 128
+            assert ses.stats().treeWidth == 8 and ses.stats().nodeBytes == 80
             monkeypatch.delenv("RAYLIB_BVH8"); monkeypatch.delenv("RAYLIB_POOL")
             assert ((bits(img8) == bits(img)) | (np.isnan(img8) & np.isnan(img))).all(), "case %d: the 8-wide walk differs from the default schedule" % case
         gpu_lib.RaylibAMD_SetSeed(1)

@@ -219,7 +219,7 @@ def test_larger_scenes_carry_a_valid_eight_wide_tree(lib, workdir, monkeypatch):
 
 @pytest.mark.parametrize("make,kw", [(scenes.cornell, dict(tess=24, displace_fraction=0.2)), (scenes.cornell, dict(tess=64, displace_fraction=0.2)),
                                       (scenes.soup, dict(n_tris=6000, seed=9)), (scenes.colonnade, dict(tess=3))], ids=["room_21k", "room_147k_split_leaves", "soup_6k", "colonnade_10k"])
-def test_eight_wide_walk_restated_on_the_host_never_skips_the_closest_hit(make, kw, lib, oracle, workdir):
+def test_eight_wide_walk_restated_on_the_host_never_skips_the_closest_hit(make, kw, lib, oracle, workdir, monkeypatch):
     """The megakernel's 8-wide walk restated on the host (RaylibAMD_SceneWalk8Host: the same float operations as rl_render.hip NodeStep8 -- half-float planes
     through one fma each, the ray's widened factors, visiting order, groups) against the oracle's closest hit: with the exit distance fixed just behind the
     oracle's hit the walk must reach the leaf that holds it, for rays in random directions AND for rays that lie IN the planes of the scene's walls -- second
@@ -229,7 +229,10 @@ def test_eight_wide_walk_restated_on_the_host_never_skips_the_closest_hit(make, 
     from raylib_amd import binding
     d = os.path.join(str(workdir), "walk8_%s_%s" % (make.__name__, "_".join(str(v) for v in kw.values()))); os.makedirs(d, exist_ok=True)
     obj = make(os.path.join(d, "w.obj"), **kw)[0]
+    if kw.get("tess") == 64:
+        monkeypatch.setenv("RAYLIB_W8_SPLIT", "1")          # (rl_bvh.cc SplitLeaves: an option of the builder, off by default)
     ses = binding.SceneSession(lib, obj, (0, 1, 4), (0, 1, -1), 45.0, 1.0)
+    monkeypatch.delenv("RAYLIB_W8_SPLIT", raising=False)
     assert lib.RaylibAMD_SceneBVH8Info(ses.scene, None, None, None, None) == 1
     flat = helpers.objflat.load_obj(obj, oracle)
     sc = oracle.scene_create(flat, 1)

@@ -12,6 +12,8 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# the vector memory path's request rate (round 5): one TCP access per lane and load instruction -- the walk's other ceiling (tools/vmem_width_bench.hip: 1.14 per clock and CU)
+run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR
 run grbm GRBM_GUI_ACTIVE
 # VALU instructions by class: tools/pmc_traffic.py weights them with the issue costs of tools/valu_calib.hip

@@ -86,6 +86,12 @@ for arg in sys.argv[1:]:
         # round 2's figure, kept for comparison: every VALU instruction charged the 2 cycles of a v_fma_f32
         "valu_busy_fraction": 2.0 * m["SQ_INSTS_VALU"] / SIMDS / cycles,
         "wave_wait_fraction": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
+        # the vector memory path's request rate: TCP accesses (one per lane and load instruction, whatever its width) per clock and CU, against the 1.14 a kernel
+        # of nothing but scattered loads reaches (tools/vmem_width_bench.hip: 0.88 clocks per lane-load)
+        "tcp_accesses_per_launch": m.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
+        "tcp_accesses_per_clock_and_cu": (m["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cycles) if m.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+        "tcp_request_ceiling_per_clock_and_cu": 1.0 / 0.88,
+        "vmem_rd_insts_per_launch": m.get("SQ_INSTS_VMEM_RD"), "lds_insts_per_launch": m.get("SQ_INSTS_LDS"),
         "waves_per_simd": m["SQ_WAVES"] / SIMDS,
         "salu_insts_per_launch": m.get("SQ_INSTS_SALU"),
         "round": TAG,

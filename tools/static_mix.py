@@ -16,10 +16,14 @@ FAST = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_sub
         "v_lshrrev_b32", "v_mov_b32", "v_fmaak_f32", "v_fmamk_f32", "v_ashrrev_i32", "v_not_b32", "v_nop"}   # 2 issue cycles per wave64 (valu_calib); the rest 4, transcendentals 8 / 16
 F32 = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_fmaak_f32", "v_fmamk_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_mul_legacy_f32"}
 TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
-INT32 = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_mul_lo_u32", "v_mul_hi_u32",
-         "v_mul_u32_u24", "v_mad_u32_u24", "v_mad_i32_i24", "v_mul_i32_i24", "v_bfe_u32", "v_bfe_i32", "v_bfi_b32", "v_and_or_b32", "v_or3_b32", "v_add3_u32", "v_lshl_add_u32", "v_add_lshl_u32",
-         "v_lshl_or_b32", "v_xad_u32", "v_min_u32", "v_max_u32", "v_min3_u32", "v_max3_u32", "v_min_i32", "v_max_i32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32",
-         "v_subrev_co_u32", "v_bcnt_u32_b32", "v_ffbh_u32", "v_ffbl_b32", "v_alignbit_b32", "v_mul_hi_i32", "v_sad_u32")
+# which opcodes the hardware counts under SQ_INSTS_VALU_INT32 was MEASURED in round 5 (tools/valu_class_pmc.sh -> profiles/valu_classes.json): integer add / sub / multiply /
+# mad, compares of integers, bit counts and field extracts, the arithmetic shift right -- and NOT the bit-wise and / or / xor / not, the logical shifts, v_and_or,
+# v_or3, v_bfi, v_lshl_or, v_alignbit, v_perm, v_bitop3, which no class counter sees (rounds 3 - 4 listed them here by guess)
+INT32 = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_ashrrev_i32", "v_mul_lo_u32", "v_mul_hi_u32",
+         "v_mul_u32_u24", "v_mad_u32_u24", "v_mad_i32_i24", "v_mul_i32_i24", "v_bfe_u32", "v_bfe_i32", "v_add3_u32", "v_lshl_add_u32", "v_add_lshl_u32",
+         "v_xad_u32", "v_min_u32", "v_max_u32", "v_min3_u32", "v_max3_u32", "v_min_i32", "v_max_i32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32",
+         "v_subrev_co_u32", "v_bcnt_u32_b32", "v_ffbh_u32", "v_ffbl_b32", "v_mul_hi_i32", "v_sad_u32", "v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32",
+         "v_med3_u32", "v_med3_i32", "v_min3_i32", "v_max3_i32", "v_ffbh_i32")
 INT64 = ("v_mad_u64_u32", "v_mad_i64_i32", "v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64", "v_lshl_add_u64", "v_mov_b64")
 
 
@@ -59,7 +63,7 @@ def classify(op):
         return "F64"
     if b in INT64:
         return "INT64"
-    if b in INT32:
+    if b in INT32 or re.match(r"v_cmpx?_\w+_[ui](16|32)$", b):
         return "INT32"
     return "OTHER"
 
