@@ -35,7 +35,7 @@ typedef struct RaylibAMDStats {
 	                             decided by the root node's two boxes alone is one query that fetched one node record */
 	uint64_t nodesVisited;    /* 64-byte BVH node records fetched (a float-box BVH4 node or a leaf-list record of four boxes counts as two) */
 	uint64_t trisTested;      /* 64-byte triangle intersection records fetched */
-	uint64_t shadedHits;      /* 64-byte triangle shading records fetched */
+	uint64_t shadedHits;      /* 64-byte triangle shading records fetched: one per shaded hit and one per cut-out candidate tested during a walk (the latter depends on the walk's order) */
 	uint64_t texFetches;      /* 16-byte texels fetched (incl. the sky texel k_resolve looks up per sample of a cell outside the scene's silhouette) */
 	uint64_t cameraSamples;   /* (pixel, sample) paths generated and traced by the megakernel (culledSamples are NOT in here: cameraSamples + culledSamples = pixels x spp) */
 	uint64_t pixels;          /* pixels written (16 bytes each) */

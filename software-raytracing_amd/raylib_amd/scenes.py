@@ -366,7 +366,7 @@ def write_textures(directory, textures):
 
 def textured(path, tess=91, displace_fraction=0.2):
     """The configs[2]-sized room with albedo maps on its walls and a fifth of its triangles as alpha-cut-out foliage cards (tess = 91: 298 116 triangles,
-    59 662 of them cards).  Writes <path>.obj, .mtl and the four PNG maps; returns the .obj path and the triangle count."""
+    59 477 of them cards).  Writes <path>.obj, .mtl and the four PNG maps; returns the .obj path and the triangle count."""
     base = os.path.splitext(path)[0]
     A = build_arrays_textured(tess, displace_fraction)
     write_obj_text(base + ".obj", A, os.path.basename(base) + ".mtl")

