@@ -159,7 +159,10 @@ def symbolize(elf, addrs):
             continue
         fn = lines[i]; loc = lines[i + 1] if i + 1 < len(lines) else ""
         m = re.match(r"(.*):(\d+):\d+$", loc)
-        frames.append((fn.split("<")[0].split("::")[-1], int(m.group(2)) if m else 0, os.path.basename(m.group(1)) if m else "?"))
+        name = fn.split("<")[0].split("::")[-1]
+        if name == "TraverseLeafList" and "<true>" in fn:
+            name = "TraverseLeafListAny"   # the occlusion query's copy of the walk (ANYHIT): its own regions -- it runs only for sun queries
+        frames.append((name, int(m.group(2)) if m else 0, os.path.basename(m.group(1)) if m else "?"))
         i += 2
     return out
 
@@ -186,7 +189,7 @@ def source_markers():
             mk["ll_tri_end"] = i
         if "void BeckmannSample11(" in l:
             mk["b11"] = i
-        if "b11" in mk and "newton" not in mk and s.startswith("while (++it < 10) {"):
+        if "b11" in mk and "newton" not in mk and s.startswith("while (++it < "):
             mk["newton"] = i
         if "newton" in mk and "newton_end" not in mk and i > mk["newton"] and s.startswith("b -= value / derivative;"):
             mk["newton_end"] = i + 1
@@ -231,12 +234,13 @@ def region_of(frames, pool, mk):
             if arm:
                 return "scatter: " + arm[-1]
     for f, line, _ in frames:
-        if f == "TraverseLeafList":
+        if f in ("TraverseLeafList", "TraverseLeafListAny"):
+            pre = "leaf list: " if f == "TraverseLeafList" else "sun query's leaf list: "
             if line < mk["ll_from"]:
-                return "leaf list: boxes" if line > mk["ll"] + 12 else "leaf list: set-up"
+                return pre + ("boxes" if line > mk["ll"] + 12 else "set-up")
             if mk["ll_tri"] <= line < mk["ll_tri_end"]:
-                return "leaf list: inside test" if line >= mk.get("ll_inner", 1 << 30) else "leaf list: triangle step"
-            return "leaf list: pick"
+                return pre + ("inside test" if line >= mk.get("ll_inner", 1 << 30) else "triangle step")
+            return pre + "pick"
     if any(n.startswith("NodeStep") for n in names):
         return "node step"
     for f, line, _ in frames:
@@ -297,6 +301,14 @@ def analyse(kernel_mangled, elf, measured):
         regions[r][op] += 1
         if op == "s_swappc_b64" and ktargets.get(addr) in funcs:
             regions[r] += flat(ktargets[addr])
+    # The compiler unrolls the Beckmann sampler's Newton loop (nine copies whatever `#pragma nounroll` says: its trip count is a constant); one RUN of the region
+    # is one iteration, i.e. one copy: every copy evaluates ErfInv once, and ErfInv holds one v_sqrt_f32.
+    nw = regions.get("newton iteration")
+    if nw:
+        copies = max(1, sum(c for op, c in nw.items() if op.startswith("v_sqrt_f32")))
+        if copies > 1:
+            regions["newton iteration"] = collections.Counter({op: c / copies for op, c in nw.items()})
+            print("   (the Newton loop is %d copies in the binary; a run of the region is one of them)" % copies)
     return kname, regions
 
 
