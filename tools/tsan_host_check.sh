@@ -5,8 +5,8 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/libraylib_tsan.so
 SRC="$ROOT/software-raytracing_amd/csrc"
 g++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=thread -ffp-contract=off -DRAYLIB_EXPORTS=1 \
-    -I"$ROOT/include" -I"$SRC" "$SRC"/rl_abi.cc "$SRC"/rl_scene.cc "$SRC"/rl_bvh.cc "$SRC"/rl_obj_loader.cc "$SRC"/rl_image_io.cc "$SRC"/rl_jpeg.cc "$SRC"/rl_log.cc \
+    -I"$ROOT/include" -I"$SRC" "$SRC"/rl_abi.cc "$SRC"/rl_scene.cc "$SRC"/rl_bvh.cc "$SRC"/rl_cull.cc "$SRC"/rl_obj_loader.cc "$SRC"/rl_image_io.cc "$SRC"/rl_jpeg.cc "$SRC"/rl_log.cc \
     "$ROOT/tools/nodevice_stub.cc" -o "$OUT" -lz -lpthread
 cd "$ROOT"
 TSAN_OPTIONS=halt_on_error=1:report_signal_unsafe=0 LD_PRELOAD="$(g++ -print-file-name=libtsan.so)" RAYLIB_LIB="$OUT" \
-    python -m pytest tests/test_host_logic.py -x -q -k "chunking or thread_count"
+    python -m pytest tests/test_host_logic.py -x -q -k "chunking or thread_count or eight_wide_walk"
