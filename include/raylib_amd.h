@@ -183,8 +183,8 @@ RAYLIB_API int32_t RaylibAMD_SceneBVH4Info(SceneHandle scene, uint32_t* outNodes
  * over the 4-wide / 8-wide tree's nodes of (node area / root area) -- the node steps a random ray is expected to take; the megakernel walks the 8-wide
  * tree when outSteps4 >= 40 (RAYLIB_BVH8=0|1 overrides; RaylibAMDStats.treeWidth says which tree a frame walked). */
 RAYLIB_API int32_t RaylibAMD_SceneBVH8Info(SceneHandle scene, uint32_t* outNodes8, uint32_t* outLevels, float* outSteps4, float* outSteps8);
-/* The megakernel's walk of that tree restated on the host, operation by operation in float (csrc/rl_bvh.cc Walk8Host: the ray's widened factors, one fma per
- * half-float plane, visiting order, groups), with the exit distance of ray i fixed at tMax[i]: outT[i] = the least distance among the triangles of the leaf
+/* The megakernel's walk of that tree restated on the host, operation by operation in float (csrc/rl_bvh.cc Walk8Host: the ray's per-node factors and error allowance, one fma per
+ * 8-bit grid plane, octant visiting order, one stack entry per level), with the exit distance of ray i fixed at tMax[i]: outT[i] = the least distance among the triangles of the leaf
  * children the walk reaches (a tolerant double-precision triangle test; FLT_MAX: none), outSteps[i] (may be NULL) the node steps.  No device needed: what the box
  * arithmetic must never do -- skip the leaf of the closest hit -- is checked against the CPU oracle in `pytest -m "not gpu"`.  rays: count x (origin, direction).
  * Returns 1, 0 without such a tree, -1 on a malformed tree. */
