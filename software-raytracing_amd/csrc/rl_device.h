@@ -146,6 +146,7 @@ static_assert(sizeof(DMaterial) == 80, "DMaterial");
 
 // Texture descriptor; texels are float RGBA (16 B) in one pool, row 0 = top
 // (reference render/image.h:88-119 keeps float Pixels too).
+#define RL_LDS_TEXTURES 56   /* texture descriptors a workgroup keeps in LDS (896 B: what the pool kernel's 40 KB share of a CU's LDS has left) */
 struct DTexture {
 	uint32_t offset;   // first texel in the pool
 	int32_t width, height;
@@ -177,8 +178,11 @@ struct DSceneView {
 	int32_t numNodes8;
 	const DTriIsect* isect;
 	const DTriShade* shade;
+	const int32_t* alphaTex;   // per triangle slot: the texture a cut-out test of that triangle reads (its material's converted albedo map), -1: none.  Lets the test inside the walk
+	                           // start its texel fetch from the triangle alone instead of triangle -> material -> texture (nullptr: no material of the scene has a map)
 	const DMaterial* materials;
 	const DTexture* textures;
+	int32_t numTextures;       // (incl. the converted copies of albedo maps) up to RL_LDS_TEXTURES descriptors are read from a copy in LDS: rl_render.hip TexTable
 	const float* texels;       // float4 pool
 	const DSphere* spheres;
 	const DCube* cubes;

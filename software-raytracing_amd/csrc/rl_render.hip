@@ -186,10 +186,22 @@ __device__ __noinline__ float4 TexFetch(const DTexture* textures, const float* t
 	if (srgb) { px.x = rtm::pow_(px.x, 2.2f); px.y = rtm::pow_(px.y, 2.2f); px.z = rtm::pow_(px.z, 2.2f); px.w = rtm::pow_(px.w, 2.2f); }
 	return px;
 }
+// The texture descriptors (first texel, width, height) of a scene with at most RL_LDS_TEXTURES textures are copied to LDS at the top of the pool kernel
+// (RL_TEX_PROLOGUE): a fetch is then descriptor (LDS) -> texel instead of two dependent trips through the vector memory pipeline.  TexFetch takes a generic
+// pointer and loads through it with a flat instruction, which serves either address space.  Only in the pool schedule's translation unit: k_trace renders the
+// scenes of a few hundred triangles, where a texel fetch is rare, and the Cornell frame was 0.6 % slower with the table in its kernel (12.36 against 12.28 ms).
+#ifdef RL_TU_POOL
+__shared__ DTexture rl_lds_tex[RL_LDS_TEXTURES];
+#define RL_TEX_PROLOGUE(S_) { if ((S_).numTextures <= RL_LDS_TEXTURES) for (int i_ = (int)threadIdx.x; i_ < (S_).numTextures; i_ += (int)blockDim.x) rl_lds_tex[i_] = (S_).textures[i_]; }
+__device__ __forceinline__ const DTexture* TexTable(const DSceneView& S) { return (S.numTextures <= RL_LDS_TEXTURES) ? (const DTexture*)rl_lds_tex : S.textures; }
+#else
+#define RL_TEX_PROLOGUE(S_)
+__device__ __forceinline__ const DTexture* TexTable(const DSceneView& S) { return S.textures; }
+#endif
 __device__ __forceinline__ float4 TexSample(const DSceneView& S, int tex, bool srgb, float u, float v, Counters& c)
 {
 	c.texels++;
-	return TexFetch(S.textures, S.texels, tex, srgb, u, v);
+	return TexFetch(TexTable(S), S.texels, tex, srgb, u, v);
 }
 
 struct Mat {   // DMaterial in registers
@@ -293,22 +305,27 @@ __device__ __forceinline__ Shade LoadShade(const DSceneView& S, int i) { return 
 
 // MicrofacetMaterial::AlphaTest for a candidate (reference render/material.cc:397-404 via geom/triangle.cc:48-54).
 // Returns bit 0 = passes, bit 1 = a texel was fetched.  Out of line: only leaves flagged as textured reach it.
-__device__ __noinline__ int AlphaTestCandidateNI(const DTriShade* shade, const DMaterial* materials, const DTexture* textures,
+__device__ __noinline__ int AlphaTestCandidateNI(const DTriShade* shade, const int32_t* alphaTex, const DMaterial* materials, const DTexture* textures,
                                                  const float* texels, int tri, float a, float b)
 {
 	const float4* p = (const float4*)(shade + tri);
+	// the texture comes from the per-triangle table (rl_runtime.inl UploadScene), fetched beside the triangle's UVs: one dependent load fewer than through the material
+	int tex = alphaTex ? alphaTex[tri] : 0;
 	const float4 q2 = p[2], q3 = p[3];
 	const float s0 = q2.y, t0 = q2.z, s1 = q2.w, t1 = q3.x, s2 = q3.y, t2 = q3.z;
-	const DMaterial* M = materials + __float_as_int(q3.w);
-	if (M->type != MAT_MICROFACET || M->tex[0] < 0) return 1;
+	if (!alphaTex) {
+		const DMaterial* M = materials + __float_as_int(q3.w);
+		tex = (M->type == MAT_MICROFACET) ? M->tex[0] : -1;
+	}
+	if (tex < 0) return 1;
 	float U = (1 - a - b) * s0 + a * s1 + b * s2;
 	float V = (1 - a - b) * t0 + a * t1 + b * t2;
-	float4 px = TexFetch(textures, texels, M->tex[0], false, U, V);   // tex[0] points at the pow(2.2) copy made at upload
+	float4 px = TexFetch(textures, texels, tex, false, U, V);   // the pow(2.2) copy made at upload
 	return (px.w >= 0.5f ? 1 : 0) | 2;
 }
 __device__ __forceinline__ bool AlphaTestCandidate(const DSceneView& S, int tri, float a, float b, Counters& c)
 {
-	const int r = AlphaTestCandidateNI(S.shade, S.materials, S.textures, S.texels, tri, a, b);
+	const int r = AlphaTestCandidateNI(S.shade, S.alphaTex, S.materials, TexTable(S), S.texels, tri, a, b);
 	c.shaded++;
 	if (r & 2) c.texels++;
 	return (r & 1) != 0;
@@ -1468,6 +1485,7 @@ k_trace(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, SampleRGB*
         float* __restrict__ pathStackK, unsigned long long* __restrict__ countersK, unsigned int* __restrict__ jobCounterK)
 {
 	(void)Pk; (void)Sk; (void)Rk; (void)samplesK; (void)pathStackK; (void)countersK; (void)jobCounterK;
+	RL_TEX_PROLOGUE(Sk);
 	RL_MATH_PROLOGUE();
 	__shared__ int s_stack[STACK * RL_BLOCK];
 	__shared__ float4 s_scene[LDS ? LdsAt<LDS>::TOTAL : 1];
@@ -2291,6 +2309,7 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 #else
 {
 	(void)Pk; (void)Sk; (void)Rk; (void)samplesK; (void)pathStackK; (void)countersK; (void)jobCounterK;   // read through RL_ARGS() where a part of the loop needs them (k_trace)
+	RL_TEX_PROLOGUE(Sk);
 	RL_MATH_PROLOGUE();
 	constexpr int PP = 64 * K;
 	static_assert(LSTACK <= STACK, "the LDS part cannot exceed the stack");
@@ -2820,6 +2839,7 @@ template <int STACK, bool PRIMS>
 __global__ void __launch_bounds__(RL_BLOCK)
 k_aov(const DRenderParams P, const DSceneView S, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
+	RL_TEX_PROLOGUE(S);
 	RL_MATH_PROLOGUE();
 	__shared__ int s_stack[STACK * RL_BLOCK];
 	int* stk = s_stack + threadIdx.x;
@@ -2893,6 +2913,7 @@ template <int STACK, bool PRIMS>
 __global__ void __launch_bounds__(RL_BLOCK)
 k_closest_hit(const DSceneView S, const float* __restrict__ rays, int n, float tMin, DHitOut* __restrict__ out)
 {
+	RL_TEX_PROLOGUE(S);
 	RL_MATH_PROLOGUE();
 	__shared__ int s_stack[STACK * RL_BLOCK];
 	int* stk = s_stack + threadIdx.x;
@@ -2959,6 +2980,7 @@ k_pp_map(float4* __restrict__ px, size_t n, const unsigned int* __restrict__ whi
 __global__ void __launch_bounds__(RL_BLOCK)
 k_eval_scatter(const DSceneView S, int material, const float* __restrict__ in, int n, unsigned long long seed, float* __restrict__ out)
 {
+	RL_TEX_PROLOGUE(S);
 	RL_MATH_PROLOGUE();
 	const int i = blockIdx.x * RL_BLOCK + threadIdx.x;
 	if (i >= n) return;

@@ -25,7 +25,7 @@ namespace rl {
 struct DeviceSceneCopy {
 	int device = 0;
 	DNode4Q* nodes4 = nullptr; DNode4* nodes4f = nullptr; DNode4* leafList = nullptr; DNode8* nodes8 = nullptr;
-	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr;
+	DNode* nodes = nullptr; DTriIsect* isect = nullptr; DTriShade* shade = nullptr; int32_t* alphaTex = nullptr;
 	DMaterial* materials = nullptr; DTexture* textures = nullptr; float* texels = nullptr;
 	DSphere* spheres = nullptr; DCube* cubes = nullptr;
 	// the sky panorama is read when a render starts, as the reference does (renderer.cc:159-176 dereferences the handle per miss)
@@ -302,7 +302,7 @@ void FreeCopy(DeviceSceneCopy* C)
 {
 	if (!C) return;
 	(void)hipSetDevice(C->device);
-	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4f) (void)hipFree(C->nodes4f); if (C->nodes8) (void)hipFree(C->nodes8); if (C->leafList) (void)hipFree(C->leafList); (void)hipFree(C->isect); (void)hipFree(C->shade);
+	(void)hipFree(C->nodes); if (C->nodes4) (void)hipFree(C->nodes4); if (C->nodes4f) (void)hipFree(C->nodes4f); if (C->nodes8) (void)hipFree(C->nodes8); if (C->leafList) (void)hipFree(C->leafList); (void)hipFree(C->isect); (void)hipFree(C->shade); if (C->alphaTex) (void)hipFree(C->alphaTex);
 	(void)hipFree(C->materials); (void)hipFree(C->textures); (void)hipFree(C->texels); (void)hipFree(C->spheres); (void)hipFree(C->cubes);
 	if (C->sky) (void)hipFree(C->sky);
 	delete C;
@@ -407,6 +407,21 @@ bool UploadScene(Scene& sc)
 			m.tex[0] = converted[src];
 		}
 	}
+	// The cut-out test of a candidate (geom/triangle.cc:54 -> MicrofacetMaterial::AlphaTest) needs one texel of the triangle's material's albedo map: as a table per
+	// triangle slot the texture is known from the triangle alone, and the test's chain of dependent loads inside the walk is triangle -> texture -> texel instead
+	// of triangle -> material -> texture -> texel (round 5).
+	std::vector<int32_t> alphaTex;
+	{
+		bool any = false;
+		for (const DMaterial& m : mats) if (m.type == MAT_MICROFACET && m.tex[0] >= 0) any = true;
+		if (any) {
+			alphaTex.resize(n);
+			for (size_t k = 0; k < n; ++k) {
+				const int32_t mi = shade[k].material;
+				alphaTex[k] = (mi >= 0 && (size_t)mi < mats.size() && mats[(size_t)mi].type == MAT_MICROFACET && mats[(size_t)mi].tex[0] >= 0) ? mats[(size_t)mi].tex[0] : -1;
+			}
+		}
+	}
 	std::vector<DSphere> dsph(sc.spheres.size());
 	for (size_t i = 0; i < dsph.size(); ++i) {
 		memset(&dsph[i], 0, sizeof(DSphere));
@@ -466,12 +481,13 @@ bool UploadScene(Scene& sc)
 		if (ok && wantFull) ok = Upload(C->nodes4f, sc.bvh.nodes4.data(), sc.bvh.nodes4.size());
 		if (ok && wantFull && !sc.bvh.leafList.empty()) ok = Upload(C->leafList, sc.bvh.leafList.data(), sc.bvh.leafList.size());
 		ok = ok && Upload(C->isect, isect.data(), n) && Upload(C->shade, shade.data(), n);
+		if (ok && !alphaTex.empty()) ok = Upload(C->alphaTex, alphaTex.data(), alphaTex.size());
 		ok = ok && Upload(C->materials, mats.data(), mats.size()) && Upload(C->textures, texs.data(), texs.size()) && Upload(C->texels, pool.data(), pool.size());
 		ok = ok && Upload(C->spheres, dsph.data(), dsph.size()) && Upload(C->cubes, dcub.data(), dcub.size());
 		if (!ok) { Log("UploadScene: device %d could not take the scene", C->device); FreeScene(D); return false; }   // nothing of a failed upload is left behind
 		DSceneView& V = C->view;
-		V.nodes = C->nodes; V.nodes4 = C->nodes4; V.nodes4f = C->nodes4f; V.nodes8 = C->nodes8; V.isect = C->isect; V.shade = C->shade; V.materials = C->materials;
-		V.textures = C->textures; V.texels = C->texels; V.spheres = C->spheres; V.cubes = C->cubes;
+		V.nodes = C->nodes; V.nodes4 = C->nodes4; V.nodes4f = C->nodes4f; V.nodes8 = C->nodes8; V.isect = C->isect; V.shade = C->shade; V.alphaTex = C->alphaTex; V.materials = C->materials;
+		V.textures = C->textures; V.numTextures = (int32_t)texs.size(); V.texels = C->texels; V.spheres = C->spheres; V.cubes = C->cubes;
 		V.sunIlluminance[0] = sc.sunIlluminance.x; V.sunIlluminance[1] = sc.sunIlluminance.y; V.sunIlluminance[2] = sc.sunIlluminance.z;
 		V.sunDirection[0] = sc.sunDirection.x; V.sunDirection[1] = sc.sunDirection.y; V.sunDirection[2] = sc.sunDirection.z;
 		V.sky = nullptr; V.skyWidth = V.skyHeight = 0;
