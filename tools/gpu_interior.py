@@ -1,5 +1,6 @@
 """The 298 k-triangle room from inside (bench.py's breakfast_interior workload at SPP samples): time and per-ray counts of the launch, for A/B runs with environment
-switches (RAYLIB_BVH8=0|1 ...) or RAYLIB_LIB variants.  usage: [SPP=64] python tools/gpu_interior.py [tag]"""
+switches (RAYLIB_BVH8=0|1 ...) or RAYLIB_LIB variants.  usage: [SPP=64] [TESS=91] [W=1920 H=1080] python tools/gpu_interior.py [tag]      (TESS=530: the 10.1 M-triangle room;
+the big scenes are written by the oracle library's OBJ writer, as in tests/helpers.big_scene)"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
@@ -7,14 +8,22 @@ from raylib_amd import binding, scenes
 lib = binding.load(); assert lib.Raylib_Initialize() == 1
 lib.RaylibAMD_SetSeed(1)
 d = tempfile.mkdtemp()
-obj, _ = scenes.cornell(os.path.join(d, "b.obj"), tess=91, displace_fraction=0.2)
+tess = int(os.environ.get("TESS", "91"))
+if tess <= 128:
+    obj, _ = scenes.cornell(os.path.join(d, "b.obj"), tess=tess, displace_fraction=0.2)
+else:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    cam0 = scenes.CONFIG_CAMERAS["breakfast_interior"]
+    obj, _ = helpers.big_scene(os.path.join(d, "b.obj"), scenes.cornell_objects(), scenes.CORNELL_MTL, helpers.ffi.load_oracle(), tess, 0.2, sun=cam0["sun"], sun_dir=cam0["sun_dir"])
 cam = scenes.CONFIG_CAMERAS["breakfast_interior"]
 spp = int(os.environ.get("SPP", "64"))
-ses = binding.SceneSession(lib, obj, cam["origin"], cam["look_at"], cam["fov"], 1920 / 1080, sun=cam["sun"], sun_dir=cam["sun_dir"])
-ses.render(1920, 1080, 2)
+W, H = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
+ses = binding.SceneSession(lib, obj, cam["origin"], cam["look_at"], cam["fov"], W / H, sun=cam["sun"], sun_dir=cam["sun_dir"])
+ses.render(W, H, 2)
 best = None
 for _ in range(3):
-    ses.render(1920, 1080, spp); s = ses.stats()
+    ses.render(W, H, spp); s = ses.stats()
     if best is None or s.traceKernelMs < best.traceKernelMs: best = s
 s = best
 print("%s: %d spp %.1f ms, %.0f Mrays/s, %.2f node records/ray, %.2f tris/ray, %.2f rays/sample" % (sys.argv[1] if len(sys.argv) > 1 else "interior", spp, s.traceKernelMs, s.rays / s.traceKernelMs / 1e3, s.nodesVisited / s.rays, s.trisTested / s.rays, s.rays / s.cameraSamples), flush=True)
