@@ -116,3 +116,56 @@ def test_scene_with_tga_bmp_jpeg_png_hdr_maps_and_an_hdr_sky(gpu_lib, oracle, wo
     oracle.scene_destroy(scene)
     lib.Raylib_DestroyImage(sky_h)
     ses.close()
+
+
+def test_more_textures_than_the_pool_kernel_keeps_in_lds(gpu_lib, oracle, workdir, monkeypatch):
+    """64 materials with a map each (+ their 64 converted copies: 128 texture descriptors, RL_LDS_TEXTURES is 56): the pool kernel then reads descriptors from
+    global memory (rl_render.hip TexTable), a scene of four maps from its LDS copy -- both must give the oracle's image, and the pool kernel's frame must be
+    k_trace's bit for bit.  Every second map has holes (alpha 0 texels): the cut-out test inside the walk takes its texture from the per-triangle table."""
+    from raylib_amd import binding
+    d = os.path.join(str(workdir), "many_maps"); os.makedirs(d, exist_ok=True)
+    rng = np.random.RandomState(11)
+    N = 64
+    mtl, objs, tex = [], [], {}
+    for i in range(N):
+        name = "m%02d" % i
+        img = rng.randint(40, 255, (4, 4, 4)).astype(np.uint8)
+        img[..., 3] = 255
+        if i % 2:
+            img[rng.randint(0, 4, 5), rng.randint(0, 4, 5), 3] = 0          # holes
+        tex["map_%02d.png" % i] = img
+        mtl.append("newmtl %s\nNs 10\nKd 0.8 0.8 0.8\nKs 0 0 0\nmap_Kd map_%02d.png\nillum 2\n" % (name, i))
+        x0, y0 = -1.0 + 0.25 * (i % 8), 0.0 + 0.25 * (i // 8)
+        z = -0.9 + 0.02 * i                                                  # a staircase of cards: rays that pass a hole meet the next card
+        objs.append((name, name, [scenes._quad((x0, y0, z), (x0 + 0.25, y0, z), (x0 + 0.25, y0 + 0.25, z), (x0, y0 + 0.25, z))]))
+    objs += [o for o in scenes.cornell_objects() if o[0] in ("floor", "backwall", "light")]
+    obj, n = scenes.write_obj(os.path.join(d, "many.obj"), objs, scenes.CORNELL_MTL, tess=3, extra_mtl="\n" + "\n".join(mtl))
+    scenes.write_textures(d, tex)
+    assert n >= 256      # (the pool schedule's class)
+    cam = dict(origin=(0.0, 1.0, 3.5), look_at=(0.0, 1.0, -1.0), fov=45.0)
+    loader = lambda p: scenes.texture_as_float(tex[os.path.basename(p)]) if os.path.basename(p) in tex else None
+    flat = objflat.load_obj(obj, oracle, texture_loader=loader)
+    assert len(flat.textures) == N
+    scene = oracle.scene_create(flat, 1)
+    ocam = ffi.make_camera(cam["origin"], cam["look_at"], cam["fov"], 1.0)
+    ses = binding.SceneSession(gpu_lib, obj, cam["origin"], cam["look_at"], cam["fov"], 1.0)
+    assert gpu_lib.RaylibAMD_SceneNumTextures(ses.scene) == N
+    frames = {}
+    for pool in ("2", "0"):
+        monkeypatch.setenv("RAYLIB_POOL", pool)
+        frames[pool] = ses.render(96, 96, 8)
+        st = ses.stats().as_dict()
+        assert st["pathsPerWave"] == (128 if pool == "2" else 64) and st["texFetches"] > 0
+    monkeypatch.delenv("RAYLIB_POOL")
+    assert np.array_equal(helpers.bits(frames["2"]), helpers.bits(frames["0"])), "the pool kernel (descriptors from global memory) and k_trace differ"
+    want = oracle.render(scene, ocam, ffi.make_settings(96, 96, 8), seed=1)
+    differ = ~helpers.same(frames["2"][..., :3], want[..., :3]).all(-1)
+    untied = 0
+    for (py, px) in zip(*np.nonzero(differ)):
+        oracle.render_region(scene, ocam, ffi.make_settings(96, 96, 8), int(px), int(py), 1, 1, seed=1)
+        cn = oracle.counters(scene)
+        if not (cn["closest_hit_ties"] > 0 or cn["hits_outside_own_box"] > 0):
+            untied += 1
+    assert untied == 0 and differ.sum() <= 40, (int(differ.sum()), untied)
+    oracle.scene_destroy(scene)
+    ses.close()
