@@ -11,6 +11,8 @@ d = tempfile.mkdtemp()
 which = sys.argv[1] if len(sys.argv) > 1 else "cornell"
 if which == "cornell":
     cam = scenes.CONFIG_CAMERAS["cornell"]; obj, _ = scenes.cornell(os.path.join(d, "c.obj")); spp = 64
+elif which == "textured":   # the 298 k room with albedo maps and alpha-cut-out foliage cards, camera inside (bench.py's extra_textured)
+    cam = scenes.CONFIG_CAMERAS["breakfast_interior"]; obj, _ = scenes.textured(os.path.join(d, "t.obj")); spp = int(os.environ.get("SPP", "128"))
 else:   # "breakfast" (the configs[2] stand-in seen from outside) or "interior" (the same scene, camera inside)
     cam = scenes.CONFIG_CAMERAS["breakfast_interior" if which == "interior" else "breakfast"]; obj, _ = scenes.cornell(os.path.join(d, "b.obj"), tess=91, displace_fraction=0.2); spp = int(os.environ.get("SPP", "128"))
 ses = binding.SceneSession(lib, obj, cam["origin"], cam["look_at"], cam["fov"], 1920 / 1080, sun=cam["sun"], sun_dir=cam["sun_dir"])
