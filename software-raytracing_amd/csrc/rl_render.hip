@@ -1940,6 +1940,13 @@ enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_T, F_TRI, F_A, F_B, F_TIME, F_C
 #ifndef RL_POOL_BOTH8
 #define RL_POOL_BOTH8 0
 #endif
+#ifndef RL_POOL_SHADE_MIN
+// Hits wait in their pool slots until a shading round is worth running.  Until round 5 that meant a full wave of 64: the material code then always ran with every lane, and on
+// average half a round's worth of finished hits -- a quarter of the pool's 128 slots -- sat parked instead of holding rays for the traversal phase, whose lanes run
+// dry towards its end.  From 32 waiting hits on a round runs at once: 298 k room from inside 88.3 -> 85.5 ms, from outside 34.9 -> 33.8, colonnade 375.6 -> 363.6,
+// 2.36 M 97.4 -> 94.5, 10.1 M 271.1 -> 267.2, textured room 102.0 -> 98.1 (thresholds 8 ... 48 are within 0.5 % of each other; profiles/r05_shade_min_ab.log).
+#define RL_POOL_SHADE_MIN 32
+#endif
 #ifndef RL_POOL_WLEAF8
 #define RL_POOL_WLEAF8 12   /* 298 k-triangle room from inside: 6 -> 365.7 ms, 9 -> 358.9, 12 -> 357.8, 16 -> 360.9 (the 4-wide tree: 381.4) */
 #endif
@@ -2679,7 +2686,7 @@ k_trace_pool(const DRenderParams Pk, const DSceneView Sk, const SkyRot Rk, Sampl
 		for (;;) {
 			RL_ARGS();
 			if (shadedEnd >= nHit) break;
-			if (nHit - shadedEnd < 64u && !exhausted) break;   // once the job queue is empty no refill will top the list up: waiting only stretches the tail
+			if (nHit - shadedEnd < (uint32_t)RL_POOL_SHADE_MIN && !exhausted) break;   // once the job queue is empty no refill will top the list up: waiting only stretches the tail
 #ifdef RL_POOL_WATCHDOG
 			if (++wdSteps > 400000u) { if (lane == 0) atomicAdd(&counters[CNT_COUNT + 20], 1ull); wdAbort = true; break; }
 #endif
