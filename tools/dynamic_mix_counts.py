@@ -1,4 +1,4 @@
-"""profiles/dynamic_mix_counts.json from the level-2 diagnostic build's wave-level step counters (tools/gpu_stamps.py cornell | breakfast | interior, the lines
+"""profiles/dynamic_mix_counts.json from the level-2 diagnostic build's wave-level step counters (tools/gpu_stamps.py cornell | breakfast | interior | textured, the lines
 "<workload>: ... diagnostic slots (wave level): [4] .. [5] .. [6] .. [7] .. [16] .. [17] .. [18] .. [19] .. trips .."; the LAST such line of a workload is the full frame).
 usage: python tools/dynamic_mix_counts.py <file with those lines>"""
 import json, os, re, sys
@@ -14,9 +14,11 @@ if "cornell" in last:
     s4, s5, s6, s7, s16, s17, s18, s19, trips = last["cornell"]
     out["cornell_1080p_64spp"] = dict(zero, **{"leaf list: boxes": s4 // 6, "leaf list: set-up": s4 // 6, "leaf list: pick": s6, "leaf list: triangle step": s5, "newton iteration": s16,
                                                  "scatter: microfacet": s18, "traverse: glue": trips, "shade": trips, "miss + fold": trips, "tree walk": 0})
-for key, wl in (("breakfast", "breakfast_300k_1080p_128spp"), ("interior", "breakfast_interior_300k_1080p_128spp")):
+for key, wl in (("breakfast", "breakfast_300k_1080p_128spp"), ("interior", "breakfast_interior_300k_1080p_128spp"), ("textured", "breakfast_textured_interior_300k_1080p_128spp")):
     if key in last:
         s4, s5, s6, s7, s16, s17, s18, s19, trips = last[key]
+        if key == "textured":
+            zero = dict(zero); zero.pop("texel fetch")      # (texel fetches run there: their count is not measured at wave level, the fit keeps it free)
         out[wl] = dict(zero, **{"node step": s4, "triangle step": s5, "traversal: turn": s4 + s5, "refill": s6, "shade: a round of hits": s7, "newton iteration": s16, "scatter: microfacet": s18,
                                 "shade: misses + hand-back": trips})
 json.dump(out, open(os.path.join(ROOT, "profiles", "dynamic_mix_counts.json"), "w"), indent=1)

@@ -25,11 +25,11 @@ python3 /root/repo/tools/static_mix.py > $OUT/static_mix.json 2>$OUT/static_mix.
 ROUND_TAG=$TAG python3 /root/repo/tools/pmc_traffic.py cornell_1080p_64spp=$OUT/pmc_cornell_1080p_64spp breakfast_300k_1080p_128spp=$OUT/pmc_breakfast_300k_1080p_128spp breakfast_interior_300k_1080p_128spp=$OUT/pmc_breakfast_interior_300k_1080p_128spp breakfast_textured_interior_300k_1080p_128spp=$OUT/pmc_breakfast_textured_interior_300k_1080p_128spp > $OUT/pmc_traffic.log 2>&1
 # wave-level step counts of the level-2 diagnostic build (libraylib_stamps2.so: make variant VARIANT=stamps2 EXTRA=-DRL_DIAG_STAMPS=2) and the mix weighted by them
 if [ -f /root/repo/software-raytracing_amd/libraylib_stamps2.so ]; then
-  for w in cornell breakfast interior; do RAYLIB_LIB=/root/repo/software-raytracing_amd/libraylib_stamps2.so python3 /root/repo/tools/gpu_stamps.py $w 2>&1 | grep -E "diagnostic slots|trace " | sed "s/^/$w: /"; done > $OUT/diag_wave_steps.txt 2>&1
+  for w in cornell breakfast interior textured; do RAYLIB_LIB=/root/repo/software-raytracing_amd/libraylib_stamps2.so python3 /root/repo/tools/gpu_stamps.py $w 2>&1 | grep -E "diagnostic slots|trace " | sed "s/^/$w: /"; done > $OUT/diag_wave_steps.txt 2>&1
   python3 /root/repo/tools/dynamic_mix_counts.py $OUT/diag_wave_steps.txt > $OUT/dynamic_mix_counts.log 2>&1
   cp /root/repo/profiles/dynamic_mix_counts.json $OUT/dynamic_mix_counts.json
 fi
-python3 /root/repo/tools/dynamic_mix.py cornell_1080p_64spp,breakfast_300k_1080p_128spp,breakfast_interior_300k_1080p_128spp > $OUT/dynamic_mix.txt 2>&1
+python3 /root/repo/tools/dynamic_mix.py cornell_1080p_64spp,breakfast_300k_1080p_128spp,breakfast_interior_300k_1080p_128spp,breakfast_textured_interior_300k_1080p_128spp > $OUT/dynamic_mix.txt 2>&1
 cp /root/repo/profiles/pmc_traffic.json $OUT/pmc_traffic.json
 # the bench lines, now carrying this round's counters: the default invocation (headline + extra + cpu baseline) and the second workload on its own
 python3 /root/repo/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
